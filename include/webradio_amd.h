@@ -1,0 +1,222 @@
+/*
+ * webradio_amd.h -- C ABI of the MI355X (gfx950) backend for webradio's per-tuner
+ * DSP hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its "plugin" interface
+ * is the C++ virtual operator DspBlock (init/deinit/process, dsp/dspblock.h:82-84)
+ * and the setters its callers use.  Each entry point below replaces the body of
+ * one of those members; the host-side classes in webradio_amd/host/ keep the
+ * reference's class names and signatures and forward to these functions, so
+ * radio.cxx compiles against them unchanged (INTEGRATION.md shows the stub a
+ * webradio maintainer would add to the upstream classes instead).
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller-owned buffers with explicit sizes
+ *   - every function returns WR_OK (0) or a WR_ERR_* code; wr_last_error() gives a
+ *     thread-local message.  The host classes map != WR_OK to `return false`
+ *     from init()/process(), which is the reference's only error channel
+ *     (dspblock.cxx:114-117,192-195).
+ *   - "frames" are IQ pairs (one sample instant); IQ is interleaved float32
+ *     [I0,Q0,I1,Q1,...] exactly like the reference's vector<sample_t> buffers.
+ *   - pointers named *_dev are HIP device pointers on the context's device;
+ *     pointers named *_host are ordinary host memory.
+ *   - all work of one wr_dev is issued on one HIP stream (given by the caller, e.g.
+ *     torch.cuda.current_stream().cuda_stream, or created by wr_dev_open).
+ *     Functions taking host pointers synchronise that stream before returning;
+ *     functions taking only device pointers are asynchronous.
+ *   - there is NO CPU fallback: without a GPU wr_dev_open fails with
+ *     WR_ERR_NODEV and nothing else can be created.
+ *
+ * Reference paths are relative to webradio's src/.
+ */
+#ifndef WEBRADIO_AMD_H_
+#define WEBRADIO_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WR_ABI_VERSION   1
+#define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
+#define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
+
+enum wr_status {
+	WR_OK = 0,
+	WR_ERR_ARG = 1,          /* bad argument (NULL, size, not a power of two, ...) */
+	WR_ERR_HIP = 2,          /* a HIP runtime call or kernel launch failed */
+	WR_ERR_STATE = 3,        /* call not legal in this state */
+	WR_ERR_NOMEM = 4,
+	WR_ERR_NODEV = 5,        /* no usable gfx950 device: the product has no CPU path */
+	WR_ERR_RATE = 6          /* rates not integer related (dspblock.cxx:119-130) */
+};
+
+/* dsp/demodulator.h:40-46 enum Mode, same numbering */
+enum wr_mode { WR_AM = 0, WR_FM = 1, WR_USB = 2, WR_LSB = 3 };
+
+/* pipeline stages of one receiver chain (radio.cxx:68-76) that can be fetched */
+enum wr_stage {
+	WR_STAGE_CHAN_IQ = 1,    /* output of Receiver::_channelFilter  (2 ch) */
+	WR_STAGE_DEMOD   = 2,    /* output of Receiver::_demodulator    (1 ch) */
+	WR_STAGE_AUDIO   = 3     /* output of Receiver::_audioFilter    (1 ch) */
+};
+
+/* how the NCO sine/cosine of dsp/downconverter.cxx:100-101 is obtained */
+enum wr_nco {
+	WR_NCO_SPLIT = 0,        /* default: exact integer phase, sin/cos from two 256-entry
+	                            LDS tables (coarse x fine angle addition); LO within
+	                            3.5e-7 of the reference table entry */
+	WR_NCO_EXACT = 1         /* the reference's own 65536-entry sinf table, gathered from
+	                            global memory, unfused multiply/add in the reference's
+	                            order: channel-filter output is bit-identical */
+};
+
+enum wr_where { WR_HOST = 0, WR_DEVICE = 1 };
+
+typedef struct wr_dev      wr_dev;
+typedef struct wr_tuner    wr_tuner;
+typedef struct wr_spectrum wr_spectrum;
+
+/* ------------------------------------------------------------------ misc -- */
+int         wr_abi_version(void);
+const char *wr_last_error(void);
+int         wr_device_count(int *count);
+
+/* --------------------------------------------- host-side design helpers -- */
+/* DownConverter::init / setIF: phaseStep = (int)((int64)hz * 2^31 / (int64)rate)
+ * (dsp/downconverter.cxx:65,80) */
+int wr_phase_step(int if_hz, unsigned int input_rate, int *phase_step);
+/* DownConverter ctor table (dsp/downconverter.cxx:49-51); table[65536] */
+int wr_sin_table(float *table_host);
+/* LowPass::init window + LowPass::recalculate (dsp/lowpass.cxx:104-110,164-189):
+ * 64 taps for `passband` Hz at `input_rate`; *maxbin_out (optional) receives the
+ * integer cut-off bin of lowpass.cxx:167 */
+int wr_lowpass_design(unsigned int passband, unsigned int input_rate,
+                      float *coeff_host /* [64] */, unsigned int *maxbin_out);
+/* SpectrumSink::init window (io/spectrumsink.cxx:71-74); window[fft_size] */
+int wr_spectrum_window(unsigned int fft_size, float *window_host);
+
+/* ---------------------------------------------------------- device ctx -- */
+/* Binds a device and a stream, uploads the NCO tables.  `hip_stream` is a
+ * hipStream_t (may be NULL: a private stream is created). */
+int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream);
+int wr_dev_close(wr_dev *dev);
+int wr_dev_sync(wr_dev *dev);
+void *wr_dev_stream(wr_dev *dev);
+/* device memory for callers without another allocator (the C++ host classes) */
+int wr_dev_malloc(wr_dev *dev, size_t bytes, void **ptr_dev);
+int wr_dev_free(wr_dev *dev, void *ptr_dev);
+int wr_dev_upload(wr_dev *dev, void *dst_dev, const void *src_host, size_t bytes);    /* sync */
+int wr_dev_download(wr_dev *dev, void *dst_host, const void *src_dev, size_t bytes);  /* sync */
+
+/* ------------------------------------------- one kernel per reference block -- */
+/* DownConverter::process (dsp/downconverter.cxx:91-114).  Frame n uses phase
+ * (*phase_io + n*phase_step) mod 2^31; on return *phase_io is the phase after the
+ * block (the member DownConverter::phase).  Bit-identical to the reference. */
+int wr_mix(wr_dev *dev, const float *in_dev, float *out_dev, size_t nframes,
+           unsigned int *phase_io, int phase_step);
+
+/* LowPass::process (dsp/lowpass.cxx:131-162) for `channels` interleaved channels.
+ * history_dev holds (63*channels) floats: the last 63 input frames of the previous
+ * call (zeros at start, lowpass.cxx:138-139); it is updated in place.
+ * out_dev receives (nframes/decimation)*channels floats.  Bit-identical. */
+int wr_fir_decimate(wr_dev *dev, const float *in_dev, size_t nframes, unsigned int channels,
+                    unsigned int decimation, const float *coeff_host /* [64] */,
+                    float *history_dev, float *out_dev);
+
+/* Demodulator::process (dsp/demodulator.cxx:77-115).  prev_io[2] = {prev_i,prev_q}
+ * (host), updated on return. */
+int wr_demod(wr_dev *dev, int mode, const float *in_dev, size_t nframes,
+             float *prev_io /* [2] host */, float *out_dev);
+
+/* RTL-SDR byte format to float, (u8 - 128)/128 (io/rtlsdrtuner.cxx:106) */
+int wr_u8_to_f32(wr_dev *dev, const uint8_t *in_dev, float *out_dev, size_t count);
+
+/* ------------------------------------------------- fused per-tuner path -- */
+/* One wr_tuner = one FrontEnd's tuner (radio.cxx:120-133) with all the Receivers
+ * attached to it (radio.cxx:151-156).  Every receiver chain
+ * DownConverter -> LowPass -> Demodulator -> LowPass (radio.cxx:68-82) of the tuner
+ * is evaluated by ONE launch sequence per input block.
+ * max_block_frames bounds nframes of wr_tuner_submit. */
+int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input_rate,
+                    unsigned int max_channels, size_t max_block_frames, int nco_mode);
+int wr_tuner_destroy(wr_tuner *tuner);
+
+/* Receiver() + FrontEnd::addReceiver (radio.cxx:62-90,151-156).  The new channel
+ * starts with phase 0, zero histories, prev_i = prev_q = 0, IF 0, AM, and no
+ * filters: it must be given both filters before the next submit. */
+int wr_chan_add(wr_tuner *tuner, int *chan);
+int wr_chan_remove(wr_tuner *tuner, int chan);
+int wr_chan_count(wr_tuner *tuner, int *count);
+
+/* Setters are STAGED and take effect at the next wr_tuner_submit (the reference
+ * applies them mid-block from other threads without locking). */
+/* DownConverter::setIF (dsp/downconverter.cxx:59-67) */
+int wr_chan_set_if(wr_tuner *tuner, int chan, int if_hz);
+/* LowPass::setPassband + setOutputSampleRate + init (dsp/lowpass.cxx:55-61,72-79,
+ * 81-116).  stage 0 = channel filter (input = tuner rate, 2 ch), stage 1 = audio
+ * filter (input = channel rate, 1 ch).  out_rate must divide the stage's input
+ * rate (WR_ERR_RATE otherwise, dspblock.cxx:126-130).  Changing out_rate resets
+ * the histories of the channel (as stop()/start() does, lowpass.cxx:118-129). */
+int wr_chan_set_filter(wr_tuner *tuner, int chan, int stage, unsigned int passband,
+                       unsigned int out_rate);
+/* same with caller-designed taps */
+int wr_chan_set_taps(wr_tuner *tuner, int chan, int stage, const float *coeff_host /* [64] */,
+                     unsigned int decimation);
+/* Demodulator::setMode (dsp/demodulator.h:49) */
+int wr_chan_set_mode(wr_tuner *tuner, int chan, int mode);
+/* ask for WR_STAGE_CHAN_IQ / WR_STAGE_DEMOD to be kept for wr_chan_fetch (audio
+ * always is).  A bitmask of (1 << stage). */
+int wr_tuner_keep_stages(wr_tuner *tuner, unsigned int stage_mask);
+
+/* streaming state of one channel: DownConverter::phase (downconverter.h:58),
+ * Demodulator::prev_i/q (demodulator.h:60-61) */
+int wr_chan_get_state(wr_tuner *tuner, int chan, unsigned int *phase, float *prev_iq /* [2] */);
+int wr_chan_set_state(wr_tuner *tuner, int chan, unsigned int phase, const float *prev_iq);
+
+/* DspSource::run for this tuner (dsp/dspblock.h:134, radio.cxx:56-59): push one
+ * block of `nframes` IQ frames through every channel.  where = WR_HOST: iq is host
+ * memory, copied to the device first; WR_DEVICE: iq is already in HBM and is read
+ * in place (it must stay valid until the stream has passed this call). Async. */
+int wr_tuner_submit(wr_tuner *tuner, const float *iq, size_t nframes, int where);
+
+/* results of the last submit.  Frames per channel: CHAN_IQ nframes/d1 (x2 floats),
+ * DEMOD nframes/d1, AUDIO nframes/d1/d2 -- the truncating arithmetic of
+ * dspblock.cxx:177-178.  Synchronises the stream. */
+int wr_chan_fetch(wr_tuner *tuner, int chan, int stage, float *out_host, size_t out_capacity,
+                  size_t *count);
+/* all channels' audio of the last submit, still on the device: audio of channel
+ * slot s starts at (*audio_dev) + s * (*chan_stride); slot = wr_chan_slot(). */
+int wr_tuner_audio_dev(wr_tuner *tuner, const float **audio_dev, size_t *chan_stride,
+                       size_t *frames);
+int wr_chan_slot(wr_tuner *tuner, int chan, int *slot);
+
+/* -------------------------------------------------------- SpectrumSink -- */
+/* SpectrumSink::init (io/spectrumsink.cxx:60-77).  fft_size: power of two
+ * (spectrumsink.cxx:53-56), 8 <= fft_size <= 1048576.  hop: frames between
+ * successive transforms; 0 or fft_size = the reference's back-to-back frames
+ * (spectrumsink.cxx:101-121); fft_size/2 = 50 % overlap (BASELINE config 3). */
+int wr_spectrum_create(wr_spectrum **spec, wr_dev *dev, unsigned int fft_size, unsigned int hop);
+int wr_spectrum_destroy(wr_spectrum *spec);
+/* SpectrumSink::process (io/spectrumsink.cxx:88-123): append frames; every time a
+ * frame is complete it is windowed and transformed.  Async for WR_DEVICE input. */
+int wr_spectrum_push(wr_spectrum *spec, const float *iq, size_t nframes, int where);
+/* SpectrumSink::getSpectrum (io/spectrumsink.cxx:125-142): dB, fft-shifted, of the
+ * most recent transform.  WR_ERR_STATE before the first complete frame (the
+ * reference returns uninitialised memory there, quirk Q8). */
+int wr_spectrum_get_db(wr_spectrum *spec, float *magnitudes_host /* [fft_size] */);
+/* raw complex bins of the most recent transform (FFTW order), for tests */
+int wr_spectrum_get_bins(wr_spectrum *spec, float *bins_host /* [2*fft_size] */);
+int wr_spectrum_frames_done(wr_spectrum *spec, unsigned long *frames);
+/* transform `nframes_fft` whole frames laid out back to back at a fixed hop in
+ * device memory and write dB rows (waterfall): frame f starts at iq_dev + 2*f*hop.
+ * db_dev receives nframes_fft rows of fft_size floats (fft-shifted). Async. */
+int wr_spectrum_batch_db(wr_spectrum *spec, const float *iq_dev, size_t nframes_fft,
+                         float *db_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEBRADIO_AMD_H_ */

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        from webradio_amd import capi
+        import ctypes as C
+        n = C.c_int()
+        return capi.load().wr_device_count(C.byref(n)) == 0 and n.value > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def dev():
+    """A wr_dev on device 0.  GPU tests FAIL (not skip) when the HIP library cannot be
+    loaded on a box that has a GPU; they are only deselected by -m "not gpu"."""
+    from webradio_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import wr_oracle
+    wr_oracle.lib()
+    return wr_oracle

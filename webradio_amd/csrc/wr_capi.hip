@@ -1,0 +1,1145 @@
+/*
+ * wr_capi.hip -- the extern "C" boundary declared in include/webradio_amd.h: handle
+ * bookkeeping, staged parameter updates, launch sequencing.  No DSP arithmetic lives
+ * here (design math: wr_design.cpp; kernels: wr_kernels.hip, wr_fft.hip).
+ *
+ * There is deliberately no CPU code path: every data-path entry point needs a
+ * wr_dev, and wr_dev_open fails with WR_ERR_NODEV when HIP reports no device.
+ */
+#include "wr_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+/* ------------------------------------------------------------------ errors -- */
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+	do {                                                                                 \
+		hipError_t e_ = (expr);                                                          \
+		if (e_ != hipSuccess)                                                            \
+			return fail(WR_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+			            __FILE__, __LINE__);                                             \
+	} while (0)
+
+/* ------------------------------------------------------------------ structs -- */
+
+struct wr_dev {
+	int device;
+	hipStream_t stream;
+	bool own_stream;
+	int num_cus;
+	float *table;              /* [65536] reference sine table */
+	float *hi_cs, *lo_cs;      /* [256][2] split NCO tables */
+	float *scratch;            /* growable scratch */
+	size_t scratch_floats;
+	float *coeff;              /* [64] staging for wr_fir_decimate */
+};
+
+struct Chan {
+	bool in_use;
+	int if_hz;
+	unsigned int stepL;        /* phaseStep << 1 */
+	unsigned int phaseL;       /* host mirror of DownConverter::phase << 1 */
+	int mode;
+	bool have[2];
+	float taps[2][WR_FIR_LENGTH];
+	unsigned int decim[2];
+	bool hist_valid;           /* channel filter has seen a block since its last reset */
+	int group;                 /* index into wr_tuner::groups, -1 while unconfigured */
+	int slot;
+	float prev_iq[2];          /* only meaningful while group < 0 (parked state) */
+	bool prev_dirty;           /* prev_iq must be uploaded to the slot */
+	bool phase_dirty;
+	bool dem_hist_reset;       /* audio filter history must be zeroed */
+};
+
+struct Group {
+	unsigned int d1, d2;
+	unsigned int slots;
+	size_t k1max, k2max;
+	WrGroupDev dev;
+	float *dem_scratch;        /* [63][slots] */
+	std::vector<int> owner;    /* slot -> chan or -1 */
+	bool dirty;                /* parameters must be uploaded before the next launch */
+	size_t last_k1, last_k2;
+	int active;
+};
+
+struct wr_tuner {
+	wr_dev *dev;
+	unsigned int input_rate;
+	unsigned int max_channels;
+	size_t max_block_frames;
+	int nco_mode;
+	unsigned int keep_mask;
+	std::vector<Chan> chans;
+	std::vector<Group *> groups;
+	float *in_stage;           /* [max_block_frames][2] for WR_HOST submits */
+	float *in_hist;            /* [63][2] */
+	float *in_hist_scratch;    /* [63][2] */
+	bool submitted;
+};
+
+struct wr_spectrum {
+	wr_dev *dev;
+	unsigned int n, hop;
+	WrFftPlan plan;
+	float *stage;              /* device stream buffer */
+	size_t stage_cap;          /* frames */
+	size_t pending;            /* frames buffered in stage, not yet consumed */
+	float *bins;               /* [n][2] most recent transform */
+	unsigned long frames_done;
+};
+
+/* ------------------------------------------------------------------ helpers -- */
+
+static int dev_bind(wr_dev *d)
+{
+	HIP_TRY(hipSetDevice(d->device));
+	return WR_OK;
+}
+
+static int dev_scratch(wr_dev *d, size_t floats)
+{
+	if (d->scratch_floats >= floats)
+		return WR_OK;
+	if (d->scratch) {
+		HIP_TRY(hipStreamSynchronize(d->stream));
+		HIP_TRY(hipFree(d->scratch));
+		d->scratch = nullptr;
+		d->scratch_floats = 0;
+	}
+	HIP_TRY(hipMalloc((void **)&d->scratch, floats * sizeof(float)));
+	d->scratch_floats = floats;
+	return WR_OK;
+}
+
+template <typename T>
+static int dev_alloc_zero(T **p, size_t count)
+{
+	HIP_TRY(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+	HIP_TRY(hipMemset(*p, 0, (count ? count : 1) * sizeof(T)));
+	return WR_OK;
+}
+
+/* ------------------------------------------------------------------ misc -- */
+
+extern "C" int wr_abi_version(void) { return WR_ABI_VERSION; }
+extern "C" const char *wr_last_error(void) { return g_err; }
+
+extern "C" int wr_device_count(int *count)
+{
+	if (!count)
+		return fail(WR_ERR_ARG, "count is NULL");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) {
+		*count = 0;
+		return fail(WR_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+	}
+	*count = n;
+	return WR_OK;
+}
+
+extern "C" int wr_phase_step(int if_hz, unsigned int input_rate, int *phase_step)
+{
+	if (!phase_step || !input_rate)
+		return fail(WR_ERR_ARG, "wr_phase_step: bad argument");
+	*phase_step = wrd_phase_step(if_hz, input_rate);
+	return WR_OK;
+}
+
+extern "C" int wr_sin_table(float *table_host)
+{
+	if (!table_host)
+		return fail(WR_ERR_ARG, "table is NULL");
+	wrd_sin_table(table_host);
+	return WR_OK;
+}
+
+extern "C" int wr_lowpass_design(unsigned int passband, unsigned int input_rate, float *coeff_host,
+                                 unsigned int *maxbin_out)
+{
+	if (!coeff_host || !input_rate)
+		return fail(WR_ERR_ARG, "wr_lowpass_design: bad argument");
+	wrd_lowpass_design(passband, input_rate, coeff_host);
+	if (maxbin_out)
+		*maxbin_out = wrd_lowpass_maxbin(passband, input_rate);
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_window(unsigned int fft_size, float *window_host)
+{
+	if (!window_host || !fft_size)
+		return fail(WR_ERR_ARG, "wr_spectrum_window: bad argument");
+	wrd_spectrum_window(fft_size, window_host);
+	return WR_OK;
+}
+
+/* ------------------------------------------------------------------ device -- */
+
+extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
+{
+	if (!dev)
+		return fail(WR_ERR_ARG, "dev is NULL");
+	*dev = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail(WR_ERR_NODEV, "no HIP device (%s): this backend has no CPU path",
+		            e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+	if (device_index < 0 || device_index >= n)
+		return fail(WR_ERR_ARG, "device %d out of range (%d devices)", device_index, n);
+	HIP_TRY(hipSetDevice(device_index));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device_index));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(WR_ERR_NODEV, "device %d is %s; this library is built for gfx950 only",
+		            device_index, prop.gcnArchName);
+
+	wr_dev *d = new (std::nothrow) wr_dev();
+	if (!d)
+		return fail(WR_ERR_NOMEM, "out of memory");
+	memset(d, 0, sizeof(*d));
+	d->device = device_index;
+	d->num_cus = prop.multiProcessorCount;
+	if (hip_stream) {
+		d->stream = (hipStream_t)hip_stream;
+		d->own_stream = false;
+	} else {
+		e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			delete d;
+			return fail(WR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+		}
+		d->own_stream = true;
+	}
+
+	std::vector<float> table(WR_TABLE_SIZE), hi(2 * WR_SPLIT_N), lo(2 * WR_SPLIT_N);
+	wrd_sin_table(table.data());
+	wrd_split_tables(hi.data(), lo.data());
+	int rc = WR_OK;
+	do {
+		if ((e = hipMalloc((void **)&d->table, WR_TABLE_SIZE * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&d->hi_cs, 2 * WR_SPLIT_N * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&d->lo_cs, 2 * WR_SPLIT_N * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&d->coeff, WR_FIR_LENGTH * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMemcpy(d->table, table.data(), WR_TABLE_SIZE * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		if ((e = hipMemcpy(d->hi_cs, hi.data(), 2 * WR_SPLIT_N * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		if ((e = hipMemcpy(d->lo_cs, lo.data(), 2 * WR_SPLIT_N * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+	} while (0);
+	if (e != hipSuccess) {
+		rc = fail(WR_ERR_HIP, "wr_dev_open: %s", hipGetErrorString(e));
+		wr_dev_close(d);
+		return rc;
+	}
+	*dev = d;
+	return WR_OK;
+}
+
+extern "C" int wr_dev_close(wr_dev *d)
+{
+	if (!d)
+		return WR_OK;
+	(void)hipSetDevice(d->device);
+	(void)hipStreamSynchronize(d->stream);
+	(void)hipFree(d->table);
+	(void)hipFree(d->hi_cs);
+	(void)hipFree(d->lo_cs);
+	(void)hipFree(d->coeff);
+	(void)hipFree(d->scratch);
+	if (d->own_stream)
+		(void)hipStreamDestroy(d->stream);
+	delete d;
+	return WR_OK;
+}
+
+extern "C" int wr_dev_sync(wr_dev *d)
+{
+	if (!d)
+		return fail(WR_ERR_ARG, "dev is NULL");
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" void *wr_dev_stream(wr_dev *d) { return d ? (void *)d->stream : nullptr; }
+
+extern "C" int wr_dev_malloc(wr_dev *d, size_t bytes, void **ptr_dev)
+{
+	if (!d || !ptr_dev)
+		return fail(WR_ERR_ARG, "wr_dev_malloc: bad argument");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	HIP_TRY(hipMalloc(ptr_dev, bytes ? bytes : 4));
+	HIP_TRY(hipMemsetAsync(*ptr_dev, 0, bytes ? bytes : 4, d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_dev_free(wr_dev *d, void *ptr_dev)
+{
+	if (!d)
+		return fail(WR_ERR_ARG, "dev is NULL");
+	if (!ptr_dev)
+		return WR_OK;
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(hipFree(ptr_dev));
+	return WR_OK;
+}
+
+extern "C" int wr_dev_upload(wr_dev *d, void *dst_dev, const void *src_host, size_t bytes)
+{
+	if (!d || (!dst_dev && bytes) || (!src_host && bytes))
+		return fail(WR_ERR_ARG, "wr_dev_upload: bad argument");
+	if (!bytes)
+		return WR_OK;
+	HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_dev_download(wr_dev *d, void *dst_host, const void *src_dev, size_t bytes)
+{
+	if (!d || (!dst_host && bytes) || (!src_dev && bytes))
+		return fail(WR_ERR_ARG, "wr_dev_download: bad argument");
+	if (!bytes)
+		return WR_OK;
+	HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+/* --------------------------------------------------- one kernel per block -- */
+
+extern "C" int wr_mix(wr_dev *d, const float *in_dev, float *out_dev, size_t nframes,
+                      unsigned int *phase_io, int phase_step)
+{
+	if (!d || !phase_io || (nframes && (!in_dev || !out_dev)))
+		return fail(WR_ERR_ARG, "wr_mix: bad argument");
+	HIP_TRY(wrk_mix(d->stream, in_dev, out_dev, nframes, *phase_io, phase_step, d->table));
+	/* DownConverter::phase after nframes increments (downconverter.cxx:103) */
+	*phase_io = (*phase_io + (unsigned int)nframes * (unsigned int)phase_step) & 0x7FFFFFFFu;
+	return WR_OK;
+}
+
+extern "C" int wr_fir_decimate(wr_dev *d, const float *in_dev, size_t nframes, unsigned int channels,
+                               unsigned int decimation, const float *coeff_host, float *history_dev,
+                               float *out_dev)
+{
+	if (!d || !coeff_host || !history_dev || !channels || !decimation ||
+	    (nframes && (!in_dev || !out_dev)))
+		return fail(WR_ERR_ARG, "wr_fir_decimate: bad argument");
+	int rc = dev_scratch(d, (size_t)WR_HIST * channels);
+	if (rc)
+		return rc;
+	HIP_TRY(hipMemcpyAsync(d->coeff, coeff_host, WR_FIR_LENGTH * sizeof(float),
+	                       hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(wrk_fir(d->stream, in_dev, nframes, channels, decimation, d->coeff, history_dev, out_dev));
+	HIP_TRY(wrk_hist_update(d->stream, in_dev, nframes, channels, history_dev, d->scratch));
+	return WR_OK;
+}
+
+extern "C" int wr_demod(wr_dev *d, int mode, const float *in_dev, size_t nframes, float *prev_io,
+                        float *out_dev)
+{
+	if (!d || !prev_io || (nframes && (!in_dev || !out_dev)))
+		return fail(WR_ERR_ARG, "wr_demod: bad argument");
+	if (mode < WR_AM || mode > WR_LSB)
+		return fail(WR_ERR_ARG, "wr_demod: bad mode %d", mode);   /* demodulator.cxx:105-107 */
+	HIP_TRY(wrk_demod(d->stream, mode, in_dev, nframes, prev_io[0], prev_io[1], out_dev));
+	if (nframes) {
+		/* prev_i/q = last input frame (demodulator.cxx:110-111) */
+		HIP_TRY(hipMemcpyAsync(prev_io, in_dev + 2 * (nframes - 1), 2 * sizeof(float),
+		                       hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));
+	}
+	return WR_OK;
+}
+
+extern "C" int wr_u8_to_f32(wr_dev *d, const uint8_t *in_dev, float *out_dev, size_t count)
+{
+	if (!d || (count && (!in_dev || !out_dev)))
+		return fail(WR_ERR_ARG, "wr_u8_to_f32: bad argument");
+	HIP_TRY(wrk_u8_to_f32(d->stream, in_dev, out_dev, count));
+	return WR_OK;
+}
+
+/* ------------------------------------------------------------------ tuner -- */
+
+static void group_free(Group *g)
+{
+	if (!g)
+		return;
+	(void)hipFree(g->dev.phase);
+	(void)hipFree(g->dev.step);
+	(void)hipFree(g->dev.hist_step);
+	(void)hipFree(g->dev.flags);
+	(void)hipFree(g->dev.mode);
+	(void)hipFree(g->dev.taps1);
+	(void)hipFree(g->dev.taps2);
+	(void)hipFree(g->dev.prev_iq);
+	(void)hipFree(g->dev.chan_iq);
+	(void)hipFree(g->dev.dem);
+	(void)hipFree(g->dev.audio);
+	(void)hipFree(g->dem_scratch);
+	delete g;
+}
+
+static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **out)
+{
+	Group *g = new (std::nothrow) Group();
+	if (!g)
+		return fail(WR_ERR_NOMEM, "out of memory");
+	memset(&g->dev, 0, sizeof(g->dev));
+	g->dem_scratch = nullptr;
+	g->d1 = d1;
+	g->d2 = d2;
+	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
+	g->k1max = t->max_block_frames / d1;
+	g->k2max = g->k1max / d2;
+	if (g->k2max == 0)
+		g->k2max = 1;
+	g->owner.assign(g->slots, -1);
+	g->dirty = true;
+	g->last_k1 = g->last_k2 = 0;
+	g->active = 0;
+	const size_t S = g->slots;
+	int rc = WR_OK;
+	if (!rc) rc = dev_alloc_zero(&g->dev.phase, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.step, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_step, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.flags, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
+	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq, S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq, (g->k1max ? g->k1max : 1) * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.dem, (WR_HIST + g->k1max) * S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
+	if (!rc) rc = dev_alloc_zero(&g->dem_scratch, (size_t)WR_HIST * S);
+	if (rc) {
+		group_free(g);
+		return rc;
+	}
+	*out = g;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input_rate,
+                               unsigned int max_channels, size_t max_block_frames, int nco_mode)
+{
+	if (!tuner || !dev || !input_rate || !max_channels || !max_block_frames)
+		return fail(WR_ERR_ARG, "wr_tuner_create: bad argument");
+	if (nco_mode != WR_NCO_SPLIT && nco_mode != WR_NCO_EXACT)
+		return fail(WR_ERR_ARG, "wr_tuner_create: bad nco_mode %d", nco_mode);
+	*tuner = nullptr;
+	if (dev_bind(dev))
+		return WR_ERR_HIP;
+	wr_tuner *t = new (std::nothrow) wr_tuner();
+	if (!t)
+		return fail(WR_ERR_NOMEM, "out of memory");
+	t->dev = dev;
+	t->input_rate = input_rate;
+	t->max_channels = max_channels;
+	t->max_block_frames = max_block_frames;
+	t->nco_mode = nco_mode;
+	t->keep_mask = 0;
+	t->in_stage = nullptr;
+	t->in_hist = t->in_hist_scratch = nullptr;
+	t->submitted = false;
+	int rc = dev_alloc_zero(&t->in_hist, (size_t)WR_HIST * 2);
+	if (!rc)
+		rc = dev_alloc_zero(&t->in_hist_scratch, (size_t)WR_HIST * 2);
+	if (rc) {
+		wr_tuner_destroy(t);
+		return rc;
+	}
+	*tuner = t;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_destroy(wr_tuner *t)
+{
+	if (!t)
+		return WR_OK;
+	(void)hipSetDevice(t->dev->device);
+	(void)hipStreamSynchronize(t->dev->stream);
+	for (Group *g : t->groups)
+		group_free(g);
+	(void)hipFree(t->in_stage);
+	(void)hipFree(t->in_hist);
+	(void)hipFree(t->in_hist_scratch);
+	delete t;
+	return WR_OK;
+}
+
+static Chan *chan_get(wr_tuner *t, int chan)
+{
+	if (!t || chan < 0 || (size_t)chan >= t->chans.size() || !t->chans[chan].in_use)
+		return nullptr;
+	return &t->chans[chan];
+}
+
+extern "C" int wr_chan_add(wr_tuner *t, int *chan)
+{
+	if (!t || !chan)
+		return fail(WR_ERR_ARG, "wr_chan_add: bad argument");
+	int live = 0;
+	for (const Chan &c : t->chans)
+		live += c.in_use ? 1 : 0;
+	if ((unsigned int)live >= t->max_channels)
+		return fail(WR_ERR_STATE, "wr_chan_add: tuner already has %u channels", t->max_channels);
+	int idx = -1;
+	for (size_t i = 0; i < t->chans.size(); ++i)
+		if (!t->chans[i].in_use) {
+			idx = (int)i;
+			break;
+		}
+	if (idx < 0) {
+		t->chans.push_back(Chan());
+		idx = (int)t->chans.size() - 1;
+	}
+	Chan &c = t->chans[idx];
+	memset(&c, 0, sizeof(c));
+	c.in_use = true;
+	c.mode = WR_AM;                /* Demodulator ctor, demodulator.cxx:34 */
+	c.group = -1;
+	c.slot = -1;
+	*chan = idx;
+	return WR_OK;
+}
+
+static int chan_unseat(wr_tuner *t, Chan &c, bool keep_state);
+
+extern "C" int wr_chan_remove(wr_tuner *t, int chan)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_remove: no channel %d", chan);
+	int rc = chan_unseat(t, *c, false);
+	c->in_use = false;
+	return rc;
+}
+
+extern "C" int wr_chan_count(wr_tuner *t, int *count)
+{
+	if (!t || !count)
+		return fail(WR_ERR_ARG, "wr_chan_count: bad argument");
+	int live = 0;
+	for (const Chan &c : t->chans)
+		live += c.in_use ? 1 : 0;
+	*count = live;
+	return WR_OK;
+}
+
+/* take a channel out of its group slot; optionally keep Demodulator prev_i/q
+ * (they survive stop()/start() in the reference, quirk Q5) */
+static int chan_unseat(wr_tuner *t, Chan &c, bool keep_state)
+{
+	if (c.group < 0)
+		return WR_OK;
+	Group *g = t->groups[c.group];
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	HIP_TRY(hipStreamSynchronize(t->dev->stream));
+	if (keep_state)
+		HIP_TRY(hipMemcpy(c.prev_iq, g->dev.prev_iq + 2 * c.slot, 2 * sizeof(float),
+		                  hipMemcpyDeviceToHost));
+	g->owner[c.slot] = -1;
+	g->active--;
+	g->dirty = true;
+	c.group = -1;
+	c.slot = -1;
+	c.hist_valid = false;
+	c.prev_dirty = keep_state;
+	c.phase_dirty = true;
+	return WR_OK;
+}
+
+/* seat a fully configured channel into the group matching its decimations */
+static int chan_seat(wr_tuner *t, int idx)
+{
+	Chan &c = t->chans[idx];
+	if (!c.have[0] || !c.have[1])
+		return WR_OK;
+	if (c.group >= 0) {
+		Group *g = t->groups[c.group];
+		if (g->d1 == c.decim[0] && g->d2 == c.decim[1]) {
+			g->dirty = true;
+			return WR_OK;
+		}
+		int rc = chan_unseat(t, c, true);
+		if (rc)
+			return rc;
+	}
+	int gi = -1;
+	for (size_t i = 0; i < t->groups.size(); ++i)
+		if (t->groups[i]->d1 == c.decim[0] && t->groups[i]->d2 == c.decim[1]) {
+			gi = (int)i;
+			break;
+		}
+	if (gi < 0) {
+		if (dev_bind(t->dev))
+			return WR_ERR_HIP;
+		Group *g = nullptr;
+		int rc = group_create(t, c.decim[0], c.decim[1], &g);
+		if (rc)
+			return rc;
+		t->groups.push_back(g);
+		gi = (int)t->groups.size() - 1;
+	}
+	Group *g = t->groups[gi];
+	int slot = -1;
+	for (unsigned int s = 0; s < g->slots; ++s)
+		if (g->owner[s] < 0) {
+			slot = (int)s;
+			break;
+		}
+	if (slot < 0)
+		return fail(WR_ERR_STATE, "no free slot in rate group %u/%u", g->d1, g->d2);
+	g->owner[slot] = idx;
+	g->active++;
+	g->dirty = true;
+	c.group = gi;
+	c.slot = slot;
+	c.hist_valid = false;          /* fresh LowPass::block: zero history (lowpass.cxx:138-139) */
+	c.dem_hist_reset = true;
+	c.prev_dirty = true;
+	c.phase_dirty = true;
+	return WR_OK;
+}
+
+extern "C" int wr_chan_set_if(wr_tuner *t, int chan, int if_hz)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_set_if: no channel %d", chan);
+	c->if_hz = if_hz;
+	c->stepL = (unsigned int)wrd_phase_step(if_hz, t->input_rate) << 1;
+	if (c->group >= 0)
+		t->groups[c->group]->dirty = true;
+	return WR_OK;
+}
+
+static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff, unsigned int decim)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "no channel %d", chan);
+	if (stage != 0 && stage != 1)
+		return fail(WR_ERR_ARG, "stage must be 0 (channel) or 1 (audio)");
+	if (!decim)
+		return fail(WR_ERR_ARG, "decimation must be >= 1");
+	if (stage == 0 && decim > t->max_block_frames)
+		return fail(WR_ERR_ARG, "decimation %u exceeds max_block_frames", decim);
+	memcpy(c->taps[stage], coeff, sizeof(float) * WR_FIR_LENGTH);
+	c->decim[stage] = decim;
+	c->have[stage] = true;
+	return chan_seat(t, chan);
+}
+
+extern "C" int wr_chan_set_taps(wr_tuner *t, int chan, int stage, const float *coeff_host,
+                                unsigned int decimation)
+{
+	if (!t || !coeff_host)
+		return fail(WR_ERR_ARG, "wr_chan_set_taps: bad argument");
+	return set_taps_common(t, chan, stage, coeff_host, decimation);
+}
+
+extern "C" int wr_chan_set_filter(wr_tuner *t, int chan, int stage, unsigned int passband,
+                                  unsigned int out_rate)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_set_filter: no channel %d", chan);
+	if (stage != 0 && stage != 1)
+		return fail(WR_ERR_ARG, "stage must be 0 (channel) or 1 (audio)");
+	unsigned int in_rate;
+	if (stage == 0) {
+		in_rate = t->input_rate;
+	} else {
+		if (!c->have[0])
+			return fail(WR_ERR_STATE, "set the channel filter (stage 0) before the audio filter");
+		in_rate = t->input_rate / c->decim[0];
+	}
+	if (!out_rate || out_rate > in_rate)
+		return fail(WR_ERR_RATE, "output rate %u not a decimation of %u", out_rate, in_rate);
+	unsigned int decim = in_rate / out_rate;           /* dspblock.cxx:119-121 */
+	if (in_rate / decim != out_rate || in_rate % out_rate)
+		return fail(WR_ERR_RATE, "Sample rates must be integer related (%u -> %u)", in_rate, out_rate);
+	float coeff[WR_FIR_LENGTH];
+	wrd_lowpass_design(passband, in_rate, coeff);
+	return set_taps_common(t, chan, stage, coeff, decim);
+}
+
+extern "C" int wr_chan_set_mode(wr_tuner *t, int chan, int mode)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_set_mode: no channel %d", chan);
+	if (mode < WR_AM || mode > WR_LSB)
+		return fail(WR_ERR_ARG, "wr_chan_set_mode: bad mode %d", mode);
+	c->mode = mode;
+	if (c->group >= 0)
+		t->groups[c->group]->dirty = true;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_keep_stages(wr_tuner *t, unsigned int stage_mask)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	t->keep_mask = stage_mask;
+	return WR_OK;
+}
+
+extern "C" int wr_chan_get_state(wr_tuner *t, int chan, unsigned int *phase, float *prev_iq)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_get_state: no channel %d", chan);
+	if (phase)
+		*phase = c->phaseL >> 1;
+	if (prev_iq) {
+		if (c->group >= 0 && !c->prev_dirty) {
+			Group *g = t->groups[c->group];
+			if (dev_bind(t->dev))
+				return WR_ERR_HIP;
+			HIP_TRY(hipStreamSynchronize(t->dev->stream));
+			HIP_TRY(hipMemcpy(prev_iq, g->dev.prev_iq + 2 * c->slot, 2 * sizeof(float),
+			                  hipMemcpyDeviceToHost));
+		} else {
+			prev_iq[0] = c->prev_iq[0];
+			prev_iq[1] = c->prev_iq[1];
+		}
+	}
+	return WR_OK;
+}
+
+extern "C" int wr_chan_set_state(wr_tuner *t, int chan, unsigned int phase, const float *prev_iq)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_set_state: no channel %d", chan);
+	c->phaseL = phase << 1;
+	c->phase_dirty = true;
+	if (prev_iq) {
+		c->prev_iq[0] = prev_iq[0];
+		c->prev_iq[1] = prev_iq[1];
+		c->prev_dirty = true;
+	}
+	if (c->group >= 0)
+		t->groups[c->group]->dirty = true;
+	return WR_OK;
+}
+
+extern "C" int wr_chan_slot(wr_tuner *t, int chan, int *slot)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c || !slot)
+		return fail(WR_ERR_ARG, "wr_chan_slot: bad argument");
+	if (c->group < 0)
+		return fail(WR_ERR_STATE, "channel %d has no filters yet", chan);
+	*slot = c->slot;
+	return WR_OK;
+}
+
+/* push the host shadow of one group's parameters to its device arrays */
+static int group_upload(wr_tuner *t, Group *g)
+{
+	const size_t S = g->slots;
+	hipStream_t st = t->dev->stream;
+	std::vector<unsigned int> step(S, 0);
+	std::vector<int> flags(S, 0), mode(S, 0);
+	std::vector<float> taps1(S * WR_FIR_LENGTH, 0.0f), taps2(S * WR_FIR_LENGTH, 0.0f);
+	for (size_t s = 0; s < S; ++s) {
+		int ci = g->owner[s];
+		if (ci < 0)
+			continue;
+		Chan &c = t->chans[ci];
+		step[s] = c.stepL;
+		mode[s] = c.mode;
+		flags[s] = 1 | (c.hist_valid ? 2 : 0);
+		for (int j = 0; j < WR_FIR_LENGTH; ++j) {
+			taps1[(size_t)j * S + s] = c.taps[0][j];
+			taps2[(size_t)j * S + s] = c.taps[1][j];
+		}
+	}
+	/* pageable sources: hipMemcpyAsync stages them before returning */
+	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.mode, mode.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.taps1, taps1.data(), taps1.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	for (size_t s = 0; s < S; ++s) {
+		int ci = g->owner[s];
+		if (ci < 0)
+			continue;
+		Chan &c = t->chans[ci];
+		if (c.phase_dirty) {
+			HIP_TRY(hipMemcpyAsync(g->dev.phase + s, &c.phaseL, sizeof(unsigned int), hipMemcpyHostToDevice, st));
+			c.phase_dirty = false;
+		}
+		if (c.prev_dirty) {
+			HIP_TRY(hipMemcpyAsync(g->dev.prev_iq + 2 * s, c.prev_iq, 2 * sizeof(float), hipMemcpyHostToDevice, st));
+			c.prev_dirty = false;
+		}
+		if (c.dem_hist_reset) {
+			/* 63 history rows of this slot: one float per row, stride S */
+			HIP_TRY(hipMemset2DAsync(g->dev.dem + s, S * sizeof(float), 0, sizeof(float), WR_HIST, st));
+			c.dem_hist_reset = false;
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(st));     /* host vectors go out of scope */
+	g->dirty = false;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int where)
+{
+	if (!t || (nframes && !iq))
+		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
+	if (nframes > t->max_block_frames)
+		return fail(WR_ERR_ARG, "wr_tuner_submit: %zu frames exceeds max_block_frames %zu", nframes,
+		            t->max_block_frames);
+	if (where != WR_HOST && where != WR_DEVICE)
+		return fail(WR_ERR_ARG, "wr_tuner_submit: bad `where`");
+	for (const Chan &c : t->chans)
+		if (c.in_use && c.group < 0)
+			return fail(WR_ERR_STATE, "a channel has no filters (LowPass::init: \"Must specify either "
+			                          "decimation or output rate\")");
+	wr_dev *d = t->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	hipStream_t st = d->stream;
+
+	const float *cur = iq;
+	if (where == WR_HOST) {
+		if (!t->in_stage)
+			HIP_TRY(hipMalloc((void **)&t->in_stage, t->max_block_frames * 2 * sizeof(float)));
+		if (nframes)
+			HIP_TRY(hipMemcpyAsync(t->in_stage, iq, nframes * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+		cur = t->in_stage;
+	}
+
+	for (Group *g : t->groups) {
+		if (g->active <= 0) {
+			g->last_k1 = g->last_k2 = 0;
+			continue;
+		}
+		if (g->dirty) {
+			int rc = group_upload(t, g);
+			if (rc)
+				return rc;
+		}
+		WrTunerLaunch L;
+		L.cur = cur;
+		L.hist = t->in_hist;
+		L.nframes = nframes;
+		L.d1 = g->d1;
+		L.d2 = g->d2;
+		L.slots = g->slots;
+		L.k1 = nframes / g->d1;                 /* dspblock.cxx:177-178 */
+		L.k2 = L.k1 / g->d2;
+		L.k2max = g->k2max;
+		L.nco_mode = t->nco_mode;
+		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, d->table, d->hi_cs, d->lo_cs, d->num_cus));
+		HIP_TRY(wrk_tuner_demod(st, L, g->dev));
+		HIP_TRY(wrk_tuner_audio(st, L, g->dev));
+		HIP_TRY(wrk_tuner_advance(st, L, g->dev, g->dem_scratch));
+		g->last_k1 = L.k1;
+		g->last_k2 = L.k2;
+	}
+	HIP_TRY(wrk_input_hist(st, cur, nframes, t->in_hist, t->in_hist_scratch));
+
+	/* host mirrors of what k_tuner_advance did */
+	for (Chan &c : t->chans) {
+		if (!c.in_use || c.group < 0)
+			continue;
+		c.phaseL += (unsigned int)nframes * c.stepL;
+		c.hist_valid = true;
+	}
+	t->submitted = true;
+	return WR_OK;
+}
+
+extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, size_t out_capacity,
+                             size_t *count)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c || !count)
+		return fail(WR_ERR_ARG, "wr_chan_fetch: bad argument");
+	if (c->group < 0 || !t->submitted)
+		return fail(WR_ERR_STATE, "wr_chan_fetch: nothing submitted yet");
+	Group *g = t->groups[c->group];
+	wr_dev *d = t->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	size_t n = 0;
+	switch (stage) {
+	case WR_STAGE_CHAN_IQ: n = g->last_k1 * 2; break;
+	case WR_STAGE_DEMOD:   n = g->last_k1; break;
+	case WR_STAGE_AUDIO:   n = g->last_k2; break;
+	default: return fail(WR_ERR_ARG, "wr_chan_fetch: bad stage %d", stage);
+	}
+	*count = n;
+	if (!n)
+		return WR_OK;
+	if (!out_host || out_capacity < n)
+		return fail(WR_ERR_ARG, "wr_chan_fetch: need room for %zu floats", n);
+	const size_t S = g->slots;
+	if (stage == WR_STAGE_AUDIO) {
+		HIP_TRY(hipMemcpyAsync(out_host, g->dev.audio + (size_t)c->slot * g->k2max, n * sizeof(float),
+		                       hipMemcpyDeviceToHost, d->stream));
+	} else {
+		int rc = dev_scratch(d, n);
+		if (rc)
+			return rc;
+		if (stage == WR_STAGE_CHAN_IQ)
+			HIP_TRY(wrk_gather_rows(d->stream, g->dev.chan_iq, g->last_k1, S * 2, (size_t)c->slot * 2, 2,
+			                        d->scratch));
+		else
+			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem + (size_t)WR_HIST * S, g->last_k1, S,
+			                        (size_t)c->slot, 1, d->scratch));
+		HIP_TRY(hipMemcpyAsync(out_host, d->scratch, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_audio_dev(wr_tuner *t, const float **audio_dev, size_t *chan_stride,
+                                  size_t *frames)
+{
+	if (!t || !audio_dev || !chan_stride || !frames)
+		return fail(WR_ERR_ARG, "wr_tuner_audio_dev: bad argument");
+	Group *g = nullptr;
+	for (Group *x : t->groups)
+		if (x->active > 0) {
+			if (g)
+				return fail(WR_ERR_STATE, "tuner has several rate groups; fetch per channel instead");
+			g = x;
+		}
+	if (!g)
+		return fail(WR_ERR_STATE, "tuner has no configured channel");
+	*audio_dev = g->dev.audio;
+	*chan_stride = g->k2max;
+	*frames = g->last_k2;
+	return WR_OK;
+}
+
+/* --------------------------------------------------------------- spectrum -- */
+
+static void plan_free(WrFftPlan &p)
+{
+	(void)hipFree(p.tw_n);
+	(void)hipFree(p.tw_sub);
+	(void)hipFree(p.window);
+	(void)hipFree(p.work);
+	memset(&p, 0, sizeof(p));
+}
+
+extern "C" int wr_spectrum_create(wr_spectrum **spec, wr_dev *dev, unsigned int fft_size, unsigned int hop)
+{
+	if (!spec || !dev)
+		return fail(WR_ERR_ARG, "wr_spectrum_create: bad argument");
+	*spec = nullptr;
+	if (fft_size < 8 || fft_size > (1u << 20) || (fft_size & (fft_size - 1)))
+		return fail(WR_ERR_ARG, "size must be a power of 2 in [8, 1048576]");   /* spectrumsink.cxx:53-56 */
+	if (hop == 0)
+		hop = fft_size;
+	if (hop > fft_size)
+		return fail(WR_ERR_ARG, "hop must not exceed fft_size");
+	if (dev_bind(dev))
+		return WR_ERR_HIP;
+	wr_spectrum *s = new (std::nothrow) wr_spectrum();
+	if (!s)
+		return fail(WR_ERR_NOMEM, "out of memory");
+	memset(&s->plan, 0, sizeof(s->plan));
+	s->dev = dev;
+	s->n = fft_size;
+	s->hop = hop;
+	s->stage = nullptr;
+	s->stage_cap = 0;
+	s->pending = 0;
+	s->bins = nullptr;
+	s->frames_done = 0;
+
+	WrFftPlan &p = s->plan;
+	p.n = fft_size;
+	if (fft_size <= 8192) {
+		p.n1 = fft_size;
+		p.n2 = 1;
+	} else {
+		unsigned int bits = 0;
+		while ((1u << bits) < fft_size)
+			bits++;
+		p.n1 = 1u << ((bits + 1) / 2);
+		p.n2 = fft_size / p.n1;
+	}
+	const unsigned int sub = (p.n2 == 1) ? 0 : (p.n1 > p.n2 ? p.n1 : p.n2);
+	std::vector<float> tw(fft_size), win(fft_size), tws(sub ? sub : 2);
+	wrd_twiddles(fft_size, tw.data());
+	wrd_spectrum_window(fft_size, win.data());
+	if (sub)
+		wrd_twiddles(sub, tws.data());
+	p.work_frames = (p.n2 == 1) ? 0 : 64;
+	hipError_t e = hipSuccess;
+	do {
+		if ((e = hipMalloc((void **)&p.tw_n, fft_size * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&p.window, fft_size * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&p.tw_sub, (sub ? sub : 2) * sizeof(float))) != hipSuccess) break;
+		if (p.work_frames &&
+		    (e = hipMalloc((void **)&p.work, p.work_frames * fft_size * 2 * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&s->bins, (size_t)fft_size * 2 * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMemcpy(p.tw_n, tw.data(), fft_size * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		if ((e = hipMemcpy(p.window, win.data(), fft_size * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		if (sub && (e = hipMemcpy(p.tw_sub, tws.data(), sub * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+	} while (0);
+	if (e != hipSuccess) {
+		int rc = fail(WR_ERR_HIP, "wr_spectrum_create: %s", hipGetErrorString(e));
+		wr_spectrum_destroy(s);
+		return rc;
+	}
+	*spec = s;
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_destroy(wr_spectrum *s)
+{
+	if (!s)
+		return WR_OK;
+	(void)hipSetDevice(s->dev->device);
+	(void)hipStreamSynchronize(s->dev->stream);
+	plan_free(s->plan);
+	(void)hipFree(s->stage);
+	(void)hipFree(s->bins);
+	delete s;
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes, int where)
+{
+	if (!s || (nframes && !iq))
+		return fail(WR_ERR_ARG, "wr_spectrum_push: bad argument");
+	if (where != WR_HOST && where != WR_DEVICE)
+		return fail(WR_ERR_ARG, "wr_spectrum_push: bad `where`");
+	wr_dev *d = s->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	hipStream_t st = d->stream;
+	const size_t have = s->pending + nframes;
+	if (have > s->stage_cap) {
+		float *nb = nullptr;
+		size_t cap = have + s->n;
+		HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
+		if (s->pending)
+			HIP_TRY(hipMemcpyAsync(nb, s->stage, s->pending * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (s->stage)
+			HIP_TRY(hipFree(s->stage));
+		s->stage = nb;
+		s->stage_cap = cap;
+	}
+	if (nframes)
+		HIP_TRY(hipMemcpyAsync(s->stage + 2 * s->pending, iq, nframes * 2 * sizeof(float),
+		                       where == WR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+	/* frames start every `hop`; the reference transforms each one but only the most
+	 * recent is observable through getSpectrum (spectrumsink.cxx:114-116,136-141) */
+	size_t nfft = 0;
+	if (have >= s->n)
+		nfft = (have - s->n) / s->hop + 1;
+	if (nfft) {
+		const float *last = s->stage + 2 * (nfft - 1) * s->hop;
+		HIP_TRY(wrk_fft_frames(st, s->plan, last, s->hop, 1, s->bins, nullptr));
+		s->frames_done += nfft;
+		const size_t consumed = nfft * s->hop;
+		const size_t rest = have - consumed;
+		if (rest) {
+			/* compact the tail to the front (ranges may overlap: go through the work area) */
+			if (rest <= consumed) {
+				HIP_TRY(hipMemcpyAsync(s->stage, s->stage + 2 * consumed, rest * 2 * sizeof(float),
+				                       hipMemcpyDeviceToDevice, st));
+			} else {
+				int rc = dev_scratch(d, rest * 2);
+				if (rc)
+					return rc;
+				HIP_TRY(hipMemcpyAsync(d->scratch, s->stage + 2 * consumed, rest * 2 * sizeof(float),
+				                       hipMemcpyDeviceToDevice, st));
+				HIP_TRY(hipMemcpyAsync(s->stage, d->scratch, rest * 2 * sizeof(float),
+				                       hipMemcpyDeviceToDevice, st));
+			}
+		}
+		s->pending = rest;
+	} else {
+		s->pending = have;
+	}
+	if (where == WR_HOST)
+		HIP_TRY(hipStreamSynchronize(st));
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_get_bins(wr_spectrum *s, float *bins_host)
+{
+	if (!s || !bins_host)
+		return fail(WR_ERR_ARG, "wr_spectrum_get_bins: bad argument");
+	if (!s->frames_done)
+		return fail(WR_ERR_STATE, "no complete frame yet");
+	if (dev_bind(s->dev))
+		return WR_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(bins_host, s->bins, (size_t)s->n * 2 * sizeof(float), hipMemcpyDeviceToHost,
+	                       s->dev->stream));
+	HIP_TRY(hipStreamSynchronize(s->dev->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_get_db(wr_spectrum *s, float *magnitudes_host)
+{
+	if (!s || !magnitudes_host)
+		return fail(WR_ERR_ARG, "wr_spectrum_get_db: bad argument");
+	if (!s->frames_done)
+		return fail(WR_ERR_STATE, "no complete frame yet");
+	wr_dev *d = s->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	int rc = dev_scratch(d, s->n);
+	if (rc)
+		return rc;
+	/* dB + fftshift of the stored bins */
+	HIP_TRY(wrk_bins_to_db(d->stream, s->bins, s->n, d->scratch));
+	HIP_TRY(hipMemcpyAsync(magnitudes_host, d->scratch, (size_t)s->n * sizeof(float), hipMemcpyDeviceToHost,
+	                       d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_frames_done(wr_spectrum *s, unsigned long *frames)
+{
+	if (!s || !frames)
+		return fail(WR_ERR_ARG, "wr_spectrum_frames_done: bad argument");
+	*frames = s->frames_done;
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_batch_db(wr_spectrum *s, const float *iq_dev, size_t nframes_fft, float *db_dev)
+{
+	if (!s || (nframes_fft && (!iq_dev || !db_dev)))
+		return fail(WR_ERR_ARG, "wr_spectrum_batch_db: bad argument");
+	if (dev_bind(s->dev))
+		return WR_ERR_HIP;
+	HIP_TRY(wrk_fft_frames(s->dev->stream, s->plan, iq_dev, s->hop, nframes_fft, nullptr, db_dev));
+	return WR_OK;
+}

@@ -1,0 +1,93 @@
+/*
+ * wr_internal.h -- internal C++ interface between the C ABI (wr_capi.hip), the host
+ * design math (wr_design.cpp) and the kernels (wr_kernels.hip, wr_fft.hip).
+ * Not installed; the public boundary is include/webradio_amd.h.
+ */
+#ifndef WR_INTERNAL_H_
+#define WR_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "webradio_amd.h"
+
+#define WR_HIST      (WR_FIR_LENGTH - 1)   /* 63 frames of FIR history, lowpass.cxx:133 */
+#define WR_LANES     64                    /* wavefront width on gfx950 */
+#define WR_SPLIT_N   256                   /* entries of the coarse and of the fine NCO table */
+
+/* ---- host design math (wr_design.cpp) ---- */
+void     wrd_sin_table(float *table);
+int      wrd_phase_step(int if_hz, unsigned int input_rate);
+unsigned wrd_lowpass_maxbin(unsigned int passband, unsigned int input_rate);
+void     wrd_lowpass_design(unsigned int passband, unsigned int input_rate, float *coeff);
+void     wrd_spectrum_window(unsigned int n, float *window);
+void     wrd_split_tables(float *hi_cs /* [256][2] cos,sin */, float *lo_cs /* [256][2] */);
+void     wrd_twiddles(unsigned int n, float *tw /* [n/2][2] cos,-sin of 2*pi*k/n */);
+
+/* ---- per-slot parameter block of one rate group of a tuner, device SoA ---- */
+struct WrGroupDev {
+	/* all arrays have `slots` entries (slots is a multiple of 64) unless noted */
+	unsigned int *phase;        /* left-aligned phase at block start: DownConverter::phase << 1 */
+	unsigned int *step;         /* phaseStep << 1 (two's complement) for this block */
+	unsigned int *hist_step;    /* phaseStep << 1 that was in force during the previous block */
+	int          *flags;        /* bit0: slot active; bit1: channel-filter history valid */
+	int          *mode;         /* wr_mode */
+	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */
+	float        *taps2;        /* [64][slots] audio-filter taps */
+	float        *prev_iq;      /* [slots][2] Demodulator::prev_i/prev_q */
+	float        *chan_iq;      /* [k1max][slots][2] channel-filter output, time major */
+	float        *dem;          /* [63 + k1max][slots] demod output with 63 history rows in front */
+	float        *audio;        /* [slots][k2max] audio, channel major */
+};
+
+struct WrTunerLaunch {
+	const float *cur;           /* this block's IQ, nframes frames (device) */
+	const float *hist;          /* last 63 IQ frames of the previous block (device) */
+	size_t       nframes;
+	unsigned int d1, d2;
+	unsigned int slots;
+	size_t       k1, k2;        /* frames per channel at channel / audio rate for this block */
+	size_t       k2max;         /* channel stride of audio */
+	int          nco_mode;
+};
+
+/* ---- kernel launchers (wr_kernels.hip); all return hipError_t ---- */
+hipError_t wrk_mix(hipStream_t st, const float *in, float *out, size_t nframes,
+                   unsigned int phase, int step, const float *table_dev);
+hipError_t wrk_fir(hipStream_t st, const float *in, size_t nframes, unsigned int channels,
+                   unsigned int decim, const float *coeff_dev, const float *hist_dev, float *out);
+hipError_t wrk_hist_update(hipStream_t st, const float *in, size_t nframes, unsigned int channels,
+                           float *hist_dev, float *scratch_dev);
+hipError_t wrk_demod(hipStream_t st, int mode, const float *in, size_t nframes, float prev_i,
+                     float prev_q, float *out);
+hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t count);
+
+hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
+                         const float *table_dev, const float *hi_dev, const float *lo_dev,
+                         int num_cus);
+hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
+                             float *dem_scratch);
+hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, float *hist,
+                          float *scratch);
+hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
+                           size_t col_offset_floats, unsigned int width_floats, float *dst);
+
+/* ---- FFT (wr_fft.hip) ---- */
+struct WrFftPlan {
+	unsigned int n;             /* transform size */
+	unsigned int n1, n2;        /* n = n1*n2; n2 == 1 for single-pass */
+	float *tw_n;                /* [n/2][2] twiddles of the full size (device) */
+	float *tw_sub;              /* [max(n1,n2)/2][2] twiddles of the LDS sub-transforms (device) */
+	float *window;              /* [n] (device) */
+	float *work;                /* [n][2] intermediate per frame in flight (device), batch-sized */
+	size_t work_frames;
+};
+hipError_t wrk_fft_frames(hipStream_t st, const WrFftPlan &P, const float *iq, size_t hop,
+                          size_t nframes_fft, float *bins_out /* or NULL */, float *db_out /* or NULL */);
+
+hipError_t wrk_bins_to_db(hipStream_t st, const float *bins, unsigned int n, float *db);
+
+#endif /* WR_INTERNAL_H_ */

@@ -1,0 +1,203 @@
+"""Thin Python handles over the C ABI: Device, Tuner (one FrontEnd's tuner with its
+Receivers), Spectrum (SpectrumSink).  Used by tests, bench.py and the examples; the
+arithmetic all happens in the HIP library.  Names follow the reference (radio.h:42-102).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, ptr
+
+
+class Device:
+    """wr_dev: a gfx950 device + the HIP stream all work is issued on."""
+
+    def __init__(self, index=0, stream=None):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        check(self.lib.wr_dev_open(C.byref(h), index, ptr(stream) if stream else None))
+        self.h = h
+        self.index = index
+
+    def close(self):
+        if self.h:
+            self.lib.wr_dev_close(self.h)
+            self.h = None
+
+    def sync(self):
+        check(self.lib.wr_dev_sync(self.h))
+
+    # --- raw device memory for tests that do not want torch --------------------
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.wr_dev_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, p):
+        check(self.lib.wr_dev_free(self.h, C.c_void_p(p)))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(max(arr.nbytes, 4))
+        check(self.lib.wr_dev_upload(self.h, C.c_void_p(p), ptr(arr), arr.nbytes))
+        return p
+
+    def download(self, p, count, dtype=np.float32):
+        out = np.empty(count, dtype=dtype)
+        check(self.lib.wr_dev_download(self.h, ptr(out), C.c_void_p(p), out.nbytes))
+        return out
+
+    # --- one kernel per reference block -----------------------------------------
+    def mix(self, iq, phase, phase_step):
+        """DownConverter::process on a host array; returns (mixed, new_phase)."""
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        n = iq.size // 2
+        din = self.upload(iq)
+        dout = self.malloc(max(iq.nbytes, 4))
+        ph = C.c_uint(phase)
+        check(self.lib.wr_mix(self.h, C.c_void_p(din), C.c_void_p(dout), n, C.byref(ph), phase_step))
+        out = self.download(dout, 2 * n)
+        self.free(din)
+        self.free(dout)
+        return out, ph.value
+
+    def fir_decimate(self, x, channels, decimation, coeff, history_dev):
+        """LowPass::process on a host array; history_dev is a device pointer kept by the caller."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        nframes = x.size // channels
+        nout = (nframes // decimation) * channels
+        din = self.upload(x)
+        dout = self.malloc(max(nout * 4, 4))
+        coeff = np.ascontiguousarray(coeff, dtype=np.float32)
+        check(self.lib.wr_fir_decimate(self.h, C.c_void_p(din), nframes, channels, decimation,
+                                       ptr(coeff), C.c_void_p(history_dev), C.c_void_p(dout)))
+        out = self.download(dout, nout)
+        self.free(din)
+        self.free(dout)
+        return out
+
+    def demod(self, mode, iq, prev):
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        n = iq.size // 2
+        din = self.upload(iq)
+        dout = self.malloc(max(n * 4, 4))
+        prev = np.array(prev, dtype=np.float32)
+        check(self.lib.wr_demod(self.h, mode, C.c_void_p(din), n, ptr(prev), C.c_void_p(dout)))
+        out = self.download(dout, n)
+        self.free(din)
+        self.free(dout)
+        return out, prev
+
+
+class Tuner:
+    """wr_tuner: every Receiver chain of one tuner, evaluated by one launch sequence."""
+
+    def __init__(self, dev, input_rate, max_channels, max_block_frames, nco=capi.WR_NCO_SPLIT):
+        self.dev = dev
+        self.lib = dev.lib
+        h = C.c_void_p()
+        check(self.lib.wr_tuner_create(C.byref(h), dev.h, input_rate, max_channels, max_block_frames, nco))
+        self.h = h
+        self.input_rate = input_rate
+
+    def destroy(self):
+        if self.h:
+            self.lib.wr_tuner_destroy(self.h)
+            self.h = None
+
+    def add_receiver(self, if_hz, chan_passband, chan_rate, mode, audio_passband, audio_rate):
+        """Receiver() + setFrontEnd(): the wiring of radio.cxx:62-90 with explicit parameters."""
+        c = C.c_int()
+        check(self.lib.wr_chan_add(self.h, C.byref(c)))
+        ch = c.value
+        check(self.lib.wr_chan_set_if(self.h, ch, if_hz))
+        check(self.lib.wr_chan_set_filter(self.h, ch, 0, chan_passband, chan_rate))
+        check(self.lib.wr_chan_set_filter(self.h, ch, 1, audio_passband, audio_rate))
+        check(self.lib.wr_chan_set_mode(self.h, ch, mode))
+        return ch
+
+    def remove_receiver(self, ch):
+        check(self.lib.wr_chan_remove(self.h, ch))
+
+    def set_if(self, ch, if_hz):
+        check(self.lib.wr_chan_set_if(self.h, ch, if_hz))
+
+    def set_mode(self, ch, mode):
+        check(self.lib.wr_chan_set_mode(self.h, ch, mode))
+
+    def set_filter(self, ch, stage, passband, out_rate):
+        check(self.lib.wr_chan_set_filter(self.h, ch, stage, passband, out_rate))
+
+    def submit_host(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        check(self.lib.wr_tuner_submit(self.h, ptr(iq), iq.size // 2, capi.WR_HOST))
+        self.dev.sync()   # the host array may be released by the caller
+
+    def submit_device(self, dev_ptr, nframes):
+        check(self.lib.wr_tuner_submit(self.h, ptr(dev_ptr), nframes, capi.WR_DEVICE))
+
+    def fetch(self, ch, stage, capacity):
+        out = np.empty(max(capacity, 1), dtype=np.float32)
+        n = C.c_size_t()
+        check(self.lib.wr_chan_fetch(self.h, ch, stage, ptr(out), capacity, C.byref(n)))
+        return out[: n.value].copy()
+
+    def state(self, ch):
+        ph = C.c_uint()
+        prev = np.zeros(2, dtype=np.float32)
+        check(self.lib.wr_chan_get_state(self.h, ch, C.byref(ph), ptr(prev)))
+        return ph.value, prev
+
+    def set_state(self, ch, phase, prev=None):
+        p = None if prev is None else np.ascontiguousarray(prev, dtype=np.float32)
+        check(self.lib.wr_chan_set_state(self.h, ch, phase, ptr(p)))
+
+    def audio_dev(self):
+        a = C.c_void_p()
+        stride = C.c_size_t()
+        frames = C.c_size_t()
+        check(self.lib.wr_tuner_audio_dev(self.h, C.byref(a), C.byref(stride), C.byref(frames)))
+        return a.value, stride.value, frames.value
+
+
+class Spectrum:
+    """wr_spectrum: SpectrumSink (io/spectrumsink.h:44-68)."""
+
+    def __init__(self, dev, fft_size, hop=0):
+        self.dev = dev
+        self.lib = dev.lib
+        self.n = fft_size
+        h = C.c_void_p()
+        check(self.lib.wr_spectrum_create(C.byref(h), dev.h, fft_size, hop))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            self.lib.wr_spectrum_destroy(self.h)
+            self.h = None
+
+    def push_host(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        check(self.lib.wr_spectrum_push(self.h, ptr(iq), iq.size // 2, capi.WR_HOST))
+
+    def push_device(self, dev_ptr, nframes):
+        check(self.lib.wr_spectrum_push(self.h, ptr(dev_ptr), nframes, capi.WR_DEVICE))
+
+    def get_db(self):
+        out = np.empty(self.n, dtype=np.float32)
+        check(self.lib.wr_spectrum_get_db(self.h, ptr(out)))
+        return out
+
+    def get_bins(self):
+        out = np.empty(2 * self.n, dtype=np.float32)
+        check(self.lib.wr_spectrum_get_bins(self.h, ptr(out)))
+        return out
+
+    def frames_done(self):
+        n = C.c_ulong()
+        check(self.lib.wr_spectrum_frames_done(self.h, C.byref(n)))
+        return n.value
+
+    def batch_db(self, iq_dev, nframes_fft, db_dev):
+        check(self.lib.wr_spectrum_batch_db(self.h, ptr(iq_dev), nframes_fft, ptr(db_dev)))
