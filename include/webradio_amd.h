@@ -20,8 +20,8 @@
  *     [I0,Q0,I1,Q1,...] exactly like the reference's vector<sample_t> buffers.
  *   - pointers named *_dev are HIP device pointers on the context's device;
  *     pointers named *_host are ordinary host memory.
- *   - all work of one wr_dev is issued on one HIP stream (given by the caller, e.g.
- *     torch.cuda.current_stream().cuda_stream, or created by wr_dev_open).
+ *   - all work of one wr_dev is issued on one HIP stream given by the caller (e.g.
+ *     torch.cuda.current_stream().cuda_stream); NULL is HIP's default stream.
  *     Functions taking host pointers synchronise that stream before returning;
  *     functions taking only device pointers are asynchronous.
  *   - there is NO CPU fallback: without a GPU wr_dev_open fails with
@@ -100,7 +100,7 @@ int wr_spectrum_window(unsigned int fft_size, float *window_host);
 
 /* ---------------------------------------------------------- device ctx -- */
 /* Binds a device and a stream, uploads the NCO tables.  `hip_stream` is a
- * hipStream_t (may be NULL: a private stream is created). */
+ * hipStream_t; NULL means HIP's default (null) stream. */
 int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream);
 int wr_dev_close(wr_dev *dev);
 int wr_dev_sync(wr_dev *dev);
@@ -192,6 +192,15 @@ int wr_chan_fetch(wr_tuner *tuner, int chan, int stage, float *out_host, size_t 
 int wr_tuner_audio_dev(wr_tuner *tuner, const float **audio_dev, size_t *chan_stride,
                        size_t *frames);
 int wr_chan_slot(wr_tuner *tuner, int chan, int *slot);
+
+/* Profiling hook, the analogue of the reference's per-block profiler
+ * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75): with `enable` != 0 every submit
+ * brackets its dominant kernel (the fused mixer + channel filter) with HIP events on
+ * the tuner's stream.  wr_tuner_profile_read synchronises, returns the number of
+ * bracketed launches since the last read and their mean duration in milliseconds, and
+ * resets the counters. */
+int wr_tuner_profile(wr_tuner *tuner, int enable);
+int wr_tuner_profile_read(wr_tuner *tuner, unsigned int *launches, double *mean_ms);
 
 /* -------------------------------------------------------- SpectrumSink -- */
 /* SpectrumSink::init (io/spectrumsink.cxx:60-77).  fft_size: power of two

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures.  Run in the build container (where
+/root/reference exists): `python tests/golden/make_golden.py`.
+
+  demod_reference.npz   inputs + outputs of the REAL reference Demodulator
+                        (dsp/demodulator.cxx driven through DspSource::run by
+                        oracle/ref_harness.cxx), all four modes, 8 blocks of 512 frames.
+  dspblock_traces.json  scheduling traces of the REAL reference DspBlock runtime
+                        (dsp/dspblock.cxx) for the scenarios of oracle/ref_harness.cxx.
+  chain_oracle.npz      regression vectors of the ORACLE for the functions whose
+                        reference sources cannot be built here (<fftw3.h> missing):
+                        C1-style single receiver, 4 blocks.  These pin the oracle to
+                        itself over time, NOT to the reference ("parity unpinned").
+Only data is written; no reference source text is stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import wr_oracle as o  # noqa: E402
+from webradio_amd import synth  # noqa: E402
+
+
+def main():
+    R = o.ref()
+    if R is None:
+        print("no /root/reference: nothing generated")
+        return 1
+    rng = np.random.default_rng(20260928)
+    iq = rng.standard_normal(2 * 4096).astype(np.float32)
+    iq[:16] = 0.0
+    iq[32:36] = [-0.0, 1.0, 0.0, -1.0]
+    out = {"iq": iq}
+    for m in ("AM", "FM", "USB", "LSB"):
+        out["out_" + m] = o.ref_demod(m, iq, 512)
+    np.savez_compressed(os.path.join(HERE, "demod_reference.npz"), **out)
+
+    traces = [o.harness_trace(R, i) for i in range(R.wr_harness_scenarios())]
+    json.dump(traces, open(os.path.join(HERE, "dspblock_traces.json"), "w"), indent=0)
+
+    c1 = synth.C1
+    n = 16384
+    rx = o.Receiver(c1["input_rate"], c1["if_hz"], c1["chan_passband"], c1["chan_rate"], o.FM,
+                    c1["audio_passband"], c1["audio_rate"])
+    u8 = synth.rtl_u8_stream(4 * n)
+    iqf = o.u8_to_float(u8)
+    audio, chan = [], []
+    for b in range(4):
+        a, c, _ = rx.run(iqf[2 * n * b: 2 * n * (b + 1)])
+        audio.append(a)
+        chan.append(c)
+    np.savez_compressed(os.path.join(HERE, "chain_oracle.npz"), u8=u8, audio=np.concatenate(audio),
+                        chan_iq=np.concatenate(chan), block_frames=n,
+                        taps_chan=o.lowpass_design(c1["chan_passband"], c1["input_rate"]),
+                        taps_audio=o.lowpass_design(c1["audio_passband"], c1["chan_rate"]))
+    print("golden fixtures written to", HERE)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,110 @@
+"""-m gpu: SpectrumSink (wr_spectrum_*) against the oracle.
+
+Tolerance: the reference runs FFTW's float transform, the oracle a double-accumulated
+one, the GPU a float32 radix-2 Stockham.  Complex bins agree within
+BIN_RTOL * max|X| (float32 butterfly rounding grows ~ log2 N); dB values are compared
+on bins within 60 dB of the frame's peak with DB_ATOL."""
+import numpy as np
+import pytest
+
+from webradio_amd import capi, synth
+from webradio_amd.device import Spectrum
+
+pytestmark = pytest.mark.gpu
+
+BIN_RTOL = 2e-6
+DB_ATOL = 0.02
+
+
+def _check(spec_db, spec_bins, want_db, want_bins):
+    peak = np.abs(want_bins[0::2] + 1j * want_bins[1::2]).max()
+    assert np.abs(spec_bins - want_bins).max() <= BIN_RTOL * peak
+    strong = want_db >= want_db.max() - 60.0
+    assert np.abs(spec_db[strong] - want_db[strong]).max() <= DB_ATOL
+
+
+@pytest.mark.parametrize("n", [8, 512, 4096, 8192, 16384, 65536])
+def test_spectrum_sizes(dev, oracle, n):
+    fs = 2_400_000
+    iq = synth.fm_stream(n, fs, [100_000, -450_000, 700_001], amp=0.2, noise_dbfs=-50, seed=n)
+    s = Spectrum(dev, n)
+    s.push_host(iq)
+    assert s.frames_done() == 1
+    o = oracle.Spectrum(n)
+    o.process(iq)
+    _check(s.get_db(), s.get_bins(), o.get(), o.bins())
+    s.destroy()
+
+
+def test_default_size_known_answer(dev):
+    # N = 512, tone at +100 kHz, fs 2.4 M -> peak bin 277
+    n = 512
+    t = np.arange(n) / 2_400_000.0
+    z = 0.5 * np.exp(2j * np.pi * 100_000 * t)
+    iq = np.empty(2 * n, np.float32)
+    iq[0::2], iq[1::2] = z.real, z.imag
+    s = Spectrum(dev, n)
+    s.push_host(iq)
+    assert int(np.argmax(s.get_db())) == 277
+    s.destroy()
+
+
+def test_streaming_partial_frames(dev, oracle):
+    """Frames straddle pushes of arbitrary size (spectrumsink.cxx:101-121)."""
+    n = 1024
+    iq = synth.fm_stream(5 * n + 300, 2_400_000, [250_000], amp=0.3)
+    s, o = Spectrum(dev, n), oracle.Spectrum(n)
+    with pytest.raises(capi.WrError):
+        s.get_db()                                      # Q8: nothing transformed yet
+    pos = 0
+    for chunk in (100, 924, 1, 2047, 1500, 848):
+        part = iq[2 * pos: 2 * (pos + chunk)]
+        pos += chunk
+        s.push_host(part)
+        o.process(part)
+        assert s.frames_done() == o.frames_done
+        if o.frames_done:
+            _check(s.get_db(), s.get_bins(), o.get(), o.bins())
+    s.destroy()
+
+
+def test_overlap_hop(dev, oracle):
+    """50 % overlap (BASELINE config 3): each frame is an ordinary reference frame fed the
+    overlapped samples explicitly."""
+    n, hop = 4096, 2048
+    iq = synth.fm_stream(n + 5 * hop, 2_400_000, [-300_000], amp=0.3)
+    s = Spectrum(dev, n, hop)
+    s.push_host(iq)
+    assert s.frames_done() == 6
+    o = oracle.Spectrum(n)
+    o.process(iq[2 * 5 * hop: 2 * (5 * hop + n)])
+    _check(s.get_db(), s.get_bins(), o.get(), o.bins())
+    s.destroy()
+
+
+def test_batch_waterfall_rows(dev, oracle):
+    import torch
+    n, hop, rows = 65536, 32768, 5
+    iq = synth.fm_stream(n + (rows - 1) * hop, 100_000_000, [12_500_000, -30_000_000], amp=0.3)
+    x = torch.from_numpy(iq).cuda()
+    out = torch.empty(rows * n, dtype=torch.float32, device="cuda")
+    s = Spectrum(dev, n, hop)
+    s.batch_db(x, rows, out)
+    dev.sync()
+    got = out.cpu().numpy().reshape(rows, n)
+    for r in (0, 3, 4):
+        frame = iq[2 * r * hop: 2 * (r * hop + n)]
+        o = oracle.Spectrum(n)
+        o.process(frame)
+        want = o.get()
+        strong = want >= want.max() - 60.0
+        assert np.abs(got[r][strong] - want[strong]).max() <= DB_ATOL
+    s.destroy()
+
+
+def test_bad_sizes(dev):
+    import ctypes as C
+    h = C.c_void_p()
+    assert dev.lib.wr_spectrum_create(C.byref(h), dev.h, 500, 0) == capi.WR_ERR_ARG   # spectrumsink.cxx:53-56
+    assert b"power of 2" in dev.lib.wr_last_error()
+    assert dev.lib.wr_spectrum_create(C.byref(h), dev.h, 512, 1024) == capi.WR_ERR_ARG

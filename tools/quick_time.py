@@ -1,0 +1,35 @@
+"""Quick C2-size timing of the fused tuner path (development aid; bench.py is the contract)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from webradio_amd import capi, synth
+from webradio_amd.device import Device, Tuner
+
+c2 = synth.C2
+fs, n = c2["input_rate"], c2["block_frames"]
+nch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+modes = {"split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT}
+which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["split", "exact"]
+ifs = synth.c2_ifs(nch)
+stream = torch.cuda.current_stream().cuda_stream
+dev = Device(0, stream)
+x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
+torch.cuda.synchronize()
+for name in which:
+    t = Tuner(dev, fs, nch, n, modes[name])
+    for f in ifs:
+        t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
+    for _ in range(2):
+        t.submit_device(x, n)
+    torch.cuda.synchronize()
+    reps = 10 if name == "split" else 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        t.submit_device(x, n)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("%s: %d ch, %.3f ms/block, %.1f Msps, %.1f GB/s algorithmic (%.2f%% of 8 TB/s)" % (
+        name, nch, ms, n / ms / 1e3, n * 8.512 / ms / 1e6, n * 8.512 / ms / 1e6 / 8000 * 100))
+    t.destroy()

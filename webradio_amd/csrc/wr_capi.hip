@@ -93,6 +93,11 @@ struct wr_tuner {
 	float *in_hist;            /* [63][2] */
 	float *in_hist_scratch;    /* [63][2] */
 	bool submitted;
+	bool profiling;
+	std::vector<hipEvent_t> ev;    /* start/stop pairs */
+	size_t ev_used;                /* events recorded and not yet read */
+	double prof_ms;
+	unsigned int prof_n;
 };
 
 struct wr_spectrum {
@@ -218,17 +223,10 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	memset(d, 0, sizeof(*d));
 	d->device = device_index;
 	d->num_cus = prop.multiProcessorCount;
-	if (hip_stream) {
-		d->stream = (hipStream_t)hip_stream;
-		d->own_stream = false;
-	} else {
-		e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
-		if (e != hipSuccess) {
-			delete d;
-			return fail(WR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-		}
-		d->own_stream = true;
-	}
+	/* NULL selects HIP's default (null) stream -- which is also what
+	 * torch.cuda.current_stream().cuda_stream is unless the caller switched streams */
+	d->stream = (hipStream_t)hip_stream;
+	d->own_stream = false;
 
 	std::vector<float> table(WR_TABLE_SIZE), hi(2 * WR_SPLIT_N), lo(2 * WR_SPLIT_N);
 	wrd_sin_table(table.data());
@@ -461,6 +459,10 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->in_stage = nullptr;
 	t->in_hist = t->in_hist_scratch = nullptr;
 	t->submitted = false;
+	t->profiling = false;
+	t->ev_used = 0;
+	t->prof_ms = 0.0;
+	t->prof_n = 0;
 	int rc = dev_alloc_zero(&t->in_hist, (size_t)WR_HIST * 2);
 	if (!rc)
 		rc = dev_alloc_zero(&t->in_hist_scratch, (size_t)WR_HIST * 2);
@@ -480,6 +482,8 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 	(void)hipStreamSynchronize(t->dev->stream);
 	for (Group *g : t->groups)
 		group_free(g);
+	for (hipEvent_t e : t->ev)
+		(void)hipEventDestroy(e);
 	(void)hipFree(t->in_stage);
 	(void)hipFree(t->in_hist);
 	(void)hipFree(t->in_hist_scratch);
@@ -644,8 +648,6 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
 		return fail(WR_ERR_ARG, "stage must be 0 (channel) or 1 (audio)");
 	if (!decim)
 		return fail(WR_ERR_ARG, "decimation must be >= 1");
-	if (stage == 0 && decim > t->max_block_frames)
-		return fail(WR_ERR_ARG, "decimation %u exceeds max_block_frames", decim);
 	memcpy(c->taps[stage], coeff, sizeof(float) * WR_FIR_LENGTH);
 	c->decim[stage] = decim;
 	c->have[stage] = true;
@@ -809,6 +811,46 @@ static int group_upload(wr_tuner *t, Group *g)
 	return WR_OK;
 }
 
+/* fold recorded event pairs into the running mean once more than `keep` pairs are pending */
+static int prof_drain(wr_tuner *t, size_t keep)
+{
+	if (t->ev_used / 2 <= keep)
+		return WR_OK;
+	HIP_TRY(hipStreamSynchronize(t->dev->stream));
+	for (size_t i = 0; i + 1 < t->ev_used; i += 2) {
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
+		t->prof_ms += ms;
+		t->prof_n++;
+	}
+	t->ev_used = 0;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_profile(wr_tuner *t, int enable)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	t->profiling = enable != 0;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_profile_read(wr_tuner *t, unsigned int *launches, double *mean_ms)
+{
+	if (!t || !launches || !mean_ms)
+		return fail(WR_ERR_ARG, "wr_tuner_profile_read: bad argument");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	int rc = prof_drain(t, 0);
+	if (rc)
+		return rc;
+	*launches = t->prof_n;
+	*mean_ms = t->prof_n ? t->prof_ms / t->prof_n : 0.0;
+	t->prof_ms = 0.0;
+	t->prof_n = 0;
+	return WR_OK;
+}
+
 extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int where)
 {
 	if (!t || (nframes && !iq))
@@ -857,7 +899,22 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		L.k2 = L.k1 / g->d2;
 		L.k2max = g->k2max;
 		L.nco_mode = t->nco_mode;
+		if (t->profiling) {
+			int rc = prof_drain(t, 64);
+			if (rc)
+				return rc;
+			while (t->ev.size() < t->ev_used + 2) {
+				hipEvent_t e;
+				HIP_TRY(hipEventCreate(&e));
+				t->ev.push_back(e);
+			}
+			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
+		}
 		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, d->table, d->hi_cs, d->lo_cs, d->num_cus));
+		if (t->profiling) {
+			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
+			t->ev_used += 2;
+		}
 		HIP_TRY(wrk_tuner_demod(st, L, g->dev));
 		HIP_TRY(wrk_tuner_audio(st, L, g->dev));
 		HIP_TRY(wrk_tuner_advance(st, L, g->dev, g->dem_scratch));

@@ -103,7 +103,9 @@ __device__ __forceinline__ float demod_one(int mode, float i, float q, float pi_
 {
 	switch (mode) {
 	case WR_AM:
-		return __fsqrt_rn(i * i + q * q);
+		/* correctly rounded like glibc's sqrtf: sqrt in double then one narrowing is exact
+		 * for float inputs (53 >= 2*24 + 2) */
+		return (float)sqrt((double)(i * i + q * q));
 	case WR_FM: {
 		float ii = i * pi_ + q * pq_;
 		float qq = q * pi_ - i * pq_;

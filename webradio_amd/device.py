@@ -153,6 +153,16 @@ class Tuner:
         p = None if prev is None else np.ascontiguousarray(prev, dtype=np.float32)
         check(self.lib.wr_chan_set_state(self.h, ch, phase, ptr(p)))
 
+    def profile(self, enable):
+        check(self.lib.wr_tuner_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(launches, mean milliseconds) of the dominant kernel since the last read"""
+        n = C.c_uint()
+        ms = C.c_double()
+        check(self.lib.wr_tuner_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def audio_dev(self):
         a = C.c_void_p()
         stride = C.c_size_t()
