@@ -23,6 +23,7 @@ for name in which:
         t.submit_device(x, n)
     torch.cuda.synchronize()
     reps = 10 if name == "split" else 3
+    t.profile(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -30,6 +31,8 @@ for name in which:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    nl, dms = t.profile_read()
+    print("%s: ddc kernel %.4f ms (%d launches)" % (name, dms, nl))
     print("%s: %d ch, %.3f ms/block, %.1f Msps, %.1f GB/s algorithmic (%.2f%% of 8 TB/s)" % (
         name, nch, ms, n / ms / 1e3, n * 8.512 / ms / 1e6, n * 8.512 / ms / 1e6 / 8000 * 100))
     t.destroy()

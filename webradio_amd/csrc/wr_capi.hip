@@ -73,9 +73,11 @@ struct Group {
 	unsigned int slots;
 	size_t k1max, k2max;
 	WrGroupDev dev;
-	float *dem_scratch;        /* [63][slots] */
+	int parity;                /* index of the current ping-pong buffers (prev_iq, dem) */
+	int last_parity;           /* parity the last submit wrote its demod rows with */
 	std::vector<int> owner;    /* slot -> chan or -1 */
 	bool dirty;                /* parameters must be uploaded before the next launch */
+	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -90,8 +92,8 @@ struct wr_tuner {
 	std::vector<Chan> chans;
 	std::vector<Group *> groups;
 	float *in_stage;           /* [max_block_frames][2] for WR_HOST submits */
-	float *in_hist;            /* [63][2] */
-	float *in_hist_scratch;    /* [63][2] */
+	float *in_hist[2];         /* [63][2] ping-pong: last 63 IQ frames of the previous block */
+	int in_par;
 	bool submitted;
 	bool profiling;
 	std::vector<hipEvent_t> ev;    /* start/stop pairs */
@@ -389,11 +391,12 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.mode);
 	(void)hipFree(g->dev.taps1);
 	(void)hipFree(g->dev.taps2);
-	(void)hipFree(g->dev.prev_iq);
+	(void)hipFree(g->dev.prev_iq[0]);
+	(void)hipFree(g->dev.prev_iq[1]);
 	(void)hipFree(g->dev.chan_iq);
-	(void)hipFree(g->dev.dem);
+	(void)hipFree(g->dev.dem[0]);
+	(void)hipFree(g->dev.dem[1]);
 	(void)hipFree(g->dev.audio);
-	(void)hipFree(g->dem_scratch);
 	delete g;
 }
 
@@ -403,7 +406,7 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!g)
 		return fail(WR_ERR_NOMEM, "out of memory");
 	memset(&g->dev, 0, sizeof(g->dev));
-	g->dem_scratch = nullptr;
+	g->parity = g->last_parity = 0;
 	g->d1 = d1;
 	g->d2 = d2;
 	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
@@ -413,6 +416,7 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 		g->k2max = 1;
 	g->owner.assign(g->slots, -1);
 	g->dirty = true;
+	g->uniform_taps = false;
 	g->last_k1 = g->last_k2 = 0;
 	g->active = 0;
 	const size_t S = g->slots;
@@ -424,11 +428,12 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
-	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq, S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq, (g->k1max ? g->k1max : 1) * S * 2);
-	if (!rc) rc = dev_alloc_zero(&g->dev.dem, (WR_HIST + g->k1max) * S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], (WR_HIST + g->k1max) * S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], (WR_HIST + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
-	if (!rc) rc = dev_alloc_zero(&g->dem_scratch, (size_t)WR_HIST * S);
 	if (rc) {
 		group_free(g);
 		return rc;
@@ -457,15 +462,16 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->nco_mode = nco_mode;
 	t->keep_mask = 0;
 	t->in_stage = nullptr;
-	t->in_hist = t->in_hist_scratch = nullptr;
+	t->in_hist[0] = t->in_hist[1] = nullptr;
+	t->in_par = 0;
 	t->submitted = false;
 	t->profiling = false;
 	t->ev_used = 0;
 	t->prof_ms = 0.0;
 	t->prof_n = 0;
-	int rc = dev_alloc_zero(&t->in_hist, (size_t)WR_HIST * 2);
+	int rc = dev_alloc_zero(&t->in_hist[0], (size_t)WR_HIST * 2);
 	if (!rc)
-		rc = dev_alloc_zero(&t->in_hist_scratch, (size_t)WR_HIST * 2);
+		rc = dev_alloc_zero(&t->in_hist[1], (size_t)WR_HIST * 2);
 	if (rc) {
 		wr_tuner_destroy(t);
 		return rc;
@@ -485,8 +491,8 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 	for (hipEvent_t e : t->ev)
 		(void)hipEventDestroy(e);
 	(void)hipFree(t->in_stage);
-	(void)hipFree(t->in_hist);
-	(void)hipFree(t->in_hist_scratch);
+	(void)hipFree(t->in_hist[0]);
+	(void)hipFree(t->in_hist[1]);
 	delete t;
 	return WR_OK;
 }
@@ -561,7 +567,7 @@ static int chan_unseat(wr_tuner *t, Chan &c, bool keep_state)
 		return WR_ERR_HIP;
 	HIP_TRY(hipStreamSynchronize(t->dev->stream));
 	if (keep_state)
-		HIP_TRY(hipMemcpy(c.prev_iq, g->dev.prev_iq + 2 * c.slot, 2 * sizeof(float),
+		HIP_TRY(hipMemcpy(c.prev_iq, g->dev.prev_iq[g->parity] + 2 * c.slot, 2 * sizeof(float),
 		                  hipMemcpyDeviceToHost));
 	g->owner[c.slot] = -1;
 	g->active--;
@@ -722,7 +728,7 @@ extern "C" int wr_chan_get_state(wr_tuner *t, int chan, unsigned int *phase, flo
 			if (dev_bind(t->dev))
 				return WR_ERR_HIP;
 			HIP_TRY(hipStreamSynchronize(t->dev->stream));
-			HIP_TRY(hipMemcpy(prev_iq, g->dev.prev_iq + 2 * c->slot, 2 * sizeof(float),
+			HIP_TRY(hipMemcpy(prev_iq, g->dev.prev_iq[g->parity] + 2 * c->slot, 2 * sizeof(float),
 			                  hipMemcpyDeviceToHost));
 		} else {
 			prev_iq[0] = c->prev_iq[0];
@@ -781,6 +787,29 @@ static int group_upload(wr_tuner *t, Group *g)
 			taps2[(size_t)j * S + s] = c.taps[1][j];
 		}
 	}
+	/* Receivers of a tuner nearly always share one channel filter (radio.cxx:78-79 sets
+	 * the same passband/rate for all).  When every 64-slot lane group is uniform, the
+	 * kernel folds the taps into the shared sample window; idle slots of such a group
+	 * are given the group's taps so that any slot can serve as its representative. */
+	bool uniform = true;
+	for (size_t base = 0; base < S && uniform; base += WR_LANES) {
+		int rep = -1;
+		for (size_t s = base; s < base + WR_LANES; ++s) {
+			int ci = g->owner[s];
+			if (ci < 0)
+				continue;
+			if (rep < 0)
+				rep = ci;
+			else if (memcmp(t->chans[ci].taps[0], t->chans[rep].taps[0], sizeof(float) * WR_FIR_LENGTH))
+				uniform = false;
+		}
+		if (rep >= 0 && uniform)
+			for (size_t s = base; s < base + WR_LANES; ++s)
+				if (g->owner[s] < 0)
+					for (int j = 0; j < WR_FIR_LENGTH; ++j)
+						taps1[(size_t)j * S + s] = t->chans[rep].taps[0][j];
+	}
+	g->uniform_taps = uniform;
 	/* pageable sources: hipMemcpyAsync stages them before returning */
 	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
@@ -797,12 +826,12 @@ static int group_upload(wr_tuner *t, Group *g)
 			c.phase_dirty = false;
 		}
 		if (c.prev_dirty) {
-			HIP_TRY(hipMemcpyAsync(g->dev.prev_iq + 2 * s, c.prev_iq, 2 * sizeof(float), hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(g->dev.prev_iq[g->parity] + 2 * s, c.prev_iq, 2 * sizeof(float), hipMemcpyHostToDevice, st));
 			c.prev_dirty = false;
 		}
 		if (c.dem_hist_reset) {
 			/* 63 history rows of this slot: one float per row, stride S */
-			HIP_TRY(hipMemset2DAsync(g->dev.dem + s, S * sizeof(float), 0, sizeof(float), WR_HIST, st));
+			HIP_TRY(hipMemset2DAsync(g->dev.dem[g->parity] + s, S * sizeof(float), 0, sizeof(float), WR_HIST, st));
 			c.dem_hist_reset = false;
 		}
 	}
@@ -878,6 +907,7 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		cur = t->in_stage;
 	}
 
+	bool hist_written = false;
 	for (Group *g : t->groups) {
 		if (g->active <= 0) {
 			g->last_k1 = g->last_k2 = 0;
@@ -890,7 +920,9 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		}
 		WrTunerLaunch L;
 		L.cur = cur;
-		L.hist = t->in_hist;
+		L.hist = t->in_hist[t->in_par];
+		L.hist_next = t->in_hist[t->in_par ^ 1];
+		L.parity = g->parity;
 		L.nframes = nframes;
 		L.d1 = g->d1;
 		L.d2 = g->d2;
@@ -899,6 +931,7 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		L.k2 = L.k1 / g->d2;
 		L.k2max = g->k2max;
 		L.nco_mode = t->nco_mode;
+		L.uniform_taps = g->uniform_taps ? 1 : 0;
 		if (t->profiling) {
 			int rc = prof_drain(t, 64);
 			if (rc)
@@ -917,11 +950,19 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		}
 		HIP_TRY(wrk_tuner_demod(st, L, g->dev));
 		HIP_TRY(wrk_tuner_audio(st, L, g->dev));
-		HIP_TRY(wrk_tuner_advance(st, L, g->dev, g->dem_scratch));
+		g->last_parity = g->parity;
+		if (L.k1) {
+			hist_written = true;       /* k_tuner_ddc stored the next input history */
+			g->parity ^= 1;            /* k_tuner_demod filled the other prev_iq / dem history */
+		} else {
+			HIP_TRY(wrk_tuner_advance(st, L, g->dev));
+		}
 		g->last_k1 = L.k1;
 		g->last_k2 = L.k2;
 	}
-	HIP_TRY(wrk_input_hist(st, cur, nframes, t->in_hist, t->in_hist_scratch));
+	if (!hist_written)
+		HIP_TRY(wrk_input_hist(st, cur, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
+	t->in_par ^= 1;
 
 	/* host mirrors of what k_tuner_advance did */
 	for (Chan &c : t->chans) {
@@ -970,7 +1011,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 			HIP_TRY(wrk_gather_rows(d->stream, g->dev.chan_iq, g->last_k1, S * 2, (size_t)c->slot * 2, 2,
 			                        d->scratch));
 		else
-			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem + (size_t)WR_HIST * S, g->last_k1, S,
+			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem[g->last_parity] + (size_t)WR_HIST * S, g->last_k1, S,
 			                        (size_t)c->slot, 1, d->scratch));
 		HIP_TRY(hipMemcpyAsync(out_host, d->scratch, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
 	}

@@ -35,21 +35,24 @@ struct WrGroupDev {
 	int          *mode;         /* wr_mode */
 	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */
 	float        *taps2;        /* [64][slots] audio-filter taps */
-	float        *prev_iq;      /* [slots][2] Demodulator::prev_i/prev_q */
+	float        *prev_iq[2];   /* [slots][2] Demodulator::prev_i/prev_q, ping-pong by block parity */
 	float        *chan_iq;      /* [k1max][slots][2] channel-filter output, time major */
-	float        *dem;          /* [63 + k1max][slots] demod output with 63 history rows in front */
+	float        *dem[2];       /* [63 + k1max][slots] demod output, 63 history rows in front; ping-pong */
 	float        *audio;        /* [slots][k2max] audio, channel major */
 };
 
 struct WrTunerLaunch {
 	const float *cur;           /* this block's IQ, nframes frames (device) */
 	const float *hist;          /* last 63 IQ frames of the previous block (device) */
+	float       *hist_next;     /* receives the history for the next block */
+	int          parity;        /* which of the group's ping-pong buffers is current */
 	size_t       nframes;
 	unsigned int d1, d2;
 	unsigned int slots;
 	size_t       k1, k2;        /* frames per channel at channel / audio rate for this block */
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
+	int          uniform_taps;  /* every 64-slot lane group carries one tap set (all its slots) */
 };
 
 /* ---- kernel launchers (wr_kernels.hip); all return hipError_t ---- */
@@ -68,10 +71,9 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
                          int num_cus);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
-hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
-                             float *dem_scratch);
-hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, float *hist,
-                          float *scratch);
+hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, const float *hist,
+                          float *hist_next);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
                            size_t col_offset_floats, unsigned int width_floats, float *dst);
 

@@ -23,6 +23,7 @@
 #include "wr_internal.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2f lds_v2f;
 
 #define PHASE_FLAG_ACTIVE   1
 #define PHASE_FLAG_HISTORY  2
@@ -110,7 +111,11 @@ __device__ __forceinline__ float demod_one(int mode, float i, float q, float pi_
 		float ii = i * pi_ + q * pq_;
 		float qq = q * pi_ - i * pq_;
 		/* atan2f(Re, Im) -- the reference's argument order -- then /M_PI/2.0 in double */
-		return (float)((double)atan2f(ii, qq) / 3.14159265358979323846 / 2.0);
+		/* reference: atan2f(..) / M_PI / 2.0 in double.  One double multiply by 1/(2*pi)
+		 * instead of two double divisions: differs from it by at most one float ulp, and
+		 * only when the quotient sits within 1e-16 of a float rounding boundary -- far
+		 * inside the atan2f tolerance this detector is tested to */
+		return (float)((double)atan2f(ii, qq) * 0.15915494309189533577);
 	}
 	case WR_USB:
 		return i + q;
@@ -188,6 +193,21 @@ __device__ __forceinline__ void mac(v2f xs, v2f cs, float hj, v2f &acc)
 	}
 }
 
+/* SPLIT NCO: issue the two LDS gathers for left-aligned phase P.  LDS byte address =
+ * table base | index << 8 | (lane & 31) << 3; the index byte of P is dropped straight
+ * into byte 1 of a copy of the base address with one SDWA move. */
+__device__ __forceinline__ void gather_split(unsigned int P, unsigned int &ah, unsigned int &al,
+                                             v2f &a, v2f &b)
+{
+	/* ah/al hold the base address; only their byte 1 is rewritten (UNUSED_PRESERVE) */
+	asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3"
+	    : "+v"(ah) : "v"(P));
+	asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2"
+	    : "+v"(al) : "v"(P));
+	a = *(const lds_v2f *)ah;                          /* cis(2*pi*coarse/256) */
+	b = *(const lds_v2f *)al;                          /* cis(2*pi*fine/65536) */
+}
+
 /*
  * k_tuner_ddc: DownConverter::process + channel LowPass::process for every channel
  * of a tuner (dsp/downconverter.cxx:91-114 feeding dsp/lowpass.cxx:131-162).
@@ -212,9 +232,16 @@ __device__ __forceinline__ void mac(v2f xs, v2f cs, float hj, v2f &acc)
  *                          on its own bank pair, so the gather is conflict-free
  *                          whatever the indices are.
  */
-template <int NCO>
+/* LDS plan of k_tuner_ddc: [0, 128 KiB) the two replicated NCO tables (SPLIT only),
+ * then one private 2 x 512 B sample window per wave (double buffered across units). */
+#define DDC_TABLE_BYTES   (2u * WR_SPLIT_N * 32u * 8u)
+#define DDC_WAVES         16u
+#define DDC_LDS_BYTES     (DDC_TABLE_BYTES + DDC_WAVES * 2u * 512u)
+
+template <int NCO, bool UTAPS>
 __global__ void __launch_bounds__(1024)
-k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist, size_t k1,
+k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
+            float2 *__restrict__ hist_next, size_t nframes, size_t k1,
             unsigned int d1, unsigned int slots,
             const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
             const unsigned int *__restrict__ hist_step, const int *__restrict__ flags,
@@ -222,7 +249,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist, siz
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs)
 {
-	extern __shared__ v2f lds_tables[];         /* SPLIT: [256][32] coarse then [256][32] fine */
+	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
 	const unsigned int lane = threadIdx.x & 63u;
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned int waves_per_wg = blockDim.x >> 6;
@@ -230,34 +257,55 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist, siz
 	if (NCO == WR_NCO_SPLIT) {
 		for (unsigned int e = threadIdx.x; e < WR_SPLIT_N * 32u; e += blockDim.x) {
 			const float2 hv = hi_cs[e >> 5], lv = lo_cs[e >> 5];
-			lds_tables[e] = (v2f){hv.x, hv.y};
-			lds_tables[WR_SPLIT_N * 32u + e] = (v2f){lv.x, lv.y};
+			lds[e] = (v2f){hv.x, hv.y};
+			lds[WR_SPLIT_N * 32u + e] = (v2f){lv.x, lv.y};
 		}
 		__syncthreads();
 	}
-	const v2f *hi_l = lds_tables + (lane & 31u);
-	const v2f *lo_l = lds_tables + WR_SPLIT_N * 32u + (lane & 31u);
+	const v2f *hi_l = lds + (lane & 31u);
+	const v2f *lo_l = lds + WR_SPLIT_N * 32u + (lane & 31u);
+	/* the same two bases as LDS byte addresses (the dynamic LDS block starts at 0: it is
+	 * the kernel's only LDS, so byte 1 of both is free for the table index) */
+	const unsigned int a_hi = (unsigned int)(uintptr_t)hi_l;
+	const unsigned int a_lo = (unsigned int)(uintptr_t)lo_l;
+	/* this wave's sample windows: 64 x float2 each, [buffer][tap] */
+	v2f *win = lds + (NCO == WR_NCO_SPLIT ? DDC_TABLE_BYTES / 8u : 0u) + wave * 128u;
+
+	/* the tuner's next input history = last 63 frames of [hist | cur] (lowpass.cxx:138-142
+	 * keeps them per LowPass; here once per tuner).  It goes to the OTHER history buffer,
+	 * so no reader of `hist` in this launch is disturbed. */
+	if (blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
+		const size_t f = nframes + lane;            /* frame index in [hist | cur] */
+		hist_next[lane] = (f < WR_HIST) ? hist[f] : cur[f - WR_HIST];
+	}
 
 	const unsigned int groups = slots >> 6;
 	const size_t units = k1 * groups;
 	const size_t wave_global = (size_t)blockIdx.x * waves_per_wg + wave;
 	const size_t wave_count = (size_t)gridDim.x * waves_per_wg;
 
-	/* a wave keeps to one lane group where it can, so its taps stay in registers */
+	/* a wave keeps to one lane group where it can, so its per-channel state stays put */
 	unsigned int loaded_g = 0xFFFFFFFFu;
-	float h[WR_FIR_LENGTH];
+	float h[UTAPS ? 1 : WR_FIR_LENGTH];         /* per-lane taps (general case)          */
+	float hlane = 0.0f;                         /* UTAPS: lane j holds the tap of sample j */
 	unsigned int p0 = 0, st = 0, hst = 0;
 	int fl = 0;
+	unsigned int buf = 0;
 
-	for (size_t u = wave_global; u < units; u += wave_count) {
+	for (size_t u = wave_global; u < units; u += wave_count, buf ^= 1u) {
 		/* g-major dealing: consecutive waves take consecutive k of the same group */
 		const unsigned int g = (unsigned int)(u / k1);
 		const size_t k = u - (size_t)g * k1;
 		const unsigned int s = g * 64u + lane;
 		if (g != loaded_g) {
+			if (UTAPS) {
+				/* every slot of the group carries the same taps (host guarantee) */
+				hlane = taps1[(size_t)(WR_FIR_LENGTH - 1 - lane) * slots + g * 64u];
+			} else {
 #pragma unroll
-			for (int j = 0; j < WR_FIR_LENGTH; ++j)
-				h[j] = taps1[(size_t)j * slots + s];
+				for (int j = 0; j < (UTAPS ? 1 : WR_FIR_LENGTH); ++j)
+					h[j] = taps1[(size_t)j * slots + s];
+			}
 			p0 = phase[s];
 			st = step[s];
 			hst = hist_step[s];
@@ -265,48 +313,108 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist, siz
 			loaded_g = g;
 		}
 
+		/* ---- the window: sample j of this output frame goes to lane j, then to LDS.
+		 * Every lane needs every sample; a tap reads its sample back with a broadcast
+		 * ds_read_b64 whose address is a constant plus an immediate -- no VALU work, no
+		 * scalar loads (they share lgkmcnt with the table gathers and return out of
+		 * order), no 64-lane vector broadcast loads (8 B x 64 lanes of return bandwidth
+		 * per tap). */
 		const long long n0 = (long long)k * d1 - WR_HIST;   /* input frame of tap j = 0 */
+		{
+			const long long n = n0 + lane;
+			/* (the tuner's history buffer starts out as zeros; whether THIS channel may use
+			 * it -- a receiver added later starts from an empty LowPass::block -- is decided
+			 * per lane where the sample is consumed) */
+			const float2 xf = (n >= 0) ? cur[n] : hist[WR_HIST + n];
+			if (UTAPS)
+				win[buf * 64u + lane] = (v2f){hlane * xf.x, hlane * xf.y};
+			else
+				win[buf * 64u + lane] = (v2f){xf.x, xf.y};
+		}
+		const lds_v2f *w = (const lds_v2f *)(win + buf * 64u);
 		v2f acc = {0.0f, 0.0f};
 
-		if (n0 >= 0) {
-			const float2 *x = cur + n0;                      /* wave-uniform */
+		if (n0 >= 0 && NCO == WR_NCO_SPLIT) {
+			unsigned int P = p0 + (unsigned int)n0 * st;
+			/* two-stage software pipeline over groups of NT taps: the table gathers of
+			 * group t+1 are in flight while group t is multiplied out */
+			constexpr int NT = UTAPS ? 4 : 2;        /* per-lane taps leave fewer registers */
+			v2f ta[2][NT], tb[2][NT];
+			unsigned int ah[NT], al[NT];             /* rotating address registers */
+#pragma unroll
+			for (int jj = 0; jj < NT; ++jj) {
+				ah[jj] = a_hi;
+				al[jj] = a_lo;
+			}
+#pragma unroll
+			for (int jj = 0; jj < NT; ++jj) {
+				gather_split(P, ah[jj], al[jj], ta[0][jj], tb[0][jj]);
+				P += st;
+			}
+#pragma unroll
+			for (int t = 0; t < WR_FIR_LENGTH / NT; ++t) {
+				if (t + 1 < WR_FIR_LENGTH / NT) {
+#pragma unroll
+					for (int jj = 0; jj < NT; ++jj) {
+						gather_split(P, ah[jj], al[jj], ta[(t + 1) & 1][jj], tb[(t + 1) & 1][jj]);
+						P += st;
+					}
+				}
+#pragma unroll
+				for (int jj = 0; jj < NT; ++jj) {
+					const int j = t * NT + jj;
+					const v2f xs = w[j];                     /* broadcast read, immediate offset */
+					const v2f a = ta[t & 1][jj], b = tb[t & 1][jj];
+					const float c = __builtin_fmaf(-a.y, b.y, a.x * b.x);
+					const float sn = __builtin_fmaf(a.x, b.y, a.y * b.x);
+					if (UTAPS) {
+						/* xs = coeff * sample already: acc += xs * conj(LO) */
+						acc.x = __builtin_fmaf(xs.y, sn, __builtin_fmaf(xs.x, c, acc.x));
+						acc.y = __builtin_fmaf(-xs.x, sn, __builtin_fmaf(xs.y, c, acc.y));
+					} else {
+						const float mi = __builtin_fmaf(xs.y, sn, xs.x * c);
+						const float mq = __builtin_fmaf(-xs.x, sn, xs.y * c);
+						const float hj = h[UTAPS ? 0 : WR_FIR_LENGTH - 1 - j];
+						acc.x = __builtin_fmaf(hj, mi, acc.x);
+						acc.y = __builtin_fmaf(hj, mq, acc.y);
+					}
+				}
+			}
+		} else if (n0 >= 0) {
+			/* EXACT: the reference's table and the reference's roundings, tap by tap */
 			unsigned int P = p0 + (unsigned int)n0 * st;
 #pragma unroll
 			for (int jb = 0; jb < WR_FIR_LENGTH; jb += 8) {
 #pragma unroll
 				for (int jj = 0; jj < 8; ++jj) {
 					const int j = jb + jj;
-					const float2 xf = x[j];
-					const v2f xs = {xf.x, xf.y};
+					const v2f xs = w[j];
 					const v2f cs = nco<NCO>(P, table, hi_l, lo_l);
 					P += st;
-					mac<NCO>(xs, cs, h[WR_FIR_LENGTH - 1 - j], acc);
+					mac<NCO>(xs, cs, h[UTAPS ? 0 : WR_FIR_LENGTH - 1 - j], acc);
 				}
-				/* keep the scheduler from hoisting every lookup of the 64 taps at once */
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		} else {
 			/* window reaches into the previous block (only the first ceil(63/D1) frames of
 			 * a block): those frames were mixed with the phase sequence and the phase step
 			 * of that block.  Rare, so taps come straight from memory, not registers. */
-			const bool have_hist = (fl & PHASE_FLAG_HISTORY) != 0;
 			for (int j = 0; j < WR_FIR_LENGTH; ++j) {
 				const long long n = n0 + j;
-				float2 xf;
-				unsigned int P;
-				if (n < 0) {
-					xf = hist[WR_HIST + n];
-					if (!have_hist)
-						xf = make_float2(0.0f, 0.0f);
-					P = p0 + (unsigned int)n * hst;
-				} else {
-					xf = cur[n];
-					P = p0 + (unsigned int)n * st;
-				}
-				const v2f xs = {xf.x, xf.y};
+				const unsigned int P = p0 + (unsigned int)n * (n < 0 ? hst : st);
+				v2f xs = w[j];
+				if (n < 0 && !(fl & PHASE_FLAG_HISTORY))
+					xs = (v2f){0.0f, 0.0f};
 				const v2f cs = nco<NCO>(P, table, hi_l, lo_l);
-				const float hj = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
-				mac<NCO>(xs, cs, hj, acc);
+				if (UTAPS) {
+					/* the window is premultiplied; same operation order as the fast path, so a
+					 * frame gives the same bits wherever the block boundaries fall */
+					acc.x = __builtin_fmaf(xs.y, cs.y, __builtin_fmaf(xs.x, cs.x, acc.x));
+					acc.y = __builtin_fmaf(-xs.x, cs.y, __builtin_fmaf(xs.y, cs.x, acc.y));
+				} else {
+					const float hj = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
+					mac<NCO>(xs, cs, hj, acc);
+				}
 			}
 		}
 		if (fl & PHASE_FLAG_ACTIVE)
@@ -314,73 +422,118 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist, siz
 	}
 }
 
-/* Demodulator::process for every channel (dsp/demodulator.cxx:77-115): thread
- * (k, s); the previous channel-rate frame is row k-1, or prev_iq for k = 0. */
+/* Demodulator::process for every channel (dsp/demodulator.cxx:77-115): thread (k, s);
+ * the previous channel-rate frame is row k-1, or prev_iq for k = 0.  The same launch
+ * also finishes the block for every channel (what DspBlock::run leaves behind in the
+ * members of the four blocks of a Receiver):
+ *   - DownConverter::phase advances by nframes steps; the step in force is remembered
+ *     (the next block's filter history was mixed with it)
+ *   - Demodulator::prev_i/q := last channel-rate frame        -> prev_next (ping-pong)
+ *   - audio LowPass history := last 63 demod outputs          -> dem_next rows 0..62
+ * All of these go to buffers no thread of this launch reads. */
+#define DEM_RPT 8u             /* consecutive rows per thread: the previous frame stays in registers */
 __global__ void __launch_bounds__(256)
-k_tuner_demod(const float2 *__restrict__ chan_iq, size_t k1, unsigned int slots,
-              const int *__restrict__ mode, const int *__restrict__ flags,
-              const float2 *__restrict__ prev_iq, float *__restrict__ dem)
+k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots, unsigned int nframes_lo,
+              const int *__restrict__ mode, int *__restrict__ flags,
+              unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+              unsigned int *__restrict__ hist_step,
+              const float2 *__restrict__ prev_iq, float2 *__restrict__ prev_next,
+              float *__restrict__ dem, float *__restrict__ dem_next)
 {
-	const size_t total = k1 * slots;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
-		const size_t k = o / slots;
-		const unsigned int s = (unsigned int)(o - k * slots);
-		if (!(flags[s] & PHASE_FLAG_ACTIVE))
-			continue;
-		const float2 z = chan_iq[o];
-		const float2 p = k ? chan_iq[o - slots] : prev_iq[s];
-		dem[(size_t)(WR_HIST + k) * slots + s] = demod_one(mode[s], z.x, z.y, p.x, p.y);
+	/* thread = (slot lane, row lane): 64 slots x 4 row lanes per workgroup, DEM_RPT rows each */
+	const unsigned int lane = threadIdx.x & 63u;
+	const unsigned int rl = threadIdx.x >> 6;
+	const unsigned int s = blockIdx.x * 64u + lane;
+	const unsigned int kbeg = (blockIdx.y * 4u + rl) * DEM_RPT;
+	const int fl = flags[s];
+	if ((fl & PHASE_FLAG_ACTIVE) && kbeg < k1) {
+		const int m = mode[s];
+		float2 p = kbeg ? chan_iq[(size_t)(kbeg - 1u) * slots + s] : prev_iq[s];
+		const unsigned int kend = (kbeg + DEM_RPT < k1) ? kbeg + DEM_RPT : k1;
+		for (unsigned int k = kbeg; k < kend; ++k) {
+			const float2 z = chan_iq[(size_t)k * slots + s];
+			const float v = demod_one(m, z.x, z.y, p.x, p.y);
+			dem[(size_t)(WR_HIST + k) * slots + s] = v;
+			if (k + WR_HIST >= k1)                      /* among the last 63 rows */
+				dem_next[(size_t)(k + WR_HIST - k1) * slots + s] = v;
+			p = z;
+		}
+		if (kend == k1)
+			prev_next[s] = p;
+	}
+	/* blocks shorter than the history: the older part of the next history comes from the
+	 * current history rows (not written by this launch) */
+	if (k1 < WR_HIST && blockIdx.y == 0 && (fl & PHASE_FLAG_ACTIVE))
+		for (unsigned int r = rl; r < WR_HIST - k1; r += 4u)
+			dem_next[(size_t)r * slots + s] = dem[(size_t)(k1 + r) * slots + s];
+	/* DownConverter::phase etc. -- nothing in this launch reads them */
+	if (blockIdx.y == 0 && rl == 0 && (fl & PHASE_FLAG_ACTIVE)) {
+		const unsigned int stp = step[s];
+		phase[s] = phase[s] + nframes_lo * stp;
+		hist_step[s] = stp;
+		flags[s] = fl | PHASE_FLAG_HISTORY;
 	}
 }
 
 /* audio LowPass::process for every channel (dsp/lowpass.cxx:131-162, 1 channel):
  * dem already carries its 63 history rows, so row k2*D2 + j is tap j's sample.
- * A 64x64 tile goes through LDS so that audio[s][k2] is written in rows. */
-__global__ void __launch_bounds__(256)
-k_tuner_audio(const float *__restrict__ dem, size_t k2, unsigned int d2, unsigned int slots,
-              const float *__restrict__ taps2, const int *__restrict__ flags,
-              float *__restrict__ audio, size_t k2max)
+ * Workgroup = 64 channel slots x `tk` output frames.  The (tk-1)*D2 + 64 demod rows the
+ * tile needs are staged in LDS once (each row is read by up to 64/D2 outputs), lanes
+ * run over slots so both the global rows and the LDS rows are contiguous per wave, and
+ * the finished 64 x tk tile is transposed through LDS so that audio[s][k2] (channel
+ * major, what each audio sink consumes) is written in runs. */
+#define AUD_ROWS 352u          /* staged demod rows: 352 x 64 x 4 B = 88 KiB */
+#define AUD_TMAX 32u
+#define AUD_THREADS 1024u
+__global__ void __launch_bounds__(AUD_THREADS)
+k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsigned int d2,
+              unsigned int tk, unsigned int slots, const float *__restrict__ taps2,
+              const int *__restrict__ flags, float *__restrict__ audio, size_t k2max)
 {
-	__shared__ float tile[64][65];
-	const unsigned int lane = threadIdx.x & 63u;       /* slot within the group */
-	const unsigned int row = threadIdx.x >> 6;         /* 0..3 */
+	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [64][64] taps, [AUD_TMAX][65] out */
+	float *stage = aud_lds;
+	float *taps = aud_lds + AUD_ROWS * 64u;
+	float *tile = taps + 64u * 64u;
+	const unsigned int lane = threadIdx.x & 63u;        /* slot within the group */
+	const unsigned int row = threadIdx.x >> 6;          /* 0..15 */
+	const unsigned int nrow = AUD_THREADS / 64u;
 	const unsigned int g = blockIdx.y;
 	const unsigned int s = g * 64u + lane;
-	const size_t kbase = (size_t)blockIdx.x * 64u;
+	const size_t kbase = (size_t)blockIdx.x * tk;
+	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
 
-	float h[WR_FIR_LENGTH];
-#pragma unroll
-	for (int j = 0; j < WR_FIR_LENGTH; ++j)
-		h[j] = taps2[(size_t)j * slots + s];
-
-	for (unsigned int r = row; r < 64u; r += 4u) {
-		const size_t k = kbase + r;
-		float acc = 0.0f;
-		if (k < k2) {
-			const float *x = dem + (k * d2) * slots + s;
-#pragma unroll
-			for (int j = 0; j < WR_FIR_LENGTH; ++j)
-				acc = acc + h[WR_FIR_LENGTH - 1 - j] * x[(size_t)j * slots];
-		}
-		tile[r][lane] = acc;
+	for (unsigned int j = row; j < WR_FIR_LENGTH; j += nrow)
+		taps[j * 64u + lane] = taps2[(size_t)j * slots + s];
+	const size_t r0 = kbase * d2;
+	for (unsigned int r = row; r < need; r += nrow) {
+		const size_t rr = r0 + r;
+		stage[r * 64u + lane] = (rr < rows_valid) ? dem[rr * slots + s] : 0.0f;
 	}
 	__syncthreads();
-	/* transposed write: thread (row, lane) writes slot (g*64 + r), time kbase + lane */
-	for (unsigned int r = row; r < 64u; r += 4u) {
-		const unsigned int so = g * 64u + r;
-		const size_t k = kbase + lane;
+	for (unsigned int kk = row; kk < tk; kk += nrow) {
+		const float *x = stage + (kk * d2) * 64u + lane;
+		float acc = 0.0f;
+#pragma unroll 16
+		for (int j = 0; j < WR_FIR_LENGTH; ++j)
+			acc = acc + taps[(WR_FIR_LENGTH - 1 - j) * 64 + lane] * x[j * 64];
+		tile[kk * 65u + lane] = acc;
+	}
+	__syncthreads();
+	/* transposed write: tk consecutive frames of one slot per tk threads */
+	for (unsigned int e = threadIdx.x; e < 64u * tk; e += AUD_THREADS) {
+		const unsigned int sl = e / tk, kk = e - sl * tk;
+		const unsigned int so = g * 64u + sl;
+		const size_t k = kbase + kk;
 		if (k < k2 && (flags[so] & PHASE_FLAG_ACTIVE))
-			audio[(size_t)so * k2max + k] = tile[lane][r];
+			audio[(size_t)so * k2max + k] = tile[kk * 65u + sl];
 	}
 }
 
-/* end-of-block state update: phases advance by nframes steps, Demodulator prev_i/q
- * become the last channel-rate frame, history flag set */
-__global__ void k_tuner_advance(unsigned int slots, unsigned int nframes_lo, size_t k1,
+/* a block too short to produce a channel-rate frame still advances the NCO
+ * (downconverter.cxx:103 runs per input frame) */
+__global__ void k_tuner_advance(unsigned int slots, unsigned int nframes_lo,
                                 unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-                                unsigned int *__restrict__ hist_step, int *__restrict__ flags,
-                                const float2 *__restrict__ chan_iq, float2 *__restrict__ prev_iq)
+                                unsigned int *__restrict__ hist_step, int *__restrict__ flags)
 {
 	unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= slots)
@@ -392,18 +545,6 @@ __global__ void k_tuner_advance(unsigned int slots, unsigned int nframes_lo, siz
 	phase[s] = phase[s] + nframes_lo * stp;
 	hist_step[s] = stp;
 	flags[s] = fl | PHASE_FLAG_HISTORY;
-	if (k1)
-		prev_iq[s] = chan_iq[(k1 - 1) * slots + s];
-}
-
-/* dem history rows for the next block = last 63 rows of [hist rows | new rows] */
-__global__ void k_dem_hist_build(const float *__restrict__ dem, size_t k1, unsigned int slots,
-                                 float *__restrict__ scratch)
-{
-	size_t total = (size_t)WR_HIST * slots;
-	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-	     e += (size_t)gridDim.x * blockDim.x)
-		scratch[e] = dem[k1 * slots + e];
 }
 
 /* strided row gather: dst[r*width + i] = src[r*row_stride + col_offset + i] */
@@ -481,6 +622,26 @@ hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t c
 	return hipGetLastError();
 }
 
+template <int NCO, bool UTAPS>
+static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaunch &L, const WrGroupDev &G,
+                             const float *table_dev, const float *hi_dev, const float *lo_dev)
+{
+	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES : (DDC_WAVES * 2u * 512u);
+	static bool attr_set = false;
+	if (!attr_set && lds > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_ddc<NCO, UTAPS>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess)
+			return e;
+		attr_set = true;
+	}
+	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
+		(const float2 *)L.cur, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes, L.k1, L.d1,
+		L.slots, G.phase, G.step, G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev,
+		(const float2 *)hi_dev, (const float2 *)lo_dev);
+	return hipGetLastError();
+}
+
 hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
                          int num_cus)
@@ -488,46 +649,32 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 	if (!L.k1 || !L.slots)
 		return hipSuccess;
 	const size_t units = L.k1 * (L.slots / 64);
-	const unsigned int waves_per_wg = 16;
-	unsigned int wgs = (unsigned int)((units + waves_per_wg - 1) / waves_per_wg);
+	unsigned int wgs = (unsigned int)((units + DDC_WAVES - 1) / DDC_WAVES);
 	if (L.nco_mode == WR_NCO_EXACT) {
-		/* no LDS: two workgroups per CU hide the gather latency */
+		/* small LDS footprint: two workgroups per CU hide the gather latency */
 		unsigned int cap = (unsigned int)num_cus * 2u;
 		if (wgs > cap)
 			wgs = cap;
-		k_tuner_ddc<WR_NCO_EXACT><<<wgs, 1024, 0, st>>>(
-			(const float2 *)L.cur, (const float2 *)L.hist, L.k1, L.d1, L.slots, G.phase, G.step,
-			G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev, (const float2 *)hi_dev,
-			(const float2 *)lo_dev);
-	} else {
-		unsigned int cap = (unsigned int)num_cus;
-		if (wgs > cap)
-			wgs = cap;
-		const size_t lds = (size_t)2 * WR_SPLIT_N * 32 * sizeof(float2);   /* 128 KiB */
-		static bool attr_set = false;
-		if (!attr_set) {
-			hipError_t e = hipFuncSetAttribute((const void *)k_tuner_ddc<WR_NCO_SPLIT>,
-			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			if (e != hipSuccess)
-				return e;
-			attr_set = true;
-		}
-		k_tuner_ddc<WR_NCO_SPLIT><<<wgs, 1024, lds, st>>>(
-			(const float2 *)L.cur, (const float2 *)L.hist, L.k1, L.d1, L.slots, G.phase, G.step,
-			G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev, (const float2 *)hi_dev,
-			(const float2 *)lo_dev);
+		return launch_ddc<WR_NCO_EXACT, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
 	}
-	return hipGetLastError();
+	/* the replicated tables take 128 KiB: one persistent workgroup per CU */
+	unsigned int cap = (unsigned int)num_cus;
+	if (wgs > cap)
+		wgs = cap;
+	if (L.uniform_taps)
+		return launch_ddc<WR_NCO_SPLIT, true>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
+	return launch_ddc<WR_NCO_SPLIT, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
 }
 
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
 {
-	size_t total = L.k1 * L.slots;
-	if (!total)
+	if (!L.k1 || !L.slots)
 		return hipSuccess;
-	k_tuner_demod<<<grid_for(total, 256, 4096), 256, 0, st>>>((const float2 *)G.chan_iq, L.k1, L.slots,
-	                                                          G.mode, G.flags, (const float2 *)G.prev_iq,
-	                                                          G.dem);
+	const int p = L.parity;
+	dim3 grid(L.slots / 64, (unsigned int)((L.k1 + 4 * DEM_RPT - 1) / (4 * DEM_RPT)));
+	k_tuner_demod<<<grid, 256, 0, st>>>(
+		(const float2 *)G.chan_iq, (unsigned int)L.k1, L.slots, (unsigned int)L.nframes, G.mode, G.flags, G.phase, G.step,
+		G.hist_step, (const float2 *)G.prev_iq[p], (float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1]);
 	return hipGetLastError();
 }
 
@@ -535,28 +682,38 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 {
 	if (!L.k2 || !L.slots)
 		return hipSuccess;
-	dim3 grid((unsigned int)((L.k2 + 63) / 64), L.slots / 64);
-	k_tuner_audio<<<grid, 256, 0, st>>>(G.dem, L.k2, L.d2, L.slots, G.taps2, G.flags, G.audio, L.k2max);
+	/* as many output frames per tile as the staged rows allow */
+	unsigned int tk = AUD_TMAX;
+	if (L.d2 > 1 && (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u < tk)
+		tk = (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u;
+	const size_t lds = (AUD_ROWS * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_audio,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess)
+			return e;
+		attr_set = true;
+	}
+	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots / 64);
+	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
+	                                      G.taps2, G.flags, G.audio, L.k2max);
 	return hipGetLastError();
 }
 
-hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
-                             float *dem_scratch)
+hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
 {
 	if (!L.slots)
 		return hipSuccess;
-	k_tuner_advance<<<(L.slots + 255) / 256, 256, 0, st>>>(L.slots, (unsigned int)L.nframes, L.k1,
-	                                                       G.phase, G.step, G.hist_step, G.flags,
-	                                                       (const float2 *)G.chan_iq, (float2 *)G.prev_iq);
-	size_t total = (size_t)WR_HIST * L.slots;
-	k_dem_hist_build<<<grid_for(total, 256, 256), 256, 0, st>>>(G.dem, L.k1, L.slots, dem_scratch);
-	k_copy_f32<<<grid_for(total, 256, 256), 256, 0, st>>>(dem_scratch, G.dem, total);
+	k_tuner_advance<<<(L.slots + 255) / 256, 256, 0, st>>>(L.slots, (unsigned int)L.nframes, G.phase, G.step,
+	                                                       G.hist_step, G.flags);
 	return hipGetLastError();
 }
 
-hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, float *hist, float *scratch)
+hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, const float *hist, float *hist_next)
 {
-	return wrk_hist_update(st, cur, nframes, 2, hist, scratch);
+	k_hist_build<<<1, 128, 0, st>>>(cur, nframes, 2, hist, hist_next);
+	return hipGetLastError();
 }
 
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
