@@ -192,6 +192,14 @@ int wr_chan_fetch(wr_tuner *tuner, int chan, int stage, float *out_host, size_t 
 int wr_tuner_audio_dev(wr_tuner *tuner, const float **audio_dev, size_t *chan_stride,
                        size_t *frames);
 int wr_chan_slot(wr_tuner *tuner, int chan, int *slot);
+/* every channel's audio of the last submit in ONE device-to-host copy (what the 256
+ * AudioStreamManager sinks of a tuner consume, web/audiostream.cxx:65-73): channel slot s
+ * lands at out_host + s * (*chan_stride); *slots_used rows are copied.  Synchronises. */
+int wr_tuner_fetch_audio_all(wr_tuner *tuner, float *out_host, size_t out_capacity,
+                             size_t *chan_stride, size_t *frames, unsigned int *slots_used);
+/* LowPass::deinit + init (dsp/lowpass.cxx:118-129, 81-116): both filter histories of the
+ * channel become empty again; NCO phase and Demodulator prev_i/q are kept (quirk Q5). */
+int wr_chan_reset_history(wr_tuner *tuner, int chan);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
  * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75): with `enable` != 0 every submit

@@ -1,0 +1,124 @@
+/*
+ * host_pipeline.cxx -- drives the host runtime the way webradio's main.cxx does
+ * (main.cxx:71-122): a FrontEnd around a Tuner, Receivers attached to it, Radio::run()
+ * in a loop -- but with a replaying tuner instead of an RTL-SDR stick and the audio
+ * collected from each Receiver's terminal sink.  TEST INFRASTRUCTURE.
+ *
+ * Built twice against the SAME headers (webradio_amd/host):
+ *   libwr_host_pipeline.so      with this repo's radio.cxx
+ *   oracle/_ref/libwr_boundary.so   with the REFERENCE's radio.cxx, compiled unchanged
+ *                                   from /root/reference/src/radio.cxx (the drop-in proof)
+ */
+#include <string.h>
+
+#include <vector>
+
+#include "radio.h"
+
+namespace {
+
+const float *g_iq = NULL;
+size_t g_frames = 0, g_pos = 0;
+unsigned int g_rate = 0, g_block = 0;
+
+/* a tuner that replays a caller-supplied IQ recording block by block */
+class ReplayTuner : public Tuner {
+public:
+	ReplayTuner(const string &name) : Tuner(name, "ReplayTuner") {
+		_name = "replay";
+		_manufacturer = "webradio_amd tests";
+	}
+protected:
+	bool init() { return true; }
+	void deinit() {}
+	bool process(const vector<sample_t> &, vector<sample_t> &out) {
+		size_t frames = out.size() / 2;
+		if (g_pos + frames > g_frames)
+			return false;
+		memcpy(out.data(), g_iq + 2 * g_pos, out.size() * sizeof(float));
+		g_pos += frames;
+		return true;
+	}
+};
+
+Tuner *makeTuner(const string &name) { return new ReplayTuner(name); }
+
+} // namespace
+
+extern "C" {
+
+/* Runs `nrx` receivers over the recording.  modes: Demodulator::Mode per receiver.
+ * audio_out receives nrx rows of `audio_cap` floats; *audio_len = samples per receiver.
+ * With `retune_at` >= 0 receiver 0 is retuned to `retune_if` before that block (the
+ * REST handlers do this from other threads, receiverhandler.cxx:130-137).
+ * spectrum_out (optional) receives fft_size dB values from FrontEnd::spectrum().
+ * Returns 0, or a negative stage code. */
+int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
+                unsigned int nrx, const int *if_hz, const int *modes,
+                unsigned int chan_passband, unsigned int chan_rate,
+                unsigned int audio_passband, unsigned int audio_rate,
+                int retune_at, int retune_if,
+                float *audio_out, size_t audio_cap, size_t *audio_len,
+                unsigned int fft_size, float *spectrum_out)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	g_pos = 0;
+	g_rate = rate;
+	g_block = block_frames;
+
+	FrontEnd *fe = new FrontEnd(makeTuner);
+	fe->tuner()->setSampleRate(rate);
+	fe->tuner()->setChannels(2);
+	fe->tuner()->setBlockSize(block_frames * 2);
+	if (fft_size)
+		fe->spectrum()->setFftSize(fft_size);
+
+	std::vector<Receiver *> rx(nrx);
+	for (unsigned int n = 0; n < nrx; n++) {
+		rx[n] = new Receiver();
+		rx[n]->downconverter()->setIF(if_hz[n]);
+		rx[n]->channelFilter()->setPassband(chan_passband);
+		rx[n]->channelFilter()->setOutputSampleRate(chan_rate);
+		rx[n]->audioFilter()->setPassband(audio_passband);
+		rx[n]->audioFilter()->setOutputSampleRate(audio_rate);
+		rx[n]->demodulator()->setMode((Demodulator::Mode)modes[n]);
+		rx[n]->stream()->setCapacity(audio_cap);
+		rx[n]->setFrontEnd(fe);
+	}
+	int rc = 0;
+	if (!fe->tuner()->start()) {
+		rc = -1;
+	} else {
+		size_t blocks = nframes / block_frames;
+		for (size_t b = 0; b < blocks; b++) {
+			if ((long)b == (long)retune_at && nrx)
+				rx[0]->downconverter()->setIF(retune_if);
+			Radio::run();
+		}
+		if (spectrum_out && fft_size)
+			fe->spectrum()->getSpectrum(spectrum_out);
+		size_t len = nrx ? rx[0]->stream()->samples().size() : 0;
+		for (unsigned int n = 0; n < nrx && rc == 0; n++) {
+			const vector<float> &a = rx[n]->stream()->samples();
+			if (a.size() != len || len > audio_cap)
+				rc = -2;
+			else
+				memcpy(audio_out + (size_t)n * audio_cap, a.data(), len * sizeof(float));
+		}
+		*audio_len = len;
+		Radio::profile();
+		fe->tuner()->stop();
+	}
+	for (unsigned int n = 0; n < nrx; n++)
+		delete rx[n];
+	delete fe;
+	return rc;
+}
+
+int wr_host_registry_sizes(void)
+{
+	return (int)(Radio::frontEnds().size() * 1000 + Radio::receivers().size());
+}
+
+} // extern "C"

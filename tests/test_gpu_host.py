@@ -1,0 +1,132 @@
+"""-m gpu: the C++ host runtime (webradio_amd/host) end to end, driven like main.cxx drives
+the reference: FrontEnd + Receivers + Radio::run().  Checked against the oracle for
+  - the fused path (every Receiver of the tuner in one launch sequence),
+  - the one-kernel-per-block path (WEBRADIO_NO_FUSION=1), which is bit-exact,
+  - the REFERENCE's radio.cxx linked against our classes (oracle/_ref/libwr_boundary.so)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from webradio_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "webradio_amd", "host")
+CXXT = os.path.join(ROOT, "tests", "cxx")
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+RUNNER = r'''
+import ctypes as C, sys, numpy as np, json
+lib, npz = sys.argv[1], sys.argv[2]
+import torch  # same HIP runtime as the rest of the suite
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz)
+iq = np.ascontiguousarray(d["iq"], np.float32); ifs = np.ascontiguousarray(d["ifs"], np.int32)
+modes = np.ascontiguousarray(d["modes"], np.int32); p = d["params"]
+nrx = ifs.size; cap = int(p[8]); fft = int(p[9])
+audio = np.zeros((nrx, cap), np.float32); n = C.c_size_t(); spec = np.zeros(max(fft, 1), np.float32)
+fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+L.wr_host_run.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, ip, ip, C.c_uint, C.c_uint, C.c_uint, C.c_uint,
+                          C.c_int, C.c_int, fp, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint, fp]
+rc = L.wr_host_run(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), nrx, ifs.ctypes.data_as(ip),
+                   modes.ctypes.data_as(ip), int(p[2]), int(p[3]), int(p[4]), int(p[5]), int(p[6]), int(p[7]),
+                   audio.ctypes.data_as(fp), cap, C.byref(n), fft, spec.ctypes.data_as(fp))
+np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], spec=spec, left=L.wr_host_registry_sizes())
+'''
+
+
+def _run(libname, tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(-1, 0), fft=0, env=None):
+    lib = os.path.join(CXXT, libname) if not os.path.isabs(libname) else libname
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", CXXT, "all"])
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    nblocks = (iq.size // 2) // block
+    cap = nblocks * (block // (rate // crate) // (crate // arate)) + 16
+    np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32), modes=np.array(modes, np.int32),
+             params=np.array([rate, block, cpb, crate, apb, arate, retune[0], retune[1], cap, fft], np.int64))
+    e = dict(os.environ, WEBRADIO_QUIET="1")
+    e.update(env or {})
+    # a fresh process per run: the host runtime keeps per-process device contexts and env switches
+    subprocess.check_call([sys.executable, "-c", RUNNER, lib, inp, out], env=e)
+    r = np.load(out)
+    assert int(r["rc"]) == 0
+    assert int(r["left"]) == 0                    # registries empty again (radio.cxx:98,143)
+    return r["audio"], r["spec"]
+
+
+def _oracle(oracle, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(-1, 0)):
+    outs = []
+    for c, (f, m) in enumerate(zip(ifs, modes)):
+        rx = oracle.Receiver(rate, f, cpb, crate, m, apb, arate)
+        a = []
+        for b in range((iq.size // 2) // block):
+            if c == 0 and b == retune[0]:
+                rx.set_if(retune[1])
+            a.append(rx.run(iq[2 * b * block: 2 * (b + 1) * block])[0])
+        outs.append(np.concatenate(a))
+    return np.stack(outs)
+
+
+CFG = dict(rate=2_000_000, block=40_000, cpb=128_000, crate=5_000, apb=160, arate=1_000)
+
+
+def test_fused_receivers_match_oracle(tmp_path, oracle):
+    ifs = [(-5 + c) * 6250 + 1234 for c in range(10)]
+    modes = [1, 0, 2, 3, 1, 1, 0, 1, 2, 1]            # FM AM USB LSB ...
+    iq = synth.fm_stream(4 * CFG["block"], CFG["rate"], ifs[::2], fm_base=30.0, beta=2.0)
+    got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"],
+                  CFG["crate"], CFG["apb"], CFG["arate"])
+    want = _oracle(oracle, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"])
+    assert got.shape == want.shape
+    for c in range(0, len(ifs), 2):                   # carrier channels
+        assert np.abs(got[c] - want[c]).max() <= 1e-5, c
+    for c, m in enumerate(modes):                     # linear detectors: every channel
+        if m != 1:
+            assert np.abs(got[c] - want[c]).max() <= 2e-6, c
+
+
+def test_unfused_blocks_are_bit_exact(tmp_path, oracle):
+    """WEBRADIO_NO_FUSION=1: each block runs its own kernel on host vectors, exactly the
+    reference's dataflow -- AM/USB/LSB chains are bit-identical."""
+    ifs, modes = [50_000, -75_000, 10], [0, 2, 3]
+    iq = synth.fm_stream(3 * CFG["block"], CFG["rate"], ifs[:2], amp=0.3)
+    got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"],
+                  CFG["crate"], CFG["apb"], CFG["arate"], retune=(1, 12_345), env={"WEBRADIO_NO_FUSION": "1"})
+    want = _oracle(oracle, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"], CFG["crate"], CFG["apb"],
+                   CFG["arate"], retune=(1, 12_345))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_fused_exact_nco_and_retune(tmp_path, oracle):
+    ifs, modes = [50_000, -75_000], [0, 3]
+    iq = synth.fm_stream(3 * CFG["block"], CFG["rate"], ifs, amp=0.3)
+    got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"],
+                  CFG["crate"], CFG["apb"], CFG["arate"], retune=(2, -40_000), env={"WEBRADIO_NCO_EXACT": "1"})
+    want = _oracle(oracle, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"], CFG["crate"], CFG["apb"],
+                   CFG["arate"], retune=(2, -40_000))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_reference_radio_cxx_on_our_blocks(tmp_path, oracle):
+    """The reference's own radio.cxx (compiled unchanged) wiring our GPU blocks."""
+    lib = os.path.join(ROOT, "oracle", "_ref", "libwr_boundary.so")
+    if not os.path.exists(lib):
+        pytest.skip("oracle/_ref/libwr_boundary.so not built (needs /root/reference at build time)")
+    ifs, modes = [50_000, -75_000, 1234, -9999], [0, 1, 2, 1]
+    iq = synth.fm_stream(3 * CFG["block"], CFG["rate"], ifs, amp=0.2, fm_base=30.0, beta=2.0)
+    got, spec = _run(lib, tmp_path, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"], CFG["crate"], CFG["apb"],
+                     CFG["arate"], fft=1024)
+    want = _oracle(oracle, iq, CFG["rate"], CFG["block"], ifs, modes, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"])
+    assert np.abs(got - want).max() <= 1e-5
+    # FrontEnd::spectrum(): last complete 1024-frame of the stream
+    o = oracle.Spectrum(1024)
+    o.process(iq)
+    w = o.get()
+    strong = w >= w.max() - 60
+    assert np.abs(spec - w)[strong].max() <= 0.02

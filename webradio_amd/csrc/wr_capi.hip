@@ -380,6 +380,16 @@ extern "C" int wr_u8_to_f32(wr_dev *d, const uint8_t *in_dev, float *out_dev, si
 
 /* ------------------------------------------------------------------ tuner -- */
 
+/* lane groups that hold at least one channel: [0, used) in units of slots */
+static unsigned int group_slots_used(const Group *g)
+{
+	unsigned int hi = 0;
+	for (unsigned int s = 0; s < g->slots; ++s)
+		if (g->owner[s] >= 0)
+			hi = s + 1;
+	return ((hi + WR_LANES - 1) / WR_LANES) * WR_LANES;
+}
+
 static void group_free(Group *g)
 {
 	if (!g)
@@ -927,6 +937,7 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		L.d1 = g->d1;
 		L.d2 = g->d2;
 		L.slots = g->slots;
+		L.slots_used = group_slots_used(g);
 		L.k1 = nframes / g->d1;                 /* dspblock.cxx:177-178 */
 		L.k2 = L.k1 / g->d2;
 		L.k2max = g->k2max;
@@ -1036,6 +1047,50 @@ extern "C" int wr_tuner_audio_dev(wr_tuner *t, const float **audio_dev, size_t *
 	*audio_dev = g->dev.audio;
 	*chan_stride = g->k2max;
 	*frames = g->last_k2;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out_capacity,
+                                        size_t *chan_stride, size_t *frames, unsigned int *slots_used)
+{
+	if (!t || !chan_stride || !frames || !slots_used)
+		return fail(WR_ERR_ARG, "wr_tuner_fetch_audio_all: bad argument");
+	Group *g = nullptr;
+	for (Group *x : t->groups)
+		if (x->active > 0) {
+			if (g)
+				return fail(WR_ERR_STATE, "tuner has several rate groups; fetch per channel instead");
+			g = x;
+		}
+	if (!g || !t->submitted)
+		return fail(WR_ERR_STATE, "nothing submitted yet");
+	unsigned int used = group_slots_used(g);
+	*chan_stride = g->last_k2;
+	*frames = g->last_k2;
+	*slots_used = used;
+	const size_t need = (size_t)used * g->last_k2;
+	if (!need)
+		return WR_OK;
+	if (!out_host || out_capacity < need)
+		return fail(WR_ERR_ARG, "wr_tuner_fetch_audio_all: need room for %zu floats", need);
+	wr_dev *d = t->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
+	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_chan_reset_history(wr_tuner *t, int chan)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_reset_history: no channel %d", chan);
+	c->hist_valid = false;
+	c->dem_hist_reset = true;
+	if (c->group >= 0)
+		t->groups[c->group]->dirty = true;
 	return WR_OK;
 }
 

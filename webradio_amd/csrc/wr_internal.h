@@ -48,7 +48,8 @@ struct WrTunerLaunch {
 	int          parity;        /* which of the group's ping-pong buffers is current */
 	size_t       nframes;
 	unsigned int d1, d2;
-	unsigned int slots;
+	unsigned int slots;         /* row stride of every per-slot array */
+	unsigned int slots_used;    /* slots [0, slots_used) hold channels (multiple of 64) */
 	size_t       k1, k2;        /* frames per channel at channel / audio rate for this block */
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;

@@ -242,7 +242,7 @@ template <int NCO, bool UTAPS>
 __global__ void __launch_bounds__(1024)
 k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
             float2 *__restrict__ hist_next, size_t nframes, size_t k1,
-            unsigned int d1, unsigned int slots,
+            unsigned int d1, unsigned int slots, unsigned int groups,
             const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
             const unsigned int *__restrict__ hist_step, const int *__restrict__ flags,
             const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
@@ -279,7 +279,6 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 		hist_next[lane] = (f < WR_HIST) ? hist[f] : cur[f - WR_HIST];
 	}
 
-	const unsigned int groups = slots >> 6;
 	const size_t units = k1 * groups;
 	const size_t wave_global = (size_t)blockIdx.x * waves_per_wg + wave;
 	const size_t wave_count = (size_t)gridDim.x * waves_per_wg;
@@ -637,7 +636,7 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 	}
 	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes, L.k1, L.d1,
-		L.slots, G.phase, G.step, G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev,
+		L.slots, L.slots_used / 64, G.phase, G.step, G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev);
 	return hipGetLastError();
 }
@@ -646,9 +645,9 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
                          int num_cus)
 {
-	if (!L.k1 || !L.slots)
+	if (!L.k1 || !L.slots_used)
 		return hipSuccess;
-	const size_t units = L.k1 * (L.slots / 64);
+	const size_t units = L.k1 * (L.slots_used / 64);
 	unsigned int wgs = (unsigned int)((units + DDC_WAVES - 1) / DDC_WAVES);
 	if (L.nco_mode == WR_NCO_EXACT) {
 		/* small LDS footprint: two workgroups per CU hide the gather latency */
@@ -668,10 +667,10 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
 {
-	if (!L.k1 || !L.slots)
+	if (!L.k1 || !L.slots_used)
 		return hipSuccess;
 	const int p = L.parity;
-	dim3 grid(L.slots / 64, (unsigned int)((L.k1 + 4 * DEM_RPT - 1) / (4 * DEM_RPT)));
+	dim3 grid(L.slots_used / 64, (unsigned int)((L.k1 + 4 * DEM_RPT - 1) / (4 * DEM_RPT)));
 	k_tuner_demod<<<grid, 256, 0, st>>>(
 		(const float2 *)G.chan_iq, (unsigned int)L.k1, L.slots, (unsigned int)L.nframes, G.mode, G.flags, G.phase, G.step,
 		G.hist_step, (const float2 *)G.prev_iq[p], (float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1]);
@@ -680,7 +679,7 @@ hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
 {
-	if (!L.k2 || !L.slots)
+	if (!L.k2 || !L.slots_used)
 		return hipSuccess;
 	/* as many output frames per tile as the staged rows allow */
 	unsigned int tk = AUD_TMAX;
@@ -695,7 +694,7 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 			return e;
 		attr_set = true;
 	}
-	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots / 64);
+	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
 	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
 	                                      G.taps2, G.flags, G.audio, L.k2max);
 	return hipGetLastError();

@@ -1,0 +1,144 @@
+/*
+ * dspblock.h -- push-model operator graph of the MI355X webradio backend.
+ *
+ * Source-compatible with webradio's src/dsp/dspblock.h:50-140: same class names, same
+ * public and protected members with the same meaning, so callers written against the
+ * reference (radio.cxx, main.cxx, the web handlers, any DspBlock subclass) build
+ * against this header unchanged.  The scheduling semantics are the reference's,
+ * restated in dspblock.cxx and pinned to it by tests/test_dspblock_parity.py.
+ *
+ * What is new is private: each block knows its producer (`upstream`), and a block may
+ * tell the runtime that its output buffer is never looked at (`elideOutput`) -- the
+ * fused GPU path computes a whole Receiver chain in one launch sequence and only the
+ * audio filter's output exists on the host.
+ */
+#ifndef DSPBLOCK_H_
+#define DSPBLOCK_H_
+
+// the reference hard-enables its profiler the same way (dspblock.h:29)
+#define DSPBLOCK_PROFILE
+
+#include <stdint.h>
+#include <time.h>
+
+#include <string>
+#include <vector>
+
+#define DEFAULT_SAMPLE_RATE		48000
+#define DEFAULT_CHANNELS		2
+#define DEFAULT_BLOCK_SIZE		16384
+
+using namespace std;	// reference headers do this and its sources rely on it (radio.h:44)
+
+typedef float sample_t;
+
+class DspSource;
+namespace wrhost { class TunerBatch; }
+
+class DspBlock
+{
+	friend class DspSource;
+	friend class wrhost::TunerBatch;
+public:
+	DspBlock(const string &name = "<undefined>", const string &type = "DspBlock");
+	virtual ~DspBlock();
+
+	/* graph construction (dspblock.cxx:57-92 in the reference) */
+	void connect(DspBlock *block);
+	void disconnect(DspBlock *block);
+
+	/* negotiated stream format */
+	unsigned int inputSampleRate() const { return _inRate; }
+	unsigned int outputSampleRate() const { return _outputSampleRate; }
+	unsigned int inputChannels() const { return _inChannels; }
+	unsigned int outputChannels() const { return _outputChannels; }
+	unsigned int decimation() const { return _decim; }
+	unsigned int interpolation() const { return _interp; }
+
+	/* per-block profiler (process-CPU nanoseconds around process()) */
+	uint64_t nsPerFrameAll() const;
+	uint64_t nsPerFrameOne() const { return _nsTotal / _framesIn; }
+	uint64_t totalNanoseconds() const { return _nsTotal; }
+	unsigned int totalIn() const { return _framesIn; }
+	unsigned int totalOut() const { return _framesOut; }
+
+	bool isRunning() const { return _running; }
+	const string& name() const { return _name; }
+	const string& type() const { return _type; }
+
+protected:
+	/* the operator interface every block implements */
+	virtual bool init() { return false; }
+	virtual void deinit() {}
+	virtual bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer) { return false; }
+
+	/* init() may override these two (rate change, channel change) */
+	unsigned int	_outputSampleRate;
+	unsigned int	_outputChannels;
+
+	/* ---- additions of this backend (not in the reference) ---- */
+	DspBlock* upstream() const { return _producer; }
+	const vector<DspBlock*>& downstream() const { return _consumers; }
+	/* A block whose output no consumer reads on the host (because the consumer gets its
+	 * data from the tuner batch on the GPU) asks the runtime not to materialise it. */
+	void elideOutput(bool on) { _elide = on; }
+	bool outputElided() const { return _elide; }
+	/* frames of the block currently being pushed through this block */
+	unsigned int currentInputFrames() const { return _curInFrames; }
+	unsigned int currentOutputFrames() const { return _curOutFrames; }
+
+private:
+	bool start();
+	void stop();
+	bool run(const vector<sample_t> &inBuffer);
+	bool runFrames(const vector<sample_t> &inBuffer, unsigned int inframes);
+	void setSampleRate(unsigned int rate);
+	void setChannels(unsigned int channels);
+
+	const string		_name;
+	const string		_type;
+	unsigned int		_inRate;
+	unsigned int		_inChannels;
+	unsigned int		_decim;
+	unsigned int		_interp;
+	uint64_t			_nsTotal;
+	uint64_t			_framesIn;
+	uint64_t			_framesOut;
+	bool				_running;
+	bool				_elide;
+	unsigned int		_curInFrames;
+	unsigned int		_curOutFrames;
+	DspBlock*			_producer;
+	vector<sample_t>	_out;
+	vector<DspBlock*>	_consumers;
+};
+
+class DspSource : public DspBlock
+{
+public:
+	DspSource(const string &name = "<undefined>", const string &type = "DspSource");
+	virtual ~DspSource();
+
+	unsigned int blockSize() const { return _blockSize; }
+
+	bool start() { return DspBlock::start(); }
+	void stop() { DspBlock::stop(); }
+	bool run();
+	void setSampleRate(unsigned int rate) { DspBlock::setSampleRate(rate); }
+	void setChannels(unsigned int channels) { DspBlock::setChannels(channels); }
+	void setBlockSize(unsigned int bytes);
+
+	/* number of run() calls so far: the "epoch" the tuner batch keys its launches on */
+	unsigned long epoch() const { return _epoch; }
+	/* per-source tuner batch (created on demand by the first DownConverter) */
+	wrhost::TunerBatch* batch() const { return _batch; }
+	void setBatch(wrhost::TunerBatch *b) { _batch = b; }
+
+private:
+	unsigned int		_blockSize;
+	unsigned long		_epoch;
+	vector<sample_t>	_pump;		/* the (zeroed) input vector handed to the source's own process() */
+	wrhost::TunerBatch*	_batch;
+};
+
+#endif /* DSPBLOCK_H_ */

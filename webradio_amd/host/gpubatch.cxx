@@ -1,0 +1,311 @@
+/*
+ * gpubatch.cxx -- see gpubatch.h.  Everything numerical happens behind the C ABI; this
+ * file only decides WHAT is submitted WHEN, so that DspBlock::run()'s depth-first walk
+ * (dspblock.cxx:207-209 upstream) ends up as one launch sequence per tuner block.
+ */
+#include "gpubatch.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "debug.h"
+#include "demodulator.h"
+#include "downconverter.h"
+#include "lowpass.h"
+
+namespace wrhost {
+
+namespace {
+std::mutex g_devLock;
+std::vector<wr_dev *> g_devs;
+int g_batches = 0;
+
+unsigned int envUnsigned(const char *name, unsigned int fallback)
+{
+	const char *v = getenv(name);
+	return (v && *v) ? (unsigned int)strtoul(v, NULL, 0) : fallback;
+}
+}
+
+int deviceCount()
+{
+	int n = 0;
+	if (wr_device_count(&n) != WR_OK)
+		return 0;
+	return n;
+}
+
+wr_dev *device(int index)
+{
+	std::lock_guard<std::mutex> g(g_devLock);
+	if (index < 0)
+		return NULL;
+	if ((size_t)index >= g_devs.size())
+		g_devs.resize(index + 1, NULL);
+	if (!g_devs[index]) {
+		wr_dev *d = NULL;
+		if (wr_dev_open(&d, index, NULL) != WR_OK) {
+			/* no CPU path: the caller's init()/process() reports failure */
+			LOG_ERROR("GPU device %d unavailable: %s\n", index, wr_last_error());
+			return NULL;
+		}
+		g_devs[index] = d;
+	}
+	return g_devs[index];
+}
+
+wr_dev *deviceFor(const DspBlock *block)
+{
+	/* a block below a batched source shares the source's GPU */
+	if (wr_dev *d = TunerBatch::batchDeviceOf(block))
+		return d;
+	return device((int)envUnsigned("WEBRADIO_DEVICE", 0));
+}
+
+bool DevBuf::reserve(wr_dev *d, size_t nbytes)
+{
+	if (dev == d && bytes >= nbytes && ptr)
+		return true;
+	release();
+	if (!d || wr_dev_malloc(d, nbytes ? nbytes : 4, &ptr) != WR_OK) {
+		ptr = NULL;
+		return false;
+	}
+	dev = d;
+	bytes = nbytes;
+	return true;
+}
+
+void DevBuf::release()
+{
+	if (ptr && dev)
+		wr_dev_free(dev, ptr);
+	ptr = NULL;
+	bytes = 0;
+	dev = NULL;
+}
+
+/* ------------------------------------------------------------------ TunerBatch -- */
+
+TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
+	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
+	  _submitOk(false), _audioStride(0), _audioFrames(0), _audioSlots(0)
+{
+}
+
+TunerBatch::~TunerBatch()
+{
+	if (_tuner)
+		wr_tuner_destroy(_tuner);
+}
+
+wr_dev *TunerBatch::batchDeviceOf(const DspBlock *block)
+{
+	const DspBlock *b = block;
+	while (b && b->_producer)
+		b = b->_producer;
+	const DspSource *src = dynamic_cast<const DspSource *>(b);
+	return (src && src->batch()) ? src->batch()->dev() : NULL;
+}
+
+/* The shape radio.cxx:68-76 builds, with nothing else attached along the way.  Only
+ * then is it safe to skip the intermediate buffers. */
+Channel *TunerBatch::enrol(DownConverter *mixer)
+{
+	if (envUnsigned("WEBRADIO_NO_FUSION", 0))
+		return NULL;
+	DspSource *src = dynamic_cast<DspSource *>(mixer->_producer);
+	if (!src || mixer->_consumers.size() != 1)
+		return NULL;
+	LowPass *f1 = dynamic_cast<LowPass *>(mixer->_consumers[0]);
+	if (!f1 || f1->_consumers.size() != 1)
+		return NULL;
+	Demodulator *dm = dynamic_cast<Demodulator *>(f1->_consumers[0]);
+	if (!dm || dm->_consumers.size() != 1)
+		return NULL;
+	LowPass *f2 = dynamic_cast<LowPass *>(dm->_consumers[0]);
+	if (!f2)
+		return NULL;
+	if (f1->_channel || dm->_channel || f2->_channel)
+		return NULL;
+
+	TunerBatch *batch = src->batch();
+	if (!batch) {
+		/* tuners shard one per GPU: the n-th batched source of the process takes GPU
+		 * n mod count unless WEBRADIO_DEVICE pins it */
+		int count = deviceCount();
+		if (count <= 0) {
+			LOG_ERROR("no GPU: %s\n", wr_last_error());
+			return NULL;
+		}
+		int index;
+		{
+			std::lock_guard<std::mutex> g(g_devLock);
+			index = getenv("WEBRADIO_DEVICE") ? (int)envUnsigned("WEBRADIO_DEVICE", 0) : (g_batches % count);
+			g_batches++;
+		}
+		wr_dev *dev = device(index);
+		if (!dev)
+			return NULL;
+		batch = new TunerBatch(src, dev);
+		src->setBatch(batch);
+	}
+
+	std::lock_guard<std::mutex> g(batch->_lock);
+	if (!batch->_tuner) {
+		batch->_rate = src->outputSampleRate();
+		batch->_maxFrames = src->blockSize() / 2;
+		if (batch->_maxFrames == 0)
+			batch->_maxFrames = 1;
+		unsigned int maxch = envUnsigned("WEBRADIO_MAX_CHANNELS", 1024);
+		int nco = envUnsigned("WEBRADIO_NCO_EXACT", 0) ? WR_NCO_EXACT : WR_NCO_SPLIT;
+		if (wr_tuner_create(&batch->_tuner, batch->_dev, batch->_rate, maxch, batch->_maxFrames, nco) != WR_OK) {
+			LOG_ERROR("wr_tuner_create: %s\n", wr_last_error());
+			batch->_tuner = NULL;
+			return NULL;
+		}
+	}
+	int id = -1;
+	if (wr_chan_add(batch->_tuner, &id) != WR_OK) {
+		LOG_ERROR("wr_chan_add: %s\n", wr_last_error());
+		return NULL;
+	}
+	Channel *ch = new Channel();
+	ch->batch = batch;
+	ch->id = id;
+	ch->mixer = mixer;
+	ch->chanFilter = f1;
+	ch->demod = dm;
+	ch->audioFilter = f2;
+	ch->dirty = true;
+	batch->_channels.push_back(ch);
+	/* NCO phase and Demodulator prev_i/q outlive stop()/start() upstream (Q5) */
+	wr_chan_set_state(batch->_tuner, id, mixer->_phase, dm->_prev);
+	mixer->_channel = f1->_channel = dm->_channel = f2->_channel = ch;
+	f1->_stage = 0;
+	f2->_stage = 1;
+	/* nobody reads these three on the host any more */
+	mixer->elideOutput(true);
+	f1->elideOutput(true);
+	dm->elideOutput(true);
+	return ch;
+}
+
+void TunerBatch::withdraw(Channel *ch)
+{
+	if (!ch)
+		return;
+	TunerBatch *batch = ch->batch;
+	if (batch && batch->_tuner) {
+		std::lock_guard<std::mutex> g(batch->_lock);
+		wr_chan_get_state(batch->_tuner, ch->id, &ch->mixer->_phase, ch->demod->_prev);
+		wr_chan_remove(batch->_tuner, ch->id);
+		for (size_t n = 0; n < batch->_channels.size(); n++)
+			if (batch->_channels[n] == ch) {
+				batch->_channels.erase(batch->_channels.begin() + n);
+				break;
+			}
+	}
+	ch->mixer->_channel = NULL;
+	ch->chanFilter->_channel = NULL;
+	ch->demod->_channel = NULL;
+	ch->audioFilter->_channel = NULL;
+	ch->mixer->elideOutput(false);
+	ch->chanFilter->elideOutput(false);
+	ch->demod->elideOutput(false);
+	delete ch;
+}
+
+void TunerBatch::markDirty(Channel *ch)
+{
+	if (!ch)
+		return;
+	std::lock_guard<std::mutex> g(ch->batch->_lock);
+	ch->dirty = true;
+}
+
+/* stage the block-level parameters of one channel (setters may have run on other
+ * threads since the last block; they take effect here, at a block boundary) */
+bool TunerBatch::pushParams(Channel *ch)
+{
+	LowPass *f1 = ch->chanFilter, *f2 = ch->audioFilter;
+	if (!f1->isRunning() || !f2->isRunning() || !ch->demod->isRunning())
+		return true;                    /* the chain is still starting: next block */
+	if (wr_chan_set_if(_tuner, ch->id, ch->mixer->_ifHz) != WR_OK)
+		return false;
+	if (f1->_coeff.size() == WR_FIR_LENGTH &&
+	    wr_chan_set_taps(_tuner, ch->id, 0, f1->_coeff.data(), f1->decimation()) != WR_OK)
+		return false;
+	if (f2->_coeff.size() == WR_FIR_LENGTH &&
+	    wr_chan_set_taps(_tuner, ch->id, 1, f2->_coeff.data(), f2->decimation()) != WR_OK)
+		return false;
+	if (wr_chan_set_mode(_tuner, ch->id, (int)ch->demod->_mode) != WR_OK)
+		return false;
+	ch->dirty = false;
+	return true;
+}
+
+bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nframes)
+{
+	std::lock_guard<std::mutex> g(_lock);
+	if (_submittedEpoch == _source->epoch())
+		return _submitOk;
+	_submittedEpoch = _source->epoch();
+	_submitOk = false;
+	for (size_t n = 0; n < _channels.size(); n++)
+		if (_channels[n]->dirty && !pushParams(_channels[n])) {
+			LOG_ERROR("channel parameters rejected: %s\n", wr_last_error());
+			return false;
+		}
+	if (nframes > _maxFrames) {
+		LOG_ERROR("block of %u frames exceeds the %zu the tuner batch was sized for\n", nframes, _maxFrames);
+		return false;
+	}
+	if (wr_tuner_submit(_tuner, tunerBuffer.data(), nframes, WR_HOST) != WR_OK) {
+		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
+		return false;
+	}
+	/* one transfer brings back the audio of every channel */
+	size_t stride = 0, frames = 0;
+	unsigned int slots = 0;
+	if (wr_tuner_fetch_audio_all(_tuner, NULL, 0, &stride, &frames, &slots) != WR_OK && frames * slots == 0) {
+		/* several rate groups: fall back to per-channel fetches in audio() */
+		_audioSlots = 0;
+		_submitOk = true;
+		return true;
+	}
+	_audio.resize((size_t)slots * frames + 1);
+	if (frames != 0 && slots != 0 &&
+	    wr_tuner_fetch_audio_all(_tuner, _audio.data(), _audio.size(), &stride, &frames, &slots) != WR_OK) {
+		_audioSlots = 0;                /* per-channel fallback */
+	} else {
+		_audioStride = stride;
+		_audioFrames = frames;
+		_audioSlots = slots;
+	}
+	_submitOk = true;
+	return true;
+}
+
+bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
+{
+	std::lock_guard<std::mutex> g(_lock);
+	if (!_submitOk)
+		return false;
+	if (out.empty())
+		return true;
+	int slot = -1;
+	if (_audioSlots && wr_chan_slot(_tuner, ch->id, &slot) == WR_OK && (unsigned int)slot < _audioSlots &&
+	    _audioFrames == out.size()) {
+		memcpy(out.data(), _audio.data() + (size_t)slot * _audioStride, out.size() * sizeof(float));
+		return true;
+	}
+	size_t got = 0;
+	if (wr_chan_fetch(_tuner, ch->id, WR_STAGE_AUDIO, out.data(), out.size(), &got) != WR_OK) {
+		LOG_ERROR("wr_chan_fetch: %s\n", wr_last_error());
+		return false;
+	}
+	return got == out.size();
+}
+
+} // namespace wrhost

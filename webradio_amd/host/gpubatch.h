@@ -1,0 +1,109 @@
+/*
+ * gpubatch.h -- host glue between the DspBlock graph and the C ABI (webradio_amd.h).
+ *
+ * The reference walks the graph depth first, one Receiver after the other
+ * (dspblock.cxx:207-209), and every block materialises its output.  The GPU wants the
+ * opposite: all Receivers of a tuner in one launch sequence, and none of the full-rate
+ * intermediates.  TunerBatch reconciles the two without changing the graph API:
+ *
+ *   - when a DownConverter that hangs directly off a DspSource is started and the blocks
+ *     after it form exactly the Receiver chain of radio.cxx:68-76
+ *     (DownConverter -> LowPass -> Demodulator -> LowPass), the four blocks are enrolled
+ *     as one CHANNEL of the source's TunerBatch (a wr_tuner on one GPU);
+ *   - the first enrolled DownConverter::process() of a source block ("epoch") uploads the
+ *     tuner buffer once and submits every channel; later process() calls of enrolled
+ *     blocks in the same epoch are no-ops, except the audio LowPass, which copies its
+ *     channel's audio out of the batch's single device-to-host transfer;
+ *   - blocks that are not part of such a chain run one kernel each (wr_mix,
+ *     wr_fir_decimate, wr_demod) on their own host buffers.
+ */
+#ifndef WRHOST_GPUBATCH_H_
+#define WRHOST_GPUBATCH_H_
+
+#include <stddef.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dspblock.h"
+#include "webradio_amd.h"
+
+class DownConverter;
+class LowPass;
+class Demodulator;
+
+namespace wrhost {
+
+/* process-wide device contexts, one per GPU, opened on first use */
+wr_dev *device(int index);
+int deviceCount();
+/* the device a block should use: its source's batch device, else WEBRADIO_DEVICE / 0 */
+wr_dev *deviceFor(const DspBlock *block);
+
+/* a resizable device buffer */
+struct DevBuf {
+	DevBuf() : dev(NULL), ptr(NULL), bytes(0) {}
+	~DevBuf() { release(); }
+	bool reserve(wr_dev *d, size_t nbytes);
+	void release();
+	wr_dev *dev;
+	void *ptr;
+	size_t bytes;
+};
+
+class TunerBatch;
+
+struct Channel {
+	TunerBatch *batch;
+	int id;                       /* wr_tuner channel id */
+	DownConverter *mixer;
+	LowPass *chanFilter;
+	Demodulator *demod;
+	LowPass *audioFilter;
+	bool dirty;                   /* parameters changed since the last submit */
+};
+
+class TunerBatch {
+public:
+	/* enrol the Receiver chain that starts at `mixer` if the graph has that shape;
+	 * returns the channel or NULL (-> the blocks run stand-alone) */
+	static Channel *enrol(DownConverter *mixer);
+	static void withdraw(Channel *ch);
+	/* the root source's batch device, or NULL if the block is not below a batched source */
+	static wr_dev *batchDeviceOf(const DspBlock *block);
+
+	/* called from DownConverter::process of an enrolled block */
+	bool submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nframes);
+	/* called from the audio LowPass::process of an enrolled block */
+	bool audio(const Channel *ch, vector<sample_t> &out);
+	/* a setter changed a parameter of this channel (any thread): re-stage it at the next
+	 * block boundary */
+	static void markDirty(Channel *ch);
+
+	wr_dev *dev() const { return _dev; }
+	DspSource *source() const { return _source; }
+
+private:
+	TunerBatch(DspSource *source, wr_dev *dev);
+	~TunerBatch();
+	bool ensureTuner(unsigned int nframes);
+	bool pushParams(Channel *ch);
+
+	DspSource *_source;
+	wr_dev *_dev;
+	wr_tuner *_tuner;
+	unsigned int _rate;
+	size_t _maxFrames;
+	unsigned long _submittedEpoch;
+	bool _submitOk;
+	std::vector<Channel *> _channels;
+	std::vector<float> _audio;        /* [slot][frames] of the last submit */
+	size_t _audioStride, _audioFrames;
+	unsigned int _audioSlots;
+	std::mutex _lock;
+};
+
+} // namespace wrhost
+
+#endif /* WRHOST_GPUBATCH_H_ */

@@ -1,0 +1,113 @@
+/*
+ * lowpass.cxx -- host side of the 64-tap decimating FIR block (webradio src/dsp/lowpass.cxx).
+ * Tap design is one-off host work (wr_lowpass_design restates lowpass.cxx:164-197); the
+ * filtering runs on the GPU, fused into the tuner batch or as wr_fir_decimate.
+ */
+#include "lowpass.h"
+
+#include "debug.h"
+#include "gpubatch.h"
+
+LowPass::LowPass(const string &name)
+	: DspBlock(name, "LowPass"), _passband(0), _reqDecimation(0), _reqOutputRate(DEFAULT_SAMPLE_RATE),
+	  _channel(NULL), _stage(-1), _in(new wrhost::DevBuf()), _out(new wrhost::DevBuf()),
+	  _history(new wrhost::DevBuf())
+{
+}
+
+LowPass::~LowPass()
+{
+	delete _in;
+	delete _out;
+	delete _history;
+}
+
+void LowPass::setPassband(unsigned int hz)
+{
+	_passband = hz;
+	if (isRunning())
+		recalculate();
+}
+
+/* asking for a decimation cancels a requested rate and vice versa; both are ignored while
+ * running (lowpass.cxx:63-79) */
+void LowPass::setDecimation(unsigned int n)
+{
+	if (isRunning())
+		return;
+	_reqDecimation = n;
+	_reqOutputRate = 0;
+}
+
+void LowPass::setOutputSampleRate(unsigned int hz)
+{
+	if (isRunning())
+		return;
+	_reqOutputRate = hz;
+	_reqDecimation = 0;
+}
+
+bool LowPass::init()
+{
+	if (_reqOutputRate > 0) {
+		_outputSampleRate = _reqOutputRate;
+	} else if (_reqDecimation > 0) {
+		_outputSampleRate = inputSampleRate() / _reqDecimation;
+	} else {
+		LOG_ERROR("Must specify either decimation or output rate\n");
+		return false;
+	}
+	_outputChannels = inputChannels();
+	recalculate();
+	if (!_channel) {
+		/* stand-alone: an empty history, as a fresh LowPass::block (lowpass.cxx:138-139) */
+		wr_dev *dev = wrhost::deviceFor(this);
+		const size_t bytes = (size_t)(WR_FIR_LENGTH - 1) * inputChannels() * sizeof(float);
+		if (!dev)
+			return false;
+		_history->release();             /* wr_dev_malloc zero-fills */
+		if (!_history->reserve(dev, bytes))
+			return false;
+	}
+	return true;
+}
+
+void LowPass::deinit()
+{
+	/* the chain's channel is withdrawn by its DownConverter */
+	_in->release();
+	_out->release();
+	_history->release();
+	vector<float>().swap(_coeff);
+}
+
+void LowPass::recalculate()
+{
+	_coeff.resize(WR_FIR_LENGTH);
+	wr_lowpass_design(_passband, inputSampleRate(), _coeff.data(), NULL);
+	wrhost::TunerBatch::markDirty(_channel);
+}
+
+bool LowPass::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer)
+{
+	if (_channel) {
+		if (_stage == 0)
+			return true;                 /* channel filter: computed inside the batch */
+		return _channel->batch->audio(_channel, outBuffer);   /* audio filter: one slice of the batch's transfer */
+	}
+	const unsigned int ch = inputChannels();
+	const unsigned int nframes = currentInputFrames();
+	wr_dev *dev = wrhost::deviceFor(this);
+	const size_t inBytes = (size_t)nframes * ch * sizeof(float);
+	const size_t outBytes = outBuffer.size() * sizeof(float);
+	if (!dev || !_in->reserve(dev, inBytes) || !_out->reserve(dev, outBytes) || !_history->ptr)
+		return false;
+	if (wr_dev_upload(dev, _in->ptr, inBuffer.data(), inBytes) != WR_OK ||
+	    wr_fir_decimate(dev, (const float *)_in->ptr, nframes, ch, decimation(), _coeff.data(),
+	                    (float *)_history->ptr, (float *)_out->ptr) != WR_OK ||
+	    wr_dev_download(dev, outBuffer.data(), _out->ptr, outBytes) != WR_OK) {
+		LOG_ERROR("LowPass: %s\n", wr_last_error());
+		return false;
+	}
+	return true;
+}

@@ -1,0 +1,46 @@
+/*
+ * lowpass.h -- 64-tap decimating FIR low-pass block.  Public surface of webradio's
+ * src/dsp/lowpass.h:36-44.  (No <fftw3.h>: the taps come from wr_lowpass_design.)
+ */
+#ifndef FILTER_H_
+#define FILTER_H_
+
+#include <string>
+#include <vector>
+
+#include "dspblock.h"
+
+using namespace std;
+
+namespace wrhost { class TunerBatch; struct Channel; struct DevBuf; }
+
+class LowPass : public DspBlock
+{
+	friend class wrhost::TunerBatch;
+public:
+	LowPass(const string &name = "<undefined>");
+	virtual ~LowPass();
+
+	unsigned int passband() const { return _passband; }
+	void setPassband(unsigned int hz);
+	void setDecimation(unsigned int n);
+	void setOutputSampleRate(unsigned int hz);
+
+private:
+	bool init();
+	void deinit();
+	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer);
+	void recalculate();
+
+	unsigned int	_passband;
+	unsigned int	_reqDecimation;
+	unsigned int	_reqOutputRate;
+	vector<float>	_coeff;			/* 64 taps, lowpass.cxx:183-189 */
+	wrhost::Channel*	_channel;
+	int				_stage;			/* 0 channel filter, 1 audio filter of an enrolled chain */
+	wrhost::DevBuf*	_in;
+	wrhost::DevBuf*	_out;
+	wrhost::DevBuf*	_history;
+};
+
+#endif /* FILTER_H_ */
