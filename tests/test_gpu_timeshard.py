@@ -1,0 +1,80 @@
+"""-m gpu: the config-5 time-sharding driver with the product's TunerShard on one GPU
+(single rank and, over gloo, two ranks sharing the GPU): identical to one sequential pass."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from webradio_amd import capi, synth, timeshard
+from webradio_amd.device import Tuner
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FS, D1, D2 = 2_000_000, 400, 5
+IFS = [50_000, -75_000, 1234, 99_999]
+T, N = 60_000, 4
+
+
+def _stream():
+    return synth.fm_stream(T * N, FS, IFS[:2], amp=0.3, fm_base=30.0, beta=2.0)
+
+
+def _sequential(dev, nco):
+    t = Tuner(dev, FS, len(IFS), T * N, nco)
+    chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_FM, 160, 1_000) for f in IFS]
+    t.submit_host(_stream())
+    a = np.stack([t.fetch(ch, capi.WR_STAGE_AUDIO, T * N) for ch in chans])
+    t.destroy()
+    return a
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT])
+def test_time_shard_single_rank_bit_identical(dev, nco):
+    iq = _stream()
+    shard = timeshard.TunerShard(dev, FS, IFS, 128_000, 5_000, capi.WR_FM, 160, 1_000, T + timeshard.halo_frames(D1, D2), nco)
+
+    class Solo:
+        rank, world = 0, 1
+        def exchange(self, tail):
+            return None
+    out = timeshard.run_time_sharded(Solo(), lambda c: iq[2 * c * T: 2 * (c + 1) * T], N, T, D1, D2, shard,
+                                     lambda a: a, lambda a: a)
+    shard.close()
+    got = np.concatenate([out[c] for c in range(N)], axis=1)
+    want = _sequential(dev, nco)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from webradio_amd.device import Device
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # one GPU on the test box: gloo ring
+    dev = Device(0)
+    iq = _stream()
+    shard = timeshard.TunerShard(dev, FS, IFS, 128_000, 5_000, capi.WR_FM, 160, 1_000, T + timeshard.halo_frames(D1, D2))
+    out = timeshard.run_time_sharded(timeshard.RingHalo(dist, rank, world), lambda c: iq[2 * c * T: 2 * (c + 1) * T],
+                                     N, T, D1, D2, shard, lambda a: torch.from_numpy(np.ascontiguousarray(a)),
+                                     lambda t: t.numpy())
+    shard.close()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **{str(c): a for c, a in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_time_shard_two_ranks(dev, tmp_path):
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = {}
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        for k in d.files:
+            parts[int(k)] = d[k]
+    got = np.concatenate([parts[c] for c in range(N)], axis=1)
+    want = _sequential(dev, capi.WR_NCO_SPLIT)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

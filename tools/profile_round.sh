@@ -1,0 +1,42 @@
+#!/bin/bash
+# Produces the rocprof evidence for bench.py's roofline numbers (run on the GPU box via gpurun):
+#   gpurun_out/<round>_bench.json            the bench line
+#   gpurun_out/<round>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/<round>_pmc_fetch.txt / _pmc_write.txt   FETCH_SIZE / WRITE_SIZE (separate passes)
+round=${1:-r01}
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd $R && python bench.py --steps 30 --warmup 5 > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$round
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$round -o $round -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /tmp/prof_$round.log 2>&1
+python3 - "$round" <<'PY'
+import csv, sys, os
+r = sys.argv[1]; R = os.environ['GRAFT_REPO_ROOT']
+src = '/tmp/prof_%s/%s_kernel_stats.csv' % (r, r)
+rows = list(csv.DictReader(open(src)))
+with open(R + '/gpurun_out/%s_kernel_stats.csv' % r, 'w') as f:
+    w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+    for x in rows:
+        name = x['Name']
+        short = name.split('(')[0][:90]          # torch's generator kernels have page-long names
+        w.writerow([short, x['Calls'], x['TotalDurationNs'], x['AverageNs'], x['Percentage'], x['MinNs'], x['MaxNs']])
+PY
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  python3 - "$c" "$round" <<'PY'
+import csv, sys, glob, collections, os
+c, r = sys.argv[1], sys.argv[2]; R = os.environ['GRAFT_REPO_ROOT']
+acc = collections.defaultdict(list)
+for f in glob.glob('/tmp/pmc_%s/*counter_collection.csv' % c):
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0][:60]
+        if k.startswith(('k_', 'void k_')):
+            acc[k].append(float(row['Counter_Value']))
+with open(R + '/gpurun_out/%s_pmc_%s.txt' % (r, c.lower()), 'w') as out:
+    for k, v in acc.items():
+        out.write('%s %s mean=%.1f KB per launch (n=%d)\n' % (k, c, sum(v) / len(v), len(v)))
+PY
+done
+cat $R/gpurun_out/${round}_bench.json; grep -E "k_tuner" $R/gpurun_out/${round}_kernel_stats.csv; cat $R/gpurun_out/${round}_pmc_*.txt
