@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--nco", choices=["split", "exact"], default="split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2)
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     return ap.parse_args()
 
 
@@ -71,12 +73,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = synth.C2
     n = cfg["block_frames"]
@@ -84,7 +90,7 @@ def main():
     # one independent tuner per GPU: its own stream of FM carriers, seed 12345 + tuner index
     x = synth.fm_stream_torch(n, cfg["input_rate"], ifs[::4], "cuda", seed=12345 + rank)
     stream = torch.cuda.current_stream().cuda_stream
-    dev = Device(local_rank, stream)
+    dev = Device(device_index, stream)
     nco = capi.WR_NCO_SPLIT if args.nco == "split" else capi.WR_NCO_EXACT
     tuner = Tuner(dev, cfg["input_rate"], args.channels, n, nco)
     for f in ifs:
@@ -111,7 +117,7 @@ def main():
     tuner.profile(False)
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

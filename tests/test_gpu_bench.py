@@ -1,0 +1,50 @@
+"""-m gpu: bench.py honours its contract -- one JSON line with the required keys at N = 1, and
+the N > 1 launch path (torch.distributed.run, barrier, max over ranks, whole-job aggregate)
+works; the latter with the gloo backend because the test box has a single GPU (on a real
+node the driver uses the default nccl = RCCL backend)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _line(out):
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                                   "--cpu-blocks", "1"], cwd=ROOT)
+    j = _line(out)
+    for k in REQUIRED + ["cpu_baseline"]:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["scaling"] == "weak"
+    assert j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert abs(j["value"] - 4.0e6 * 5 / (j["ms_per_step"] * 5 / 1e3) / 1e6) / j["value"] < 1e-3
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["launches_timed"] == 5
+    assert r["kernel_ms"] < j["ms_per_step"]                      # the dominant kernel is part of a step
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+def test_two_rank_launch_path():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29711", os.path.join(ROOT, "bench.py"),
+                                   "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo"], cwd=ROOT, env=env)
+    j = _line(out)
+    assert j["n_gpus"] == 2 and "cpu_baseline" not in j
+    # whole-job aggregate: two tuners' samples over the slowest rank's time
+    assert abs(j["value"] - 2 * 4.0e6 * 4 / (j["ms_per_step"] * 4 / 1e3) / 1e6) / j["value"] < 1e-3

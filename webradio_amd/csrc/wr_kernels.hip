@@ -24,6 +24,8 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
 
 #define PHASE_FLAG_ACTIVE   1
 #define PHASE_FLAG_HISTORY  2
@@ -279,9 +281,14 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 		hist_next[lane] = (f < WR_HIST) ? hist[f] : cur[f - WR_HIST];
 	}
 
-	const size_t units = k1 * groups;
-	const size_t wave_global = (size_t)blockIdx.x * waves_per_wg + wave;
-	const size_t wave_count = (size_t)gridDim.x * waves_per_wg;
+	/* Units (g, k) are dealt g-major, round-robin over the waves of the grid: a wave walks
+	 * u = first, first + stride, ... where u = g*k1 + k.  (g, k) is carried incrementally:
+	 * a 64-bit division per unit would cost as much as eight taps. */
+	const unsigned int k1u = (unsigned int)k1;
+	const unsigned int stride = gridDim.x * waves_per_wg;
+	const unsigned int first = blockIdx.x * waves_per_wg + wave;
+	const unsigned int stride_g = stride / k1u, stride_k = stride % k1u;
+	unsigned int g = first / k1u, k = first % k1u;
 
 	/* a wave keeps to one lane group where it can, so its per-channel state stays put */
 	unsigned int loaded_g = 0xFFFFFFFFu;
@@ -291,11 +298,28 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 	int fl = 0;
 	unsigned int buf = 0;
 
-	for (size_t u = wave_global; u < units; u += wave_count, buf ^= 1u) {
-		/* g-major dealing: consecutive waves take consecutive k of the same group */
-		const unsigned int g = (unsigned int)(u / k1);
-		const size_t k = u - (size_t)g * k1;
+	/* sample `lane` of the window of unit (gg, kk) (frame index n0 + lane): from the current
+	 * block, or from the previous block's last 63 frames.  (The tuner's history buffer starts
+	 * out as zeros; whether a given channel may use it -- a receiver added later starts from an
+	 * empty LowPass::block -- is decided per lane where the sample is consumed.) */
+	auto window_sample = [&](unsigned int kk) -> float2 {
+		const long long n = (long long)kk * d1 - WR_HIST + lane;
+		return (n >= 0) ? cur[n] : hist[WR_HIST + n];
+	};
+	/* the window of the NEXT unit is fetched while this one is computed: its global-load
+	 * latency would otherwise sit in front of every unit */
+	float2 xnext = make_float2(0.0f, 0.0f);
+	if (g < groups)
+		xnext = window_sample(k);
+
+	for (; g < groups; buf ^= 1u) {
 		const unsigned int s = g * 64u + lane;
+		/* the unit after this one */
+		unsigned int gn = g + stride_g, kn = k + stride_k;
+		if (kn >= k1u) {
+			kn -= k1u;
+			++gn;
+		}
 		if (g != loaded_g) {
 			if (UTAPS) {
 				/* every slot of the group carries the same taps (host guarantee) */
@@ -320,11 +344,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 		 * per tap). */
 		const long long n0 = (long long)k * d1 - WR_HIST;   /* input frame of tap j = 0 */
 		{
-			const long long n = n0 + lane;
-			/* (the tuner's history buffer starts out as zeros; whether THIS channel may use
-			 * it -- a receiver added later starts from an empty LowPass::block -- is decided
-			 * per lane where the sample is consumed) */
-			const float2 xf = (n >= 0) ? cur[n] : hist[WR_HIST + n];
+			const float2 xf = xnext;
+			if (gn < groups)
+				xnext = window_sample(kn);
 			if (UTAPS)
 				win[buf * 64u + lane] = (v2f){hlane * xf.x, hlane * xf.y};
 			else
@@ -338,13 +360,19 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 			/* two-stage software pipeline over groups of NT taps: the table gathers of
 			 * group t+1 are in flight while group t is multiplied out */
 			constexpr int NT = UTAPS ? 4 : 2;        /* per-lane taps leave fewer registers */
-			v2f ta[2][NT], tb[2][NT];
+			v2f ta[2][NT], tb[2][NT];                /* gathered cis(coarse), cis(fine)       */
+			v4f xw[2][NT / 2];                       /* window samples, two taps per 16 B read */
 			unsigned int ah[NT], al[NT];             /* rotating address registers */
+			const lds_v4f *w4 = (const lds_v4f *)(win + buf * 64u);
 #pragma unroll
 			for (int jj = 0; jj < NT; ++jj) {
 				ah[jj] = a_hi;
 				al[jj] = a_lo;
 			}
+			/* stage 0 */
+#pragma unroll
+			for (int jj = 0; jj < NT / 2; ++jj)
+				xw[0][jj] = w4[jj];
 #pragma unroll
 			for (int jj = 0; jj < NT; ++jj) {
 				gather_split(P, ah[jj], al[jj], ta[0][jj], tb[0][jj]);
@@ -352,7 +380,12 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 			}
 #pragma unroll
 			for (int t = 0; t < WR_FIR_LENGTH / NT; ++t) {
+				/* everything stage t+1 needs from LDS is issued before stage t is multiplied
+				 * out; LDS returns in order, so stage t's operands only wait for older reads */
 				if (t + 1 < WR_FIR_LENGTH / NT) {
+#pragma unroll
+					for (int jj = 0; jj < NT / 2; ++jj)
+						xw[(t + 1) & 1][jj] = w4[(t + 1) * (NT / 2) + jj];
 #pragma unroll
 					for (int jj = 0; jj < NT; ++jj) {
 						gather_split(P, ah[jj], al[jj], ta[(t + 1) & 1][jj], tb[(t + 1) & 1][jj]);
@@ -362,7 +395,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 #pragma unroll
 				for (int jj = 0; jj < NT; ++jj) {
 					const int j = t * NT + jj;
-					const v2f xs = w[j];                     /* broadcast read, immediate offset */
+					const v4f x2 = xw[t & 1][jj >> 1];
+					const v2f xs = (jj & 1) ? (v2f){x2.z, x2.w} : (v2f){x2.x, x2.y};
 					const v2f a = ta[t & 1][jj], b = tb[t & 1][jj];
 					const float c = __builtin_fmaf(-a.y, b.y, a.x * b.x);
 					const float sn = __builtin_fmaf(a.x, b.y, a.y * b.x);
@@ -417,7 +451,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 			}
 		}
 		if (fl & PHASE_FLAG_ACTIVE)
-			chan_iq[k * slots + s] = make_float2(acc.x, acc.y);
+			chan_iq[(size_t)k * slots + s] = make_float2(acc.x, acc.y);
+		g = gn;
+		k = kn;
 	}
 }
 
