@@ -181,6 +181,11 @@ int wr_chan_set_state(wr_tuner *tuner, int chan, unsigned int phase, const float
  * memory, copied to the device first; WR_DEVICE: iq is already in HBM and is read
  * in place (it must stay valid until the stream has passed this call). Async. */
 int wr_tuner_submit(wr_tuner *tuner, const float *iq, size_t nframes, int where);
+/* the same for a block in the RTL-SDR byte format (unsigned 8-bit interleaved IQ, what
+ * RtlSdrTuner::dataReady receives, io/rtlsdrtuner.cxx:86-117): the (u8 - 128)/128
+ * conversion of rtlsdrtuner.cxx:106 happens in the kernel's load stage, so a quarter of
+ * the bytes cross PCIe and leave HBM.  Results are identical to converting first. */
+int wr_tuner_submit_u8(wr_tuner *tuner, const uint8_t *iq_u8, size_t nframes, int where);
 
 /* results of the last submit.  Frames per channel: CHAN_IQ nframes/d1 (x2 floats),
  * DEMOD nframes/d1, AUDIO nframes/d1/d2 -- the truncating arithmetic of

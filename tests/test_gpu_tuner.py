@@ -273,3 +273,40 @@ def test_c2_full_size_properties(dev, oracle, nco):
         assert np.array_equal(outs[capi.WR_NCO_EXACT][c][0][: wc.size].view(np.uint32), wc.view(np.uint32))
         assert np.abs(outs[nco][c][0][: wc.size] - wc).max() <= IQ_ATOL
         assert np.abs(outs[nco][c][1][: wa.size] - wa).max() <= AUDIO_ATOL
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT])
+def test_u8_ingest_equals_converting_first(dev, oracle, nco):
+    """SURVEY 8f-1: the RTL-SDR byte format goes straight into the DDC kernel's load stage;
+    the (u8 - 128)/128 rule of rtlsdrtuner.cxx:106 is exact in float, so the result is
+    bit-identical to converting on the host first (and, in EXACT mode, to the oracle)."""
+    c1 = synth.C1
+    n = 16384
+    u8 = synth.rtl_u8_stream(3 * n)
+    iq = oracle.u8_to_float(u8)
+    outs = []
+    for fmt in ("f32", "u8"):
+        t = Tuner(dev, c1["input_rate"], 2, n, nco)
+        chans = [t.add_receiver(f, c1["chan_passband"], c1["chan_rate"], capi.WR_FM, c1["audio_passband"],
+                                c1["audio_rate"]) for f in (c1["if_hz"], -250_000)]
+        got = []
+        for b in range(3):
+            if fmt == "f32":
+                t.submit_host(iq[2 * n * b: 2 * n * (b + 1)])
+            else:
+                blk = np.ascontiguousarray(u8[2 * n * b: 2 * n * (b + 1)])
+                capi.check(t.lib.wr_tuner_submit_u8(t.h, capi.ptr(blk), n, capi.WR_HOST))
+                dev.sync()
+            got.append([(t.fetch(ch, capi.WR_STAGE_CHAN_IQ, 2 * n), t.fetch(ch, capi.WR_STAGE_AUDIO, n)) for ch in chans])
+        outs.append(got)
+        t.destroy()
+    for bf, bu in zip(*outs):
+        for (cf, af), (cu, au) in zip(bf, bu):
+            assert np.array_equal(cf.view(np.uint32), cu.view(np.uint32))
+            assert np.array_equal(af.view(np.uint32), au.view(np.uint32))
+    if nco == capi.WR_NCO_EXACT:
+        rx = oracle.Receiver(c1["input_rate"], c1["if_hz"], c1["chan_passband"], c1["chan_rate"], oracle.FM,
+                             c1["audio_passband"], c1["audio_rate"])
+        for b in range(3):
+            _, wc, _ = rx.run(iq[2 * n * b: 2 * n * (b + 1)])
+            assert np.array_equal(outs[1][b][0][0].view(np.uint32), wc.view(np.uint32))

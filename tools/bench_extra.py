@@ -35,6 +35,21 @@ for name, buf in (("pageable", xh), ("pinned", xp)):
     dt = (time.perf_counter() - t0) / reps
     out["c2_host_%s_msps" % name] = round(n / dt / 1e6, 1)
     out["c2_host_%s_ms" % name] = round(dt * 1e3, 3)
+# 1b. the same stream in the RTL-SDR byte format (2 B per frame): PCIe-inclusive and resident
+u8 = ((x.clamp(-1, 1) * 127.0) + 127.5).round().clamp(0, 255).to(torch.uint8)
+u8h = u8.cpu()
+for name, buf, where in (("host_u8", u8h, capi.WR_HOST), ("resident_u8", u8, capi.WR_DEVICE)):
+    for _ in range(2):
+        capi.check(t.lib.wr_tuner_submit_u8(t.h, capi.ptr(buf), n, where))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 8
+    for _ in range(reps):
+        capi.check(t.lib.wr_tuner_submit_u8(t.h, capi.ptr(buf), n, where))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out["c2_%s_msps" % name] = round(n / dt / 1e6, 1)
+    out["c2_%s_ms" % name] = round(dt * 1e3, 3)
 t.destroy()
 
 # 2. C3 waterfall

@@ -890,7 +890,19 @@ extern "C" int wr_tuner_profile_read(wr_tuner *t, unsigned int *launches, double
 	return WR_OK;
 }
 
+static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8);
+
 extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int where)
+{
+	return tuner_submit(t, iq, nframes, where, false);
+}
+
+extern "C" int wr_tuner_submit_u8(wr_tuner *t, const uint8_t *iq_u8, size_t nframes, int where)
+{
+	return tuner_submit(t, iq_u8, nframes, where, true);
+}
+
+static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8)
 {
 	if (!t || (nframes && !iq))
 		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
@@ -908,14 +920,17 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		return WR_ERR_HIP;
 	hipStream_t st = d->stream;
 
-	const float *cur = iq;
+	const void *src = iq;
 	if (where == WR_HOST) {
 		if (!t->in_stage)
 			HIP_TRY(hipMalloc((void **)&t->in_stage, t->max_block_frames * 2 * sizeof(float)));
 		if (nframes)
-			HIP_TRY(hipMemcpyAsync(t->in_stage, iq, nframes * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-		cur = t->in_stage;
+			HIP_TRY(hipMemcpyAsync(t->in_stage, iq, nframes * 2 * (u8 ? sizeof(uint8_t) : sizeof(float)),
+			                       hipMemcpyHostToDevice, st));
+		src = t->in_stage;
 	}
+	const float *cur = u8 ? nullptr : (const float *)src;
+	const uint8_t *cur_u8 = u8 ? (const uint8_t *)src : nullptr;
 
 	bool hist_written = false;
 	for (Group *g : t->groups) {
@@ -930,6 +945,7 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		}
 		WrTunerLaunch L;
 		L.cur = cur;
+		L.cur_u8 = cur_u8;
 		L.hist = t->in_hist[t->in_par];
 		L.hist_next = t->in_hist[t->in_par ^ 1];
 		L.parity = g->parity;
@@ -972,7 +988,7 @@ extern "C" int wr_tuner_submit(wr_tuner *t, const float *iq, size_t nframes, int
 		g->last_k2 = L.k2;
 	}
 	if (!hist_written)
-		HIP_TRY(wrk_input_hist(st, cur, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
+		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
 	t->in_par ^= 1;
 
 	/* host mirrors of what k_tuner_advance did */

@@ -42,7 +42,8 @@ struct WrGroupDev {
 };
 
 struct WrTunerLaunch {
-	const float *cur;           /* this block's IQ, nframes frames (device) */
+	const float *cur;           /* this block's IQ, nframes frames (device), or NULL when ... */
+	const uint8_t *cur_u8;      /* ... the block is in the RTL-SDR byte format (2 bytes per frame) */
 	const float *hist;          /* last 63 IQ frames of the previous block (device) */
 	float       *hist_next;     /* receives the history for the next block */
 	int          parity;        /* which of the group's ping-pong buffers is current */
@@ -73,8 +74,8 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
-hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, const float *hist,
-                          float *hist_next);
+hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
+                          const float *hist, float *hist_next);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
                            size_t col_offset_floats, unsigned int width_floats, float *dst);
 

@@ -234,6 +234,19 @@ __device__ __forceinline__ void gather_split(unsigned int P, unsigned int &ah, u
  *                          on its own bank pair, so the gather is conflict-free
  *                          whatever the indices are.
  */
+/* One IQ frame of the tuner block: float32 pairs, or the RTL-SDR byte format converted
+ * with the reference's rule (u8 - 128) / 128 (io/rtlsdrtuner.cxx:106) in the load stage --
+ * a quarter of the bytes over PCIe and out of HBM, same values as converting first. */
+__device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
+                                              size_t n)
+{
+	if (cur_u8) {
+		const uchar2 b = cur_u8[n];
+		return make_float2(((float)b.x - 128.0f) / 128.0f, ((float)b.y - 128.0f) / 128.0f);
+	}
+	return cur[n];
+}
+
 /* LDS plan of k_tuner_ddc: [0, 128 KiB) the two replicated NCO tables (SPLIT only),
  * then one private 2 x 512 B sample window per wave (double buffered across units). */
 #define DDC_TABLE_BYTES   (2u * WR_SPLIT_N * 32u * 8u)
@@ -242,7 +255,8 @@ __device__ __forceinline__ void gather_split(unsigned int P, unsigned int &ah, u
 
 template <int NCO, bool UTAPS>
 __global__ void __launch_bounds__(1024)
-k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
+k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
+            const float2 *__restrict__ hist,
             float2 *__restrict__ hist_next, size_t nframes, size_t k1,
             unsigned int d1, unsigned int slots, unsigned int groups,
             const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
@@ -278,7 +292,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 	 * so no reader of `hist` in this launch is disturbed. */
 	if (blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
 		const size_t f = nframes + lane;            /* frame index in [hist | cur] */
-		hist_next[lane] = (f < WR_HIST) ? hist[f] : cur[f - WR_HIST];
+		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
 	}
 
 	/* Units (g, k) are dealt g-major, round-robin over the waves of the grid: a wave walks
@@ -304,7 +318,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const float2 *__restrict__ hist,
 	 * empty LowPass::block -- is decided per lane where the sample is consumed.) */
 	auto window_sample = [&](unsigned int kk) -> float2 {
 		const long long n = (long long)kk * d1 - WR_HIST + lane;
-		return (n >= 0) ? cur[n] : hist[WR_HIST + n];
+		return (n >= 0) ? input_frame(cur, cur_u8, (size_t)n) : hist[WR_HIST + n];
 	};
 	/* the window of the NEXT unit is fetched while this one is computed: its global-load
 	 * latency would otherwise sit in front of every unit */
@@ -671,7 +685,8 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 		attr_set = true;
 	}
 	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
-		(const float2 *)L.cur, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes, L.k1, L.d1,
+		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
+		L.k1, L.d1,
 		L.slots, L.slots_used / 64, G.phase, G.step, G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev);
 	return hipGetLastError();
@@ -745,9 +760,21 @@ hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	return hipGetLastError();
 }
 
-hipError_t wrk_input_hist(hipStream_t st, const float *cur, size_t nframes, const float *hist, float *hist_next)
+__global__ void k_input_hist(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes,
+                             const float2 *__restrict__ hist, float2 *__restrict__ hist_next)
 {
-	k_hist_build<<<1, 128, 0, st>>>(cur, nframes, 2, hist, hist_next);
+	const unsigned int lane = threadIdx.x;
+	if (lane < WR_HIST) {
+		const size_t f = nframes + lane;
+		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
+	}
+}
+
+hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
+                          const float *hist, float *hist_next)
+{
+	k_input_hist<<<1, 64, 0, st>>>((const float2 *)cur, (const uchar2 *)cur_u8, nframes, (const float2 *)hist,
+	                               (float2 *)hist_next);
 	return hipGetLastError();
 }
 
