@@ -161,6 +161,144 @@ k_fft_pass2(const float2 *__restrict__ work, unsigned int n1, unsigned int n2, u
 	}
 }
 
+/* ------------------------------------------------------------------------------------
+ * 65536-point fast path (BASELINE config 3): 256 x 256 four-step with the 256-point
+ * sub-transforms done as 16 x 16 in REGISTERS -- each thread holds 16 points, does a
+ * 16-point FFT, one exchange through LDS, another 16-point FFT.  One LDS round trip per
+ * 256-point transform instead of eight (radix-2).
+ * ------------------------------------------------------------------------------------ */
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+/* 16-point forward DFT in registers: decimation in frequency, then undo the bit reversal.
+ * All indices are compile-time, so the loops dissolve into straight-line code and the
+ * twiddles exp(-2*pi*i*j/len) into literals. */
+__device__ __forceinline__ void fft16(float2 (&v)[16])
+{
+	const float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f;   /* cos, sin(pi/8) */
+	const float r2 = 0.70710678118654752440f;
+	const float2 w16[8] = { {1.0f, 0.0f}, {c1, -s1}, {r2, -r2}, {s1, -c1},
+	                        {0.0f, -1.0f}, {-s1, -c1}, {-r2, -r2}, {-c1, -s1} };
+#pragma unroll
+	for (int len = 16; len >= 2; len >>= 1) {
+		const int half = len >> 1;
+#pragma unroll
+		for (int base = 0; base < 16; base += len) {
+#pragma unroll
+			for (int j = 0; j < half; ++j) {
+				const float2 a = v[base + j], b = v[base + j + half];
+				v[base + j] = cadd(a, b);
+				const float2 d = csub(a, b);
+				const int tw = j * (16 / len);             /* W_len^j = W_16^(j*16/len) */
+				if (tw == 0)
+					v[base + j + half] = d;
+				else if (tw == 4)
+					v[base + j + half] = make_float2(d.y, -d.x);          /* times -i */
+				else
+					v[base + j + half] = cmul(d, w16[tw]);
+			}
+		}
+	}
+	/* bit-reversed -> natural order (a register renaming) */
+	float2 t;
+#define SWAP16(a, b) t = v[a]; v[a] = v[b]; v[b] = t;
+	SWAP16(1, 8) SWAP16(2, 4) SWAP16(3, 12) SWAP16(5, 10) SWAP16(7, 14) SWAP16(11, 13)
+#undef SWAP16
+}
+
+/* W_256^m from the half-circle table (128 entries): W^(m+128) = -W^m */
+__device__ __forceinline__ float2 w256(const float2 *__restrict__ tw, unsigned int m)
+{
+	const float2 w = tw[m & 127u];
+	return (m & 128u) ? make_float2(-w.x, -w.y) : w;
+}
+
+#define F256_S 272        /* LDS row stride (float2): 16 x 16 plus 16 -> conflict-free exchanges */
+
+/* pass 1: 16 adjacent columns n2 of one frame; thread (t = tid >> 4, c = tid & 15).
+ * grid = (16, frames).  work[k1][n2] = W_65536^(n2*k1) * sum_n1 w[n]x[n] W_256^(n1*k1). */
+__global__ void __launch_bounds__(256)
+k_fft64k_pass1(const float2 *__restrict__ iq, size_t hop, const float *__restrict__ window,
+               const float2 *__restrict__ tw256, const float2 *__restrict__ tw_n, float2 *__restrict__ work)
+{
+	__shared__ float2 ex[16 * F256_S];
+	const unsigned int c = threadIdx.x & 15u, t = threadIdx.x >> 4;
+	const unsigned int col = blockIdx.x * 16u + c;
+	const float2 *x = iq + (size_t)blockIdx.y * hop;
+	float2 v[16];
+#pragma unroll
+	for (int a = 0; a < 16; ++a) {
+		const unsigned int idx = (a * 16u + t) * 256u + col;
+		const float2 s = x[idx];
+		const float w = window[idx];
+		v[a] = make_float2(s.x * w, s.y * w);          /* spectrumsink.cxx:109-112 */
+	}
+	fft16(v);                                          /* over a: k = 0..15, for n1 = a*16 + t */
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		const float2 w = w256(tw256, t * k);           /* W_256^(t*k) */
+		ex[k * F256_S + t * 16u + c] = (k == 0) ? v[k] : cmul(v[k], w);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int b = 0; b < 16; ++b)
+		v[b] = ex[t * F256_S + b * 16u + c];           /* this thread now owns k_low = t */
+	fft16(v);                                          /* over b: k1 = t + 16*k_high */
+	float2 *wout = work + (size_t)blockIdx.y * 65536u;
+#pragma unroll
+	for (int kh = 0; kh < 16; ++kh) {
+		const unsigned int k1 = t + 16u * kh;
+		const unsigned int m = col * k1;               /* < 65536 */
+		float2 w = tw_n[m & 32767u];
+		if (m & 32768u)
+			w = make_float2(-w.x, -w.y);
+		wout[k1 * 256u + col] = cmul(v[kh], w);
+	}
+}
+
+/* pass 2: 16 adjacent rows k1 of the intermediate; bins X[k1 + 256*k2].  Loads run with t
+ * fastest (a row is contiguous), stores with the row index fastest (bins of neighbouring
+ * k1 are contiguous).  grid = (16, frames). */
+__global__ void __launch_bounds__(256)
+k_fft64k_pass2(const float2 *__restrict__ work, const float2 *__restrict__ tw256,
+               float2 *__restrict__ bins, float *__restrict__ db, float scaledb)
+{
+	__shared__ float2 ex[16 * 289];
+	const unsigned int row0 = blockIdx.x * 16u;
+	const float2 *win = work + (size_t)blockIdx.y * 65536u;
+	float2 v[16];
+	{
+		const unsigned int t = threadIdx.x & 15u, r = threadIdx.x >> 4;
+#pragma unroll
+		for (int a = 0; a < 16; ++a)
+			v[a] = win[(row0 + r) * 256u + a * 16u + t];
+		fft16(v);
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			const float2 w = w256(tw256, t * k);
+			ex[k * 289u + r * 17u + t] = (k == 0) ? v[k] : cmul(v[k], w);
+		}
+	}
+	__syncthreads();
+	{
+		const unsigned int r = threadIdx.x & 15u, t = threadIdx.x >> 4;   /* t = k_low */
+#pragma unroll
+		for (int b = 0; b < 16; ++b)
+			v[b] = ex[t * 289u + r * 17u + b];
+		fft16(v);
+		const size_t fbase = (size_t)blockIdx.y * 65536u;
+#pragma unroll
+		for (int kh = 0; kh < 16; ++kh) {
+			const unsigned int k = row0 + r + 256u * (t + 16u * kh);
+			if (bins)
+				bins[fbase + k] = v[kh];
+			if (db)
+				db[fbase + ((k + 32768u) & 65535u)] = to_db(v[kh], scaledb);
+		}
+	}
+}
+
 /* getSpectrum on stored bins (io/spectrumsink.cxx:125-142) */
 __global__ void k_bins_to_db(const float2 *__restrict__ bins, unsigned int n, float *__restrict__ db,
                              float scaledb)
@@ -198,6 +336,26 @@ hipError_t wrk_fft_frames(hipStream_t st, const WrFftPlan &P, const float *iq, s
 			(const float2 *)iq, hop, P.n, P.window, (const float2 *)P.tw_n, (float2 *)bins_out,
 			db_out, scaledb);
 		return hipGetLastError();
+	}
+	if (P.n1 == 256 && P.n2 == 256) {
+		size_t done = 0;
+		while (done < nframes_fft) {
+			size_t batch = nframes_fft - done;
+			if (batch > P.work_frames)
+				batch = P.work_frames;
+			dim3 grid(16, (unsigned int)batch);
+			k_fft64k_pass1<<<grid, 256, 0, st>>>((const float2 *)(iq + 2 * done * hop), hop, P.window,
+			                                     (const float2 *)P.tw_sub, (const float2 *)P.tw_n, (float2 *)P.work);
+			k_fft64k_pass2<<<grid, 256, 0, st>>>(
+				(const float2 *)P.work, (const float2 *)P.tw_sub,
+				bins_out ? (float2 *)(bins_out + 2 * done * P.n) : (float2 *)nullptr,
+				db_out ? db_out + done * P.n : (float *)nullptr, scaledb);
+			e = hipGetLastError();
+			if (e != hipSuccess)
+				return e;
+			done += batch;
+		}
+		return hipSuccess;
 	}
 	const unsigned int tw_sub_len = P.n1 > P.n2 ? P.n1 : P.n2;
 	unsigned int ct = 8192u / P.n1;
