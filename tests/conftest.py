@@ -11,6 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The built libraries are git-ignored; if this checkout has none (fresh clone), build them
+    # once (hipcc cross-compiles gfx950 without a GPU).  Nothing is ever substituted for them.
+    needed = [os.path.join(ROOT, "webradio_amd", "lib", "libwebradio_amd.so"),
+              os.path.join(ROOT, "webradio_amd", "host", "libwebradio_host.so"),
+              os.path.join(ROOT, "oracle", "libwr_oracle.so"),
+              os.path.join(ROOT, "tests", "cxx", "libwr_host_pipeline.so")]
+    if not all(os.path.exists(p) for p in needed):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def _gpu_available():

@@ -497,15 +497,24 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 	const int fl = flags[s];
 	if ((fl & PHASE_FLAG_ACTIVE) && kbeg < k1) {
 		const int m = mode[s];
-		float2 p = kbeg ? chan_iq[(size_t)(kbeg - 1u) * slots + s] : prev_iq[s];
 		const unsigned int kend = (kbeg + DEM_RPT < k1) ? kbeg + DEM_RPT : k1;
-		for (unsigned int k = kbeg; k < kend; ++k) {
-			const float2 z = chan_iq[(size_t)k * slots + s];
-			const float v = demod_one(m, z.x, z.y, p.x, p.y);
-			dem[(size_t)(WR_HIST + k) * slots + s] = v;
-			if (k + WR_HIST >= k1)                      /* among the last 63 rows */
-				dem_next[(size_t)(k + WR_HIST - k1) * slots + s] = v;
-			p = z;
+		/* all loads first: the rows are independent, their latency should overlap */
+		float2 z[DEM_RPT + 1];
+		z[0] = kbeg ? chan_iq[(size_t)(kbeg - 1u) * slots + s] : prev_iq[s];
+#pragma unroll
+		for (unsigned int i = 0; i < DEM_RPT; ++i)
+			z[i + 1] = (kbeg + i < kend) ? chan_iq[(size_t)(kbeg + i) * slots + s] : make_float2(0.0f, 0.0f);
+		float2 p = z[0];
+#pragma unroll
+		for (unsigned int i = 0; i < DEM_RPT; ++i) {
+			const unsigned int k = kbeg + i;
+			if (k < kend) {
+				const float v = demod_one(m, z[i + 1].x, z[i + 1].y, z[i].x, z[i].y);
+				dem[(size_t)(WR_HIST + k) * slots + s] = v;
+				if (k + WR_HIST >= k1)                  /* among the last 63 rows */
+					dem_next[(size_t)(k + WR_HIST - k1) * slots + s] = v;
+				p = z[i + 1];
+			}
 		}
 		if (kend == k1)
 			prev_next[s] = p;
@@ -532,7 +541,7 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
  * the finished 64 x tk tile is transposed through LDS so that audio[s][k2] (channel
  * major, what each audio sink consumes) is written in runs. */
 #define AUD_ROWS 352u          /* staged demod rows: 352 x 64 x 4 B = 88 KiB */
-#define AUD_TMAX 32u
+#define AUD_TMAX 16u
 #define AUD_THREADS 1024u
 __global__ void __launch_bounds__(AUD_THREADS)
 k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsigned int d2,
@@ -540,8 +549,9 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
               const int *__restrict__ flags, float *__restrict__ audio, size_t k2max)
 {
 	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [64][64] taps, [AUD_TMAX][65] out */
-	float *stage = aud_lds;
-	float *taps = aud_lds + AUD_ROWS * 64u;
+	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
+	float *stage = aud_lds;                             /* [need][64] */
+	float *taps = aud_lds + need * 64u;
 	float *tile = taps + 64u * 64u;
 	const unsigned int lane = threadIdx.x & 63u;        /* slot within the group */
 	const unsigned int row = threadIdx.x >> 6;          /* 0..15 */
@@ -549,7 +559,6 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 	const unsigned int g = blockIdx.y;
 	const unsigned int s = g * 64u + lane;
 	const size_t kbase = (size_t)blockIdx.x * tk;
-	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
 
 	for (unsigned int j = row; j < WR_FIR_LENGTH; j += nrow)
 		taps[j * 64u + lane] = taps2[(size_t)j * slots + s];
@@ -736,11 +745,14 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	unsigned int tk = AUD_TMAX;
 	if (L.d2 > 1 && (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u < tk)
 		tk = (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u;
-	const size_t lds = (AUD_ROWS * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
+	/* LDS sized to what this decimation needs, so that two workgroups fit a CU when D2 is small */
+	const unsigned int need = (tk - 1u) * L.d2 + WR_FIR_LENGTH;
+	const size_t lds = ((size_t)need * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
 	static bool attr_set = false;
 	if (!attr_set) {
+		const size_t lds_max = ((size_t)AUD_ROWS * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
 		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_audio,
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
 		if (e != hipSuccess)
 			return e;
 		attr_set = true;
