@@ -129,6 +129,16 @@ def main():
         total_samples = float(n) * args.steps * world
         value = total_samples / elapsed / 1e6
         achieved = (n * ALGO_BYTES_PER_SAMPLE / 1e9) / (ddc_ms / 1e3) if ddc_ms > 0 else 0.0
+        # HBM bytes of the dominant kernel from the PMC passes of tools/profile_round.sh (they
+        # cannot be collected from inside this process); null when the committed figure is
+        # not for this configuration
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if args.channels == 256 and args.nco == "split":
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "complex Msamples/sec (node), 256-ch DDC+NFM demod",
             "value": round(value, 2),
@@ -159,7 +169,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch, PMC FETCH_SIZE+WRITE_SIZE (profiles/traffic.json)",
                 "kernel_ms": round(ddc_ms, 5),
                 "launches_timed": launches,
                 "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SAMPLE,
