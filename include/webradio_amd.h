@@ -205,6 +205,10 @@ int wr_tuner_fetch_audio_all(wr_tuner *tuner, float *out_host, size_t out_capaci
 /* LowPass::deinit + init (dsp/lowpass.cxx:118-129, 81-116): both filter histories of the
  * channel become empty again; NCO phase and Demodulator prev_i/q are kept (quirk Q5). */
 int wr_chan_reset_history(wr_tuner *tuner, int chan);
+/* scale applied to the audio as it is stored (default 1).  The MP3 encoder behind every
+ * Receiver multiplies by 32768 before LAME (web/mp3encoder.cxx:65-72); a sink that wants
+ * that format gets it from the audio kernel's store instead of a host loop. */
+int wr_tuner_set_audio_scale(wr_tuner *tuner, float scale);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
  * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75): with `enable` != 0 every submit
@@ -232,6 +236,16 @@ int wr_spectrum_get_db(wr_spectrum *spec, float *magnitudes_host /* [fft_size] *
 /* raw complex bins of the most recent transform (FFTW order), for tests */
 int wr_spectrum_get_bins(wr_spectrum *spec, float *bins_host /* [2*fft_size] */);
 int wr_spectrum_frames_done(wr_spectrum *spec, unsigned long *frames);
+/* One waterfall row as the browser draws it (web/waterfallhandler.cxx:56-69 +
+ * html/waterfall.js:92-109), computed on the device from the most recent transform:
+ *   db_row_host[width]   (optional) dB per pixel column; non-finite values become -10000
+ *                        (waterfallhandler.cxx:65-68)
+ *   palette_host[width]  (optional) palette index clamp(floor((dB + 50) / 25 * 255), 0, 255)
+ * `width` <= fft_size, fft_size % width == 0.  hold = 0: the bin the UI's overdraw leaves
+ * visible in each column (the LAST of the fft_size/width bins that map to it);
+ * hold = 1: the maximum of those bins (peak hold, loses no narrow carrier). */
+int wr_spectrum_get_waterfall_row(wr_spectrum *spec, unsigned int width, int hold,
+                                  float *db_row_host, uint8_t *palette_host);
 /* transform `nframes_fft` whole frames laid out back to back at a fixed hop in
  * device memory and write dB rows (waterfall): frame f starts at iq_dev + 2*f*hop.
  * db_dev receives nframes_fft rows of fft_size floats (fft-shifted). Async. */

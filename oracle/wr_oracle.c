@@ -343,6 +343,38 @@ void wro_spectrum_db(unsigned int n, const float *outbuf, float *magnitudes)
 	}
 }
 
+/* One waterfall row as the browser ends up drawing it: waterfallhandler.cxx:56-69 (dB row,
+ * non-finite -> -10000) reduced to `width` pixel columns the way waterfall.js:92-109 paints
+ * (each bin fills floor(bin*w)..+ceil(w), later bins overdraw earlier ones; hold = 1 keeps
+ * the maximum instead) and mapped to a palette index floor((v + 50) / 25 * 255) clamped to
+ * 0..255 in double arithmetic, like JavaScript. */
+void wro_waterfall_row(unsigned int n, const float *outbuf, unsigned int width, int hold,
+                       float *db_row, unsigned char *palette)
+{
+	float *db = (float *)malloc(sizeof(float) * n);
+	unsigned int per = n / width;
+	wro_spectrum_db(n, outbuf, db);
+	for (unsigned int x = 0; x < width; x++) {
+		float v = 0.0f;
+		for (unsigned int i = 0; i < per; i++) {
+			float d = db[x * per + i];
+			if (!isfinite(d))
+				d = -10000.0f;
+			if (i == 0 || !hold || d > v)
+				v = d;
+		}
+		if (db_row)
+			db_row[x] = v;
+		if (palette) {
+			double c = floor(((double)v + 50.0) / 25.0 * 255.0);
+			if (c < 0.0) c = 0.0;
+			if (c > 255.0) c = 255.0;
+			palette[x] = (unsigned char)c;
+		}
+	}
+	free(db);
+}
+
 void wro_spectrum_get(const wro_spectrum *s, float *magnitudes)
 {
 	wro_spectrum_db(s->fft_size, s->outbuf, magnitudes);

@@ -91,6 +91,9 @@ void     wro_spectrum_get(const wro_spectrum *s, float *magnitudes);
 void     wro_fft_forward(unsigned int n, const float *in, float *out);
 /* dB + fftshift of one already transformed frame (spectrumsink.cxx:127-140) */
 void     wro_spectrum_db(unsigned int n, const float *outbuf, float *magnitudes);
+/* waterfall row for the UI (web/waterfallhandler.cxx:56-69, html/waterfall.js:92-109) */
+void     wro_waterfall_row(unsigned int n, const float *outbuf, unsigned int width, int hold,
+                           float *db_row, unsigned char *palette);
 
 /* ---- a7: one Receiver chain (radio.cxx:62-90): DownConverter -> LowPass ->
  *          Demodulator -> LowPass, with every intermediate materialised exactly

@@ -160,6 +160,16 @@ def spectrum_db(bins):
     return out
 
 
+def waterfall_row(bins, width, hold):
+    bins = _f32(bins)
+    n = bins.size // 2
+    db = np.empty(width, np.float32)
+    pal = np.empty(width, np.uint8)
+    lib().wro_waterfall_row(C.c_uint(n), _p(bins), C.c_uint(width), C.c_int(hold), _p(db),
+                            pal.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return db, pal
+
+
 class Spectrum:
     def __init__(self, n):
         self.s = SpectrumState()

@@ -108,3 +108,33 @@ def test_bad_sizes(dev):
     assert dev.lib.wr_spectrum_create(C.byref(h), dev.h, 500, 0) == capi.WR_ERR_ARG   # spectrumsink.cxx:53-56
     assert b"power of 2" in dev.lib.wr_last_error()
     assert dev.lib.wr_spectrum_create(C.byref(h), dev.h, 512, 1024) == capi.WR_ERR_ARG
+
+
+def test_waterfall_row_for_the_ui(dev, oracle):
+    """the row the browser draws (dB, fft-shift, column reduction, palette index)
+    produced on the device.  dB within DB_ATOL on strong columns; palette index equal except
+    where the dB difference straddles a palette step (at most one step)."""
+    n, width = 65536, 512
+    iq = synth.fm_stream(n, 100_000_000, [12_500_000, -30_000_000, 3_000], amp=0.2, noise_dbfs=-60)
+    s = Spectrum(dev, n)
+    s.push_host(iq)
+    o = oracle.Spectrum(n)
+    o.process(iq)
+    for hold in (0, 1):
+        gdb, gpal = s.waterfall_row(width, hold)
+        wdb, wpal = oracle.waterfall_row(o.bins(), width, hold)
+        strong = wdb >= wdb.max() - 60.0
+        assert np.abs(gdb - wdb)[strong].max() <= DB_ATOL
+        assert np.abs(gpal.astype(int) - wpal.astype(int)).max() <= 1
+        assert (gpal == wpal).mean() > 0.9
+    # peak hold keeps narrow carriers that plain overdraw can lose
+    assert s.waterfall_row(width, 1)[0].max() >= s.waterfall_row(width, 0)[0].max()
+    with pytest.raises(capi.WrError):
+        s.waterfall_row(500)
+    s.destroy()
+    # an all-zero frame: log10f(0) = -inf -> -10000 -> palette 0 (waterfallhandler.cxx:65-68)
+    z = Spectrum(dev, 512)
+    z.push_host(np.zeros(1024, np.float32))
+    db, pal = z.waterfall_row(512)
+    assert (db == -10000.0).all() and (pal == 0).all()
+    z.destroy()

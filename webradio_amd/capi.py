@@ -64,6 +64,8 @@ SIGNATURES = {
     "wr_chan_slot": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "wr_tuner_fetch_audio_all": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_u32)]),
     "wr_chan_reset_history": (C.c_int, [_vp, C.c_int]),
+    "wr_tuner_set_audio_scale": (C.c_int, [_vp, C.c_float]),
+    "wr_spectrum_get_waterfall_row": (C.c_int, [_vp, _u32, C.c_int, _vp, _vp]),
     "wr_tuner_profile": (C.c_int, [_vp, C.c_int]),
     "wr_tuner_profile_read": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_double)]),
     "wr_spectrum_create": (C.c_int, [C.POINTER(_vp), _vp, _u32, _u32]),

@@ -95,6 +95,7 @@ struct wr_tuner {
 	float *in_hist[2];         /* [63][2] ping-pong: last 63 IQ frames of the previous block */
 	int in_par;
 	bool submitted;
+	float audio_scale;
 	bool profiling;
 	std::vector<hipEvent_t> ev;    /* start/stop pairs */
 	size_t ev_used;                /* events recorded and not yet read */
@@ -475,6 +476,7 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->in_hist[0] = t->in_hist[1] = nullptr;
 	t->in_par = 0;
 	t->submitted = false;
+	t->audio_scale = 1.0f;
 	t->profiling = false;
 	t->ev_used = 0;
 	t->prof_ms = 0.0;
@@ -959,6 +961,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.k2max = g->k2max;
 		L.nco_mode = t->nco_mode;
 		L.uniform_taps = g->uniform_taps ? 1 : 0;
+		L.audio_scale = t->audio_scale;
 		if (t->profiling) {
 			int rc = prof_drain(t, 64);
 			if (rc)
@@ -1095,6 +1098,14 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_set_audio_scale(wr_tuner *t, float scale)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	t->audio_scale = scale;
 	return WR_OK;
 }
 
@@ -1291,6 +1302,30 @@ extern "C" int wr_spectrum_get_db(wr_spectrum *s, float *magnitudes_host)
 	HIP_TRY(wrk_bins_to_db(d->stream, s->bins, s->n, d->scratch));
 	HIP_TRY(hipMemcpyAsync(magnitudes_host, d->scratch, (size_t)s->n * sizeof(float), hipMemcpyDeviceToHost,
 	                       d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+extern "C" int wr_spectrum_get_waterfall_row(wr_spectrum *s, unsigned int width, int hold, float *db_row_host,
+                                             uint8_t *palette_host)
+{
+	if (!s || !width || width > s->n || s->n % width)
+		return fail(WR_ERR_ARG, "wr_spectrum_get_waterfall_row: width must divide fft_size");
+	if (!s->frames_done)
+		return fail(WR_ERR_STATE, "no complete frame yet");
+	wr_dev *d = s->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	int rc = dev_scratch(d, (size_t)width * 2);
+	if (rc)
+		return rc;
+	float *db_dev = d->scratch;
+	uint8_t *pal_dev = (uint8_t *)(d->scratch + width);
+	HIP_TRY(wrk_waterfall_row(d->stream, s->bins, s->n, width, hold, db_dev, pal_dev));
+	if (db_row_host)
+		HIP_TRY(hipMemcpyAsync(db_row_host, db_dev, (size_t)width * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+	if (palette_host)
+		HIP_TRY(hipMemcpyAsync(palette_host, pal_dev, width, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	return WR_OK;
 }

@@ -307,6 +307,42 @@ __global__ void k_bins_to_db(const float2 *__restrict__ bins, unsigned int n, fl
 		db[(k + (n >> 1)) & (n - 1)] = to_db(bins[k], scaledb);
 }
 
+/* waterfall row: dB + fft-shift of the stored bins reduced to `width` pixel columns */
+__global__ void k_waterfall_row(const float2 *__restrict__ bins, unsigned int n, unsigned int width, int hold,
+                                float scaledb, float *__restrict__ db_row, uint8_t *__restrict__ palette)
+{
+	const unsigned int per = n / width;
+	for (unsigned int x = blockIdx.x * blockDim.x + threadIdx.x; x < width; x += gridDim.x * blockDim.x) {
+		float v = 0.0f;
+		for (unsigned int i = 0; i < per; ++i) {
+			const unsigned int shifted = x * per + i;                 /* index in the shifted row */
+			const unsigned int k = (shifted + (n >> 1)) & (n - 1);     /* FFTW-order bin */
+			float d = to_db(bins[k], scaledb);
+			if (!isfinite(d))
+				d = -10000.0f;                                        /* waterfallhandler.cxx:65-68 */
+			if (i == 0 || !hold || d > v)
+				v = d;                                                /* last one wins, or running max */
+		}
+		if (db_row)
+			db_row[x] = v;
+		if (palette) {
+			/* waterfall.js:94-106, in double like JavaScript numbers */
+			double c = floor(((double)v + 50.0) / 25.0 * 255.0);
+			c = c < 0.0 ? 0.0 : (c > 255.0 ? 255.0 : c);
+			palette[x] = (uint8_t)c;
+		}
+	}
+}
+
+hipError_t wrk_waterfall_row(hipStream_t st, const float *bins, unsigned int n, unsigned int width, int hold,
+                             float *db_row, uint8_t *palette)
+{
+	const float scaledb = 20.0f * log10f((float)n);
+	unsigned int grid = (width + 255) / 256;
+	k_waterfall_row<<<grid, 256, 0, st>>>((const float2 *)bins, n, width, hold, scaledb, db_row, palette);
+	return hipGetLastError();
+}
+
 hipError_t wrk_bins_to_db(hipStream_t st, const float *bins, unsigned int n, float *db)
 {
 	const float scaledb = 20.0f * log10f((float)n);

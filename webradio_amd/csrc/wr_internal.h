@@ -54,6 +54,7 @@ struct WrTunerLaunch {
 	size_t       k1, k2;        /* frames per channel at channel / audio rate for this block */
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
+	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
 	int          uniform_taps;  /* every 64-slot lane group carries one tap set (all its slots) */
 };
 
@@ -93,5 +94,7 @@ hipError_t wrk_fft_frames(hipStream_t st, const WrFftPlan &P, const float *iq, s
                           size_t nframes_fft, float *bins_out /* or NULL */, float *db_out /* or NULL */);
 
 hipError_t wrk_bins_to_db(hipStream_t st, const float *bins, unsigned int n, float *db);
+hipError_t wrk_waterfall_row(hipStream_t st, const float *bins, unsigned int n, unsigned int width, int hold,
+                             float *db_row, uint8_t *palette);
 
 #endif /* WR_INTERNAL_H_ */

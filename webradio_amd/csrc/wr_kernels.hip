@@ -546,7 +546,7 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 __global__ void __launch_bounds__(AUD_THREADS)
 k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsigned int d2,
               unsigned int tk, unsigned int slots, const float *__restrict__ taps2,
-              const int *__restrict__ flags, float *__restrict__ audio, size_t k2max)
+              const int *__restrict__ flags, float *__restrict__ audio, size_t k2max, float scale)
 {
 	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [64][64] taps, [AUD_TMAX][65] out */
 	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
@@ -583,7 +583,7 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 		const unsigned int so = g * 64u + sl;
 		const size_t k = kbase + kk;
 		if (k < k2 && (flags[so] & PHASE_FLAG_ACTIVE))
-			audio[(size_t)so * k2max + k] = tile[kk * 65u + sl];
+			audio[(size_t)so * k2max + k] = (scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * scale;
 	}
 }
 
@@ -759,7 +759,7 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	}
 	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
 	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
-	                                      G.taps2, G.flags, G.audio, L.k2max);
+	                                      G.taps2, G.flags, G.audio, L.k2max, L.audio_scale);
 	return hipGetLastError();
 }
 

@@ -204,6 +204,12 @@ class Spectrum:
         check(self.lib.wr_spectrum_get_bins(self.h, ptr(out)))
         return out
 
+    def waterfall_row(self, width, hold=0):
+        db = np.empty(width, dtype=np.float32)
+        pal = np.empty(width, dtype=np.uint8)
+        check(self.lib.wr_spectrum_get_waterfall_row(self.h, width, hold, ptr(db), ptr(pal)))
+        return db, pal
+
     def frames_done(self):
         n = C.c_ulong()
         check(self.lib.wr_spectrum_frames_done(self.h, C.byref(n)))
