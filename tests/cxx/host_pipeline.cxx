@@ -116,6 +116,95 @@ int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int
 	return rc;
 }
 
+/* stop()/start() in the middle of the stream (what a REST client does when it changes the
+ * tuner's sample rate, tunercontrolhandler.cxx:88-107): LowPass histories are dropped
+ * (lowpass.cxx:118-129), NCO phase and Demodulator prev_i/q survive (quirk Q5).
+ * Two front ends are run side by side to exercise one TunerBatch per source.
+ * audio_out: [2 tuners][nrx][audio_cap]. */
+int wr_host_run_restart(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
+                        unsigned int nrx, const int *if_hz, int mode,
+                        unsigned int chan_passband, unsigned int chan_rate,
+                        unsigned int audio_passband, unsigned int audio_rate, unsigned int restart_at,
+                        float *audio_out, size_t audio_cap, size_t *audio_len)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	g_pos = 0;
+	/* both tuners replay the same recording; the second one starts one block later */
+	struct Replay2 : public Tuner {
+		Replay2(const string &n) : Tuner(n, "Replay2"), pos(0) {}
+		size_t pos;
+		bool init() { return true; }
+		void deinit() {}
+		bool process(const vector<sample_t> &, vector<sample_t> &out) {
+			size_t frames = out.size() / 2;
+			if (pos + frames > g_frames)
+				return false;
+			memcpy(out.data(), g_iq + 2 * pos, out.size() * sizeof(float));
+			pos += frames;
+			return true;
+		}
+	};
+	struct F { static Tuner *make(const string &n) { return new Replay2(n); } };
+	FrontEnd *fe[2] = { new FrontEnd(F::make), new FrontEnd(F::make) };
+	std::vector<Receiver *> rx;
+	for (int t = 0; t < 2; t++) {
+		fe[t]->tuner()->setSampleRate(rate);
+		fe[t]->tuner()->setChannels(2);
+		fe[t]->tuner()->setBlockSize(block_frames * 2);
+		static_cast<Replay2 *>(fe[t]->tuner())->pos = (size_t)t * block_frames;
+		for (unsigned int n = 0; n < nrx; n++) {
+			Receiver *r = new Receiver();
+			r->downconverter()->setIF(if_hz[n]);
+			r->channelFilter()->setPassband(chan_passband);
+			r->channelFilter()->setOutputSampleRate(chan_rate);
+			r->audioFilter()->setPassband(audio_passband);
+			r->audioFilter()->setOutputSampleRate(audio_rate);
+			r->demodulator()->setMode((Demodulator::Mode)mode);
+			r->stream()->setCapacity(audio_cap);
+			r->setFrontEnd(fe[t]);
+			rx.push_back(r);
+		}
+	}
+	int rc = 0;
+	if (!fe[0]->tuner()->start() || !fe[1]->tuner()->start())
+		rc = -1;
+	size_t blocks = nframes / block_frames - 1;
+	std::vector<std::vector<float> > keep(rx.size());
+	for (size_t b = 0; b < blocks && rc == 0; b++) {
+		if (b == restart_at) {
+			for (size_t n = 0; n < rx.size(); n++)          /* the sinks clear themselves on init() */
+				keep[n] = rx[n]->stream()->samples();
+			for (int t = 0; t < 2; t++) {
+				fe[t]->tuner()->stop();
+				if (!fe[t]->tuner()->start())
+					rc = -3;
+			}
+		}
+		Radio::run();
+	}
+	size_t len = 0;
+	for (size_t n = 0; n < rx.size() && rc == 0; n++) {
+		std::vector<float> all = keep[n];
+		const vector<float> &a = rx[n]->stream()->samples();
+		all.insert(all.end(), a.begin(), a.end());
+		if (n == 0)
+			len = all.size();
+		if (all.size() != len || len > audio_cap)
+			rc = -2;
+		else
+			memcpy(audio_out + n * audio_cap, all.data(), len * sizeof(float));
+	}
+	*audio_len = len;
+	for (int t = 0; t < 2; t++)
+		fe[t]->tuner()->stop();
+	for (size_t n = 0; n < rx.size(); n++)
+		delete rx[n];
+	delete fe[0];
+	delete fe[1];
+	return rc;
+}
+
 int wr_host_registry_sizes(void)
 {
 	return (int)(Radio::frontEnds().size() * 1000 + Radio::receivers().size());

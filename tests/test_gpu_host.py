@@ -130,3 +130,53 @@ def test_reference_radio_cxx_on_our_blocks(tmp_path, oracle):
     w = o.get()
     strong = w >= w.max() - 60
     assert np.abs(spec - w)[strong].max() <= 0.02
+
+
+RESTART_RUNNER = r'''
+import ctypes as C, sys, numpy as np
+lib, npz = sys.argv[1], sys.argv[2]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz)
+iq = np.ascontiguousarray(d["iq"], np.float32); ifs = np.ascontiguousarray(d["ifs"], np.int32); p = d["params"]
+nrx = ifs.size; cap = int(p[8])
+audio = np.zeros((2 * nrx, cap), np.float32); n = C.c_size_t()
+fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+L.wr_host_run_restart.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, ip, C.c_int, C.c_uint, C.c_uint, C.c_uint,
+                                  C.c_uint, C.c_uint, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+rc = L.wr_host_run_restart(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), nrx, ifs.ctypes.data_as(ip), int(p[6]),
+                           int(p[2]), int(p[3]), int(p[4]), int(p[5]), int(p[7]), audio.ctypes.data_as(fp), cap, C.byref(n))
+np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], left=L.wr_host_registry_sizes())
+'''
+
+
+def test_stop_start_keeps_phase_and_two_front_ends(tmp_path, oracle):
+    """stop()/start() mid-stream: both LowPass histories restart empty (lowpass.cxx:118-129),
+    DownConverter::phase and Demodulator::prev_i/q carry on (quirk Q5); two FrontEnds, each
+    with its own TunerBatch, run side by side on different parts of the recording."""
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    ifs, mode = [50_000, -75_000, 4321], 3                        # LSB: linear, tight tolerance
+    rate, block = CFG["rate"], CFG["block"]
+    nblk, restart_at = 5, 2
+    iq = synth.fm_stream((nblk + 1) * block, rate, ifs, amp=0.2)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    cap = nblk * (block // 2000) + 16
+    np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
+             params=np.array([rate, block, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], mode, restart_at, cap], np.int64))
+    subprocess.check_call([sys.executable, "-c", RESTART_RUNNER, lib, inp, out],
+                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
+    r = np.load(out)
+    assert int(r["rc"]) == 0 and int(r["left"]) == 0
+    got = r["audio"]
+    for t in range(2):
+        for c, f in enumerate(ifs):
+            rx = oracle.Receiver(rate, f, CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+            a = []
+            for b in range(nblk):
+                if b == restart_at:                               # fresh filters, same NCO phase and prev_i/q
+                    nx = oracle.Receiver(rate, f, CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+                    nx.s.phase, nx.s.prev_i, nx.s.prev_q = rx.s.phase, rx.s.prev_i, rx.s.prev_q
+                    rx = nx
+                a.append(rx.run(iq[2 * (b + t) * block: 2 * (b + t + 1) * block])[0])
+            want = np.concatenate(a)
+            assert np.array_equal(got[t * len(ifs) + c].view(np.uint32), want.view(np.uint32)), (t, c)
