@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--nco", choices=["split", "exact"], default="split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2)
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="bracket every n-th step's dominant kernel with HIP events (an event pair costs ~4 us)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     return ap.parse_args()
@@ -105,7 +107,7 @@ def main():
 
     for _ in range(args.warmup):
         tuner.submit_device(x, n)
-    tuner.profile(True)
+    tuner.profile(max(1, args.profile_stride))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -211,7 +211,8 @@ int wr_chan_reset_history(wr_tuner *tuner, int chan);
 int wr_tuner_set_audio_scale(wr_tuner *tuner, float scale);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
- * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75): with `enable` != 0 every submit
+ * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75): with `enable` = 1 every submit (with
+ * `enable` = n > 1 every n-th submit: an event pair costs a few microseconds of stream time)
  * brackets its dominant kernel (the fused mixer + channel filter) with HIP events on
  * the tuner's stream.  wr_tuner_profile_read synchronises, returns the number of
  * bracketed launches since the last read and their mean duration in milliseconds, and

@@ -33,7 +33,7 @@ def test_single_gpu_line():
     assert abs(j["value"] - 4.0e6 * 5 / (j["ms_per_step"] * 5 / 1e3) / 1e6) / j["value"] < 1e-3
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["launches_timed"] == 5
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 1 <= r["launches_timed"] <= 5
     assert r["kernel_ms"] < j["ms_per_step"]                      # the dominant kernel is part of a step
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0

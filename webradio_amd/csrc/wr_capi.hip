@@ -75,6 +75,12 @@ struct Group {
 	WrGroupDev dev;
 	int parity;                /* index of the current ping-pong buffers (prev_iq, dem) */
 	int last_parity;           /* parity the last submit wrote its demod rows with */
+	int sp;                    /* state set (phase, hist_step, flags) the next block reads */
+	int cb;                    /* chan_iq buffer the next block writes */
+	int last_cb;               /* chan_iq buffer the last submit wrote */
+	hipEvent_t ev_ddc;         /* DDC of the last submit done (main stream) */
+	hipEvent_t ev_demod[2];    /* the demod that read chan_iq[i] is done (post stream) */
+	bool ev_demod_valid[2];
 	std::vector<int> owner;    /* slot -> chan or -1 */
 	bool dirty;                /* parameters must be uploaded before the next launch */
 	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
@@ -95,8 +101,14 @@ struct wr_tuner {
 	float *in_hist[2];         /* [63][2] ping-pong: last 63 IQ frames of the previous block */
 	int in_par;
 	bool submitted;
+	hipStream_t post_stream;   /* demod + audio of block b run here while block b+1's DDC runs */
+	bool overlap;
+	hipEvent_t ev_post;        /* everything of the last submit done */
+	bool ev_post_valid;
 	float audio_scale;
 	bool profiling;
+	unsigned int prof_stride;  /* bracket every prof_stride-th submit */
+	unsigned int prof_tick;
 	std::vector<hipEvent_t> ev;    /* start/stop pairs */
 	size_t ev_used;                /* events recorded and not yet read */
 	double prof_ms;
@@ -395,16 +407,25 @@ static void group_free(Group *g)
 {
 	if (!g)
 		return;
-	(void)hipFree(g->dev.phase);
+	(void)hipFree(g->dev.phase[0]);
+	(void)hipFree(g->dev.phase[1]);
 	(void)hipFree(g->dev.step);
-	(void)hipFree(g->dev.hist_step);
-	(void)hipFree(g->dev.flags);
+	(void)hipFree(g->dev.hist_step[0]);
+	(void)hipFree(g->dev.hist_step[1]);
+	(void)hipFree(g->dev.flags[0]);
+	(void)hipFree(g->dev.flags[1]);
 	(void)hipFree(g->dev.mode);
 	(void)hipFree(g->dev.taps1);
 	(void)hipFree(g->dev.taps2);
 	(void)hipFree(g->dev.prev_iq[0]);
 	(void)hipFree(g->dev.prev_iq[1]);
-	(void)hipFree(g->dev.chan_iq);
+	(void)hipFree(g->dev.chan_iq[0]);
+	(void)hipFree(g->dev.chan_iq[1]);
+	if (g->ev_ddc)
+		(void)hipEventDestroy(g->ev_ddc);
+	for (int i = 0; i < 2; ++i)
+		if (g->ev_demod[i])
+			(void)hipEventDestroy(g->ev_demod[i]);
 	(void)hipFree(g->dev.dem[0]);
 	(void)hipFree(g->dev.dem[1]);
 	(void)hipFree(g->dev.audio);
@@ -418,6 +439,10 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 		return fail(WR_ERR_NOMEM, "out of memory");
 	memset(&g->dev, 0, sizeof(g->dev));
 	g->parity = g->last_parity = 0;
+	g->sp = g->cb = g->last_cb = 0;
+	g->ev_ddc = nullptr;
+	g->ev_demod[0] = g->ev_demod[1] = nullptr;
+	g->ev_demod_valid[0] = g->ev_demod_valid[1] = false;
 	g->d1 = d1;
 	g->d2 = d2;
 	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
@@ -432,16 +457,23 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	g->active = 0;
 	const size_t S = g->slots;
 	int rc = WR_OK;
-	if (!rc) rc = dev_alloc_zero(&g->dev.phase, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.phase[0], S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.phase[1], S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.step, S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.hist_step, S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.flags, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_step[0], S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_step[1], S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.flags[0], S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.flags[1], S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
-	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq, (g->k1max ? g->k1max : 1) * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[1], (g->k1max ? g->k1max : 1) * S * 2);
+	if (!rc && hipEventCreateWithFlags(&g->ev_ddc, hipEventDisableTiming) != hipSuccess) rc = fail(WR_ERR_HIP, "hipEventCreate");
+	for (int i = 0; i < 2 && !rc; ++i)
+		if (hipEventCreateWithFlags(&g->ev_demod[i], hipEventDisableTiming) != hipSuccess) rc = fail(WR_ERR_HIP, "hipEventCreate");
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], (WR_HIST + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], (WR_HIST + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
@@ -476,11 +508,28 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->in_hist[0] = t->in_hist[1] = nullptr;
 	t->in_par = 0;
 	t->submitted = false;
+	t->post_stream = nullptr;
+	t->ev_post = nullptr;
+	t->ev_post_valid = false;
+	{
+		/* Opt-in experiment: run demod + audio of block b on a second stream beside the DDC of
+		 * block b+1.  Measured on MI355X / ROCm 7.2: the cross-stream event
+		 * hand-off costs ~20 us per block, as much as the overlap saves, so it is off. */
+		const char *on = getenv("WR_OVERLAP");
+		t->overlap = (on && *on && *on != '0');
+	}
 	t->audio_scale = 1.0f;
 	t->profiling = false;
+	t->prof_stride = 1;
+	t->prof_tick = 0;
 	t->ev_used = 0;
 	t->prof_ms = 0.0;
 	t->prof_n = 0;
+	if (hipStreamCreateWithFlags(&t->post_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&t->ev_post, hipEventDisableTiming) != hipSuccess) {
+		wr_tuner_destroy(t);
+		return fail(WR_ERR_HIP, "wr_tuner_create: stream/event creation failed");
+	}
 	int rc = dev_alloc_zero(&t->in_hist[0], (size_t)WR_HIST * 2);
 	if (!rc)
 		rc = dev_alloc_zero(&t->in_hist[1], (size_t)WR_HIST * 2);
@@ -498,8 +547,14 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 		return WR_OK;
 	(void)hipSetDevice(t->dev->device);
 	(void)hipStreamSynchronize(t->dev->stream);
+	if (t->post_stream)
+		(void)hipStreamSynchronize(t->post_stream);
 	for (Group *g : t->groups)
 		group_free(g);
+	if (t->ev_post)
+		(void)hipEventDestroy(t->ev_post);
+	if (t->post_stream)
+		(void)hipStreamDestroy(t->post_stream);
 	for (hipEvent_t e : t->ev)
 		(void)hipEventDestroy(e);
 	(void)hipFree(t->in_stage);
@@ -508,6 +563,9 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 	delete t;
 	return WR_OK;
 }
+
+static int tuner_join(wr_tuner *t);
+static int tuner_quiesce(wr_tuner *t);
 
 static Chan *chan_get(wr_tuner *t, int chan)
 {
@@ -577,7 +635,11 @@ static int chan_unseat(wr_tuner *t, Chan &c, bool keep_state)
 	Group *g = t->groups[c.group];
 	if (dev_bind(t->dev))
 		return WR_ERR_HIP;
-	HIP_TRY(hipStreamSynchronize(t->dev->stream));
+	{
+		int rc = tuner_quiesce(t);
+		if (rc)
+			return rc;
+	}
 	if (keep_state)
 		HIP_TRY(hipMemcpy(c.prev_iq, g->dev.prev_iq[g->parity] + 2 * c.slot, 2 * sizeof(float),
 		                  hipMemcpyDeviceToHost));
@@ -739,7 +801,11 @@ extern "C" int wr_chan_get_state(wr_tuner *t, int chan, unsigned int *phase, flo
 			Group *g = t->groups[c->group];
 			if (dev_bind(t->dev))
 				return WR_ERR_HIP;
-			HIP_TRY(hipStreamSynchronize(t->dev->stream));
+			{
+				int rc = tuner_quiesce(t);
+				if (rc)
+					return rc;
+			}
 			HIP_TRY(hipMemcpy(prev_iq, g->dev.prev_iq[g->parity] + 2 * c->slot, 2 * sizeof(float),
 			                  hipMemcpyDeviceToHost));
 		} else {
@@ -778,13 +844,35 @@ extern "C" int wr_chan_slot(wr_tuner *t, int chan, int *slot)
 	return WR_OK;
 }
 
+/* make the main stream wait for the post-processing stream (results of the last submit) */
+static int tuner_join(wr_tuner *t)
+{
+	if (t->ev_post_valid)
+		HIP_TRY(hipStreamWaitEvent(t->dev->stream, t->ev_post, 0));
+	return WR_OK;
+}
+
+/* host is about to touch device arrays the post kernels read: drain both streams */
+static int tuner_quiesce(wr_tuner *t)
+{
+	HIP_TRY(hipStreamSynchronize(t->dev->stream));
+	if (t->post_stream)
+		HIP_TRY(hipStreamSynchronize(t->post_stream));
+	return WR_OK;
+}
+
 /* push the host shadow of one group's parameters to its device arrays */
 static int group_upload(wr_tuner *t, Group *g)
 {
 	const size_t S = g->slots;
 	hipStream_t st = t->dev->stream;
+	{
+		int rc = tuner_quiesce(t);
+		if (rc)
+			return rc;
+	}
 	std::vector<unsigned int> step(S, 0);
-	std::vector<int> flags(S, 0), mode(S, 0);
+	std::vector<int> flags(S, 0), mode(S, -1);      /* mode < 0 marks an idle slot */
 	std::vector<float> taps1(S * WR_FIR_LENGTH, 0.0f), taps2(S * WR_FIR_LENGTH, 0.0f);
 	for (size_t s = 0; s < S; ++s) {
 		int ci = g->owner[s];
@@ -824,7 +912,7 @@ static int group_upload(wr_tuner *t, Group *g)
 	g->uniform_taps = uniform;
 	/* pageable sources: hipMemcpyAsync stages them before returning */
 	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.flags[g->sp], flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.mode, mode.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1, taps1.data(), taps1.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -834,7 +922,7 @@ static int group_upload(wr_tuner *t, Group *g)
 			continue;
 		Chan &c = t->chans[ci];
 		if (c.phase_dirty) {
-			HIP_TRY(hipMemcpyAsync(g->dev.phase + s, &c.phaseL, sizeof(unsigned int), hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(g->dev.phase[g->sp] + s, &c.phaseL, sizeof(unsigned int), hipMemcpyHostToDevice, st));
 			c.phase_dirty = false;
 		}
 		if (c.prev_dirty) {
@@ -873,6 +961,8 @@ extern "C" int wr_tuner_profile(wr_tuner *t, int enable)
 	if (!t)
 		return fail(WR_ERR_ARG, "tuner is NULL");
 	t->profiling = enable != 0;
+	t->prof_stride = enable > 1 ? (unsigned int)enable : 1u;
+	t->prof_tick = 0;
 	return WR_OK;
 }
 
@@ -935,6 +1025,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 	const uint8_t *cur_u8 = u8 ? (const uint8_t *)src : nullptr;
 
 	bool hist_written = false;
+	const bool prof_now = t->profiling && (t->prof_tick++ % t->prof_stride) == 0;
 	for (Group *g : t->groups) {
 		if (g->active <= 0) {
 			g->last_k1 = g->last_k2 = 0;
@@ -951,6 +1042,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.hist = t->in_hist[t->in_par];
 		L.hist_next = t->in_hist[t->in_par ^ 1];
 		L.parity = g->parity;
+		L.sp = g->sp;
+		L.cb = g->cb;
 		L.nframes = nframes;
 		L.d1 = g->d1;
 		L.d2 = g->d2;
@@ -962,7 +1055,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.nco_mode = t->nco_mode;
 		L.uniform_taps = g->uniform_taps ? 1 : 0;
 		L.audio_scale = t->audio_scale;
-		if (t->profiling) {
+		L.overlapped = t->overlap ? 1 : 0;
+		if (prof_now) {
 			int rc = prof_drain(t, 64);
 			if (rc)
 				return rc;
@@ -973,22 +1067,44 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			}
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
 		}
+		/* this block's DDC overwrites chan_iq[cb]: the demod that read it two blocks ago must
+		 * be done (a GPU-side wait; in steady state it completed long ago) */
+		hipStream_t ps = t->overlap ? t->post_stream : st;
+		if (t->overlap && g->ev_demod_valid[g->cb])
+			HIP_TRY(hipStreamWaitEvent(st, g->ev_demod[g->cb], 0));
 		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, d->table, d->hi_cs, d->lo_cs, d->num_cus));
-		if (t->profiling) {
+		if (prof_now) {
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
 			t->ev_used += 2;
 		}
-		HIP_TRY(wrk_tuner_demod(st, L, g->dev));
-		HIP_TRY(wrk_tuner_audio(st, L, g->dev));
+		if (!L.k1)
+			HIP_TRY(wrk_tuner_advance(st, L, g->dev));       /* no DDC launch: still advance the NCO */
+		/* demod + audio of this block on the post stream, behind this block's DDC only:
+		 * the next block's DDC (main stream) does not wait for them */
+		if (t->overlap) {
+			HIP_TRY(hipEventRecord(g->ev_ddc, st));
+			HIP_TRY(hipStreamWaitEvent(ps, g->ev_ddc, 0));
+		}
+		HIP_TRY(wrk_tuner_demod(ps, L, g->dev));
+		if (t->overlap) {
+			HIP_TRY(hipEventRecord(g->ev_demod[g->cb], ps));
+			g->ev_demod_valid[g->cb] = true;
+		}
+		HIP_TRY(wrk_tuner_audio(ps, L, g->dev));
 		g->last_parity = g->parity;
+		g->last_cb = g->cb;
+		g->sp ^= 1;                    /* the kernels wrote the other state set */
 		if (L.k1) {
 			hist_written = true;       /* k_tuner_ddc stored the next input history */
 			g->parity ^= 1;            /* k_tuner_demod filled the other prev_iq / dem history */
-		} else {
-			HIP_TRY(wrk_tuner_advance(st, L, g->dev));
+			g->cb ^= 1;
 		}
 		g->last_k1 = L.k1;
 		g->last_k2 = L.k2;
+	}
+	if (t->overlap) {
+		HIP_TRY(hipEventRecord(t->ev_post, t->post_stream));
+		t->ev_post_valid = true;
 	}
 	if (!hist_written)
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
@@ -1017,6 +1133,11 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	{
+		int rc = tuner_join(t);         /* demod/audio of the last submit ran on the post stream */
+		if (rc)
+			return rc;
+	}
 	size_t n = 0;
 	switch (stage) {
 	case WR_STAGE_CHAN_IQ: n = g->last_k1 * 2; break;
@@ -1038,7 +1159,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 		if (rc)
 			return rc;
 		if (stage == WR_STAGE_CHAN_IQ)
-			HIP_TRY(wrk_gather_rows(d->stream, g->dev.chan_iq, g->last_k1, S * 2, (size_t)c->slot * 2, 2,
+			HIP_TRY(wrk_gather_rows(d->stream, g->dev.chan_iq[g->last_cb], g->last_k1, S * 2, (size_t)c->slot * 2, 2,
 			                        d->scratch));
 		else
 			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem[g->last_parity] + (size_t)WR_HIST * S, g->last_k1, S,
@@ -1063,6 +1184,11 @@ extern "C" int wr_tuner_audio_dev(wr_tuner *t, const float **audio_dev, size_t *
 		}
 	if (!g)
 		return fail(WR_ERR_STATE, "tuner has no configured channel");
+	{
+		int rc = tuner_join(t);         /* order the caller's stream behind the audio kernel */
+		if (rc)
+			return rc;
+	}
 	*audio_dev = g->dev.audio;
 	*chan_stride = g->k2max;
 	*frames = g->last_k2;
@@ -1095,6 +1221,11 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	{
+		int rc = tuner_join(t);
+		if (rc)
+			return rc;
+	}
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));

@@ -28,15 +28,18 @@ void     wrd_twiddles(unsigned int n, float *tw /* [n/2][2] cos,-sin of 2*pi*k/n
 /* ---- per-slot parameter block of one rate group of a tuner, device SoA ---- */
 struct WrGroupDev {
 	/* all arrays have `slots` entries (slots is a multiple of 64) unless noted */
-	unsigned int *phase;        /* left-aligned phase at block start: DownConverter::phase << 1 */
+	/* the three arrays a block CHANGES come as two sets: a launch reads set `sp` and writes
+	 * set `sp ^ 1`, so consecutive blocks' DDC launches depend only on each other */
+	unsigned int *phase[2];     /* left-aligned phase at block start: DownConverter::phase << 1 */
 	unsigned int *step;         /* phaseStep << 1 (two's complement) for this block */
-	unsigned int *hist_step;    /* phaseStep << 1 that was in force during the previous block */
-	int          *flags;        /* bit0: slot active; bit1: channel-filter history valid */
-	int          *mode;         /* wr_mode */
+	unsigned int *hist_step[2]; /* phaseStep << 1 that was in force during the previous block */
+	int          *flags[2];     /* bit0: slot active; bit1: channel-filter history valid */
+	int          *mode;         /* wr_mode, or -1 for an idle slot (what the post-DDC kernels test) */
 	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */
 	float        *taps2;        /* [64][slots] audio-filter taps */
 	float        *prev_iq[2];   /* [slots][2] Demodulator::prev_i/prev_q, ping-pong by block parity */
-	float        *chan_iq;      /* [k1max][slots][2] channel-filter output, time major */
+	float        *chan_iq[2];   /* [k1max][slots][2] channel-filter output, time major; double buffered so
+	                               that block b+1's DDC can run while block b is being demodulated */
 	float        *dem[2];       /* [63 + k1max][slots] demod output, 63 history rows in front; ping-pong */
 	float        *audio;        /* [slots][k2max] audio, channel major */
 };
@@ -46,7 +49,9 @@ struct WrTunerLaunch {
 	const uint8_t *cur_u8;      /* ... the block is in the RTL-SDR byte format (2 bytes per frame) */
 	const float *hist;          /* last 63 IQ frames of the previous block (device) */
 	float       *hist_next;     /* receives the history for the next block */
-	int          parity;        /* which of the group's ping-pong buffers is current */
+	int          parity;        /* which of the group's prev_iq / dem ping-pong buffers is current */
+	int          sp;            /* which state set (phase, hist_step, flags) this block reads */
+	int          cb;            /* which chan_iq buffer this block writes */
 	size_t       nframes;
 	unsigned int d1, d2;
 	unsigned int slots;         /* row stride of every per-slot array */
@@ -55,6 +60,7 @@ struct WrTunerLaunch {
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
 	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
+	int          overlapped;    /* post-DDC kernels run beside the next block's DDC: use no LDS */
 	int          uniform_taps;  /* every 64-slot lane group carries one tap set (all its slots) */
 };
 

@@ -261,6 +261,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             unsigned int d1, unsigned int slots, unsigned int groups,
             const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
             const unsigned int *__restrict__ hist_step, const int *__restrict__ flags,
+            unsigned int *__restrict__ phase_next, unsigned int *__restrict__ hist_step_next,
+            int *__restrict__ flags_next,
             const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs)
@@ -293,6 +295,23 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	if (blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
 		const size_t f = nframes + lane;            /* frame index in [hist | cur] */
 		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
+	}
+
+	/* End-of-block state of every channel, written to the OTHER state set so that no reader
+	 * of this launch is disturbed and the next block's launch depends on nothing but this
+	 * one: DownConverter::phase advances by nframes steps (downconverter.cxx:103), the step
+	 * in force is remembered (the next block's filter history was mixed with it), and the
+	 * channel filter now has a history. */
+	if (blockIdx.x == 0) {
+		const unsigned int nlo = (unsigned int)nframes;
+		for (unsigned int s = threadIdx.x; s < slots; s += blockDim.x) {
+			const int f = flags[s];
+			const unsigned int stp = step[s];
+			const bool act = (f & PHASE_FLAG_ACTIVE) != 0;
+			phase_next[s] = act ? phase[s] + nlo * stp : phase[s];
+			hist_step_next[s] = act ? stp : hist_step[s];
+			flags_next[s] = act ? (f | PHASE_FLAG_HISTORY) : f;
+		}
 	}
 
 	/* Units (g, k) are dealt g-major, round-robin over the waves of the grid: a wave walks
@@ -475,17 +494,13 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
  * the previous channel-rate frame is row k-1, or prev_iq for k = 0.  The same launch
  * also finishes the block for every channel (what DspBlock::run leaves behind in the
  * members of the four blocks of a Receiver):
- *   - DownConverter::phase advances by nframes steps; the step in force is remembered
- *     (the next block's filter history was mixed with it)
  *   - Demodulator::prev_i/q := last channel-rate frame        -> prev_next (ping-pong)
  *   - audio LowPass history := last 63 demod outputs          -> dem_next rows 0..62
  * All of these go to buffers no thread of this launch reads. */
 #define DEM_RPT 8u             /* consecutive rows per thread: the previous frame stays in registers */
 __global__ void __launch_bounds__(256)
-k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots, unsigned int nframes_lo,
-              const int *__restrict__ mode, int *__restrict__ flags,
-              unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-              unsigned int *__restrict__ hist_step,
+k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
+              const int *__restrict__ mode,
               const float2 *__restrict__ prev_iq, float2 *__restrict__ prev_next,
               float *__restrict__ dem, float *__restrict__ dem_next)
 {
@@ -494,9 +509,8 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 	const unsigned int rl = threadIdx.x >> 6;
 	const unsigned int s = blockIdx.x * 64u + lane;
 	const unsigned int kbeg = (blockIdx.y * 4u + rl) * DEM_RPT;
-	const int fl = flags[s];
-	if ((fl & PHASE_FLAG_ACTIVE) && kbeg < k1) {
-		const int m = mode[s];
+	const int m = mode[s];                              /* < 0: idle slot */
+	if (m >= 0 && kbeg < k1) {
 		const unsigned int kend = (kbeg + DEM_RPT < k1) ? kbeg + DEM_RPT : k1;
 		/* all loads first: the rows are independent, their latency should overlap */
 		float2 z[DEM_RPT + 1];
@@ -521,16 +535,9 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 	}
 	/* blocks shorter than the history: the older part of the next history comes from the
 	 * current history rows (not written by this launch) */
-	if (k1 < WR_HIST && blockIdx.y == 0 && (fl & PHASE_FLAG_ACTIVE))
+	if (k1 < WR_HIST && blockIdx.y == 0 && m >= 0)
 		for (unsigned int r = rl; r < WR_HIST - k1; r += 4u)
 			dem_next[(size_t)r * slots + s] = dem[(size_t)(k1 + r) * slots + s];
-	/* DownConverter::phase etc. -- nothing in this launch reads them */
-	if (blockIdx.y == 0 && rl == 0 && (fl & PHASE_FLAG_ACTIVE)) {
-		const unsigned int stp = step[s];
-		phase[s] = phase[s] + nframes_lo * stp;
-		hist_step[s] = stp;
-		flags[s] = fl | PHASE_FLAG_HISTORY;
-	}
 }
 
 /* audio LowPass::process for every channel (dsp/lowpass.cxx:131-162, 1 channel):
@@ -546,7 +553,7 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 __global__ void __launch_bounds__(AUD_THREADS)
 k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsigned int d2,
               unsigned int tk, unsigned int slots, const float *__restrict__ taps2,
-              const int *__restrict__ flags, float *__restrict__ audio, size_t k2max, float scale)
+              const int *__restrict__ mode, float *__restrict__ audio, size_t k2max, float scale)
 {
 	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [64][64] taps, [AUD_TMAX][65] out */
 	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
@@ -582,27 +589,71 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 		const unsigned int sl = e / tk, kk = e - sl * tk;
 		const unsigned int so = g * 64u + sl;
 		const size_t k = kbase + kk;
-		if (k < k2 && (flags[so] & PHASE_FLAG_ACTIVE))
+		if (k < k2 && mode[so] >= 0)
 			audio[(size_t)so * k2max + k] = (scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * scale;
+	}
+}
+
+/* The same filter without LDS, for the overlapped schedule: while block b+1's DDC holds
+ * 144 KiB of every CU's LDS, block b's audio filter can only share the CUs if it needs
+ * none.  Thread = (slot lane, AUD_DQ consecutive output frames): taps in registers, the
+ * (AUD_DQ-1)*D2 + 64 demod rows stream through once (each row read is one coalesced 256 B
+ * segment per wave, served by L2), results leave as one 16-byte store per lane. */
+#define AUD_DQ 4u
+__global__ void __launch_bounds__(256)
+k_tuner_audio_direct(const float *__restrict__ dem, size_t k2, unsigned int d2, unsigned int slots,
+                     const float *__restrict__ taps2, const int *__restrict__ mode,
+                     float *__restrict__ audio, size_t k2max, float scale)
+{
+	const unsigned int lane = threadIdx.x & 63u;
+	const unsigned int w = threadIdx.x >> 6;
+	const unsigned int s = blockIdx.y * 64u + lane;
+	const size_t kq = ((size_t)blockIdx.x * 4u + w) * AUD_DQ;      /* first output frame of this thread */
+	if (kq >= k2 || mode[s] < 0)
+		return;
+	float h[WR_FIR_LENGTH];
+#pragma unroll
+	for (int j = 0; j < WR_FIR_LENGTH; ++j)
+		h[j] = taps2[(size_t)j * slots + s];
+	float acc[AUD_DQ];
+#pragma unroll
+	for (unsigned int q = 0; q < AUD_DQ; ++q) {
+		acc[q] = 0.0f;
+		if (kq + q < k2) {
+			const float *x = dem + ((kq + q) * d2) * slots + s;
+#pragma unroll 16
+			for (int j = 0; j < WR_FIR_LENGTH; ++j)
+				acc[q] = acc[q] + h[WR_FIR_LENGTH - 1 - j] * x[(size_t)j * slots];
+			if (scale != 1.0f)
+				acc[q] = acc[q] * scale;
+		}
+	}
+	float *o = audio + (size_t)s * k2max + kq;
+	if (kq + AUD_DQ <= k2 && ((k2max & 3u) == 0)) {
+		*reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+	} else {
+		for (unsigned int q = 0; q < AUD_DQ && kq + q < k2; ++q)
+			o[q] = acc[q];
 	}
 }
 
 /* a block too short to produce a channel-rate frame still advances the NCO
  * (downconverter.cxx:103 runs per input frame) */
 __global__ void k_tuner_advance(unsigned int slots, unsigned int nframes_lo,
-                                unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-                                unsigned int *__restrict__ hist_step, int *__restrict__ flags)
+                                const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+                                const unsigned int *__restrict__ hist_step, const int *__restrict__ flags,
+                                unsigned int *__restrict__ phase_next, unsigned int *__restrict__ hist_step_next,
+                                int *__restrict__ flags_next)
 {
 	unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= slots)
 		return;
-	int fl = flags[s];
-	if (!(fl & PHASE_FLAG_ACTIVE))
-		return;
-	unsigned int stp = step[s];
-	phase[s] = phase[s] + nframes_lo * stp;
-	hist_step[s] = stp;
-	flags[s] = fl | PHASE_FLAG_HISTORY;
+	const int f = flags[s];
+	const unsigned int stp = step[s];
+	const bool act = (f & PHASE_FLAG_ACTIVE) != 0;
+	phase_next[s] = act ? phase[s] + nframes_lo * stp : phase[s];
+	hist_step_next[s] = act ? stp : hist_step[s];
+	flags_next[s] = act ? (f | PHASE_FLAG_HISTORY) : f;
 }
 
 /* strided row gather: dst[r*width + i] = src[r*row_stride + col_offset + i] */
@@ -696,7 +747,8 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
-		L.slots, L.slots_used / 64, G.phase, G.step, G.hist_step, G.flags, G.taps1, (float2 *)G.chan_iq, table_dev,
+		L.slots, L.slots_used / 64, G.phase[L.sp], G.step, G.hist_step[L.sp], G.flags[L.sp], G.phase[L.sp ^ 1],
+		G.hist_step[L.sp ^ 1], G.flags[L.sp ^ 1], G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev);
 	return hipGetLastError();
 }
@@ -732,8 +784,8 @@ hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	const int p = L.parity;
 	dim3 grid(L.slots_used / 64, (unsigned int)((L.k1 + 4 * DEM_RPT - 1) / (4 * DEM_RPT)));
 	k_tuner_demod<<<grid, 256, 0, st>>>(
-		(const float2 *)G.chan_iq, (unsigned int)L.k1, L.slots, (unsigned int)L.nframes, G.mode, G.flags, G.phase, G.step,
-		G.hist_step, (const float2 *)G.prev_iq[p], (float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1]);
+		(const float2 *)G.chan_iq[L.cb], (unsigned int)L.k1, L.slots, G.mode, (const float2 *)G.prev_iq[p],
+		(float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1]);
 	return hipGetLastError();
 }
 
@@ -741,6 +793,13 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 {
 	if (!L.k2 || !L.slots_used)
 		return hipSuccess;
+	if (L.overlapped) {
+		/* shares the CUs with the next block's DDC: no LDS */
+		dim3 grid((unsigned int)((L.k2 + 4 * AUD_DQ - 1) / (4 * AUD_DQ)), L.slots_used / 64);
+		k_tuner_audio_direct<<<grid, 256, 0, st>>>(G.dem[L.parity], L.k2, L.d2, L.slots, G.taps2, G.mode,
+		                                           G.audio, L.k2max, L.audio_scale);
+		return hipGetLastError();
+	}
 	/* as many output frames per tile as the staged rows allow */
 	unsigned int tk = AUD_TMAX;
 	if (L.d2 > 1 && (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u < tk)
@@ -759,7 +818,7 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	}
 	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
 	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
-	                                      G.taps2, G.flags, G.audio, L.k2max, L.audio_scale);
+	                                      G.taps2, G.mode, G.audio, L.k2max, L.audio_scale);
 	return hipGetLastError();
 }
 
@@ -767,8 +826,9 @@ hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGro
 {
 	if (!L.slots)
 		return hipSuccess;
-	k_tuner_advance<<<(L.slots + 255) / 256, 256, 0, st>>>(L.slots, (unsigned int)L.nframes, G.phase, G.step,
-	                                                       G.hist_step, G.flags);
+	k_tuner_advance<<<(L.slots + 255) / 256, 256, 0, st>>>(L.slots, (unsigned int)L.nframes, G.phase[L.sp], G.step,
+	                                                       G.hist_step[L.sp], G.flags[L.sp], G.phase[L.sp ^ 1],
+	                                                       G.hist_step[L.sp ^ 1], G.flags[L.sp ^ 1]);
 	return hipGetLastError();
 }
 

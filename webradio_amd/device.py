@@ -154,7 +154,8 @@ class Tuner:
         check(self.lib.wr_chan_set_state(self.h, ch, phase, ptr(p)))
 
     def profile(self, enable):
-        check(self.lib.wr_tuner_profile(self.h, 1 if enable else 0))
+        """False/0: off, True/1: every submit, n > 1: every n-th submit"""
+        check(self.lib.wr_tuner_profile(self.h, int(enable)))
 
     def profile_read(self):
         """(launches, mean milliseconds) of the dominant kernel since the last read"""
