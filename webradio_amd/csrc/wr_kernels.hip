@@ -392,7 +392,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			unsigned int P = p0 + (unsigned int)n0 * st;
 			/* two-stage software pipeline over groups of NT taps: the table gathers of
 			 * group t+1 are in flight while group t is multiplied out */
-			constexpr int NT = UTAPS ? 4 : 2;        /* per-lane taps leave fewer registers */
+			constexpr int NT = 2;                    /* measured: 2 beats 4 and 8 by 1-2 % */
 			v2f ta[2][NT], tb[2][NT];                /* gathered cis(coarse), cis(fine)       */
 			v4f xw[2][NT / 2];                       /* window samples, two taps per 16 B read */
 			unsigned int ah[NT], al[NT];             /* rotating address registers */
@@ -497,7 +497,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
  *   - Demodulator::prev_i/q := last channel-rate frame        -> prev_next (ping-pong)
  *   - audio LowPass history := last 63 demod outputs          -> dem_next rows 0..62
  * All of these go to buffers no thread of this launch reads. */
-#define DEM_RPT 8u             /* consecutive rows per thread: the previous frame stays in registers */
+#define DEM_RPT 4u             /* consecutive rows per thread: the previous frame stays in registers */
 __global__ void __launch_bounds__(256)
 k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
               const int *__restrict__ mode,
