@@ -1,0 +1,124 @@
+/*
+ * host_bench.cxx -- the drop-in path at BASELINE config-2 scale: one FrontEnd, 256 Receivers
+ * wired exactly as radio.cxx wires them, Radio::run() pumping 4 000 000-frame blocks.  What a
+ * webradio process would see: the tuner block lives in HOST memory (PCIe is inside the
+ * timing), every Receiver's AudioStreamManager gets its audio.  TEST/MEASUREMENT DRIVER.
+ *
+ *   host_bench [receivers=256] [blocks=10] [block_frames=4000000]
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <vector>
+
+#include "radio.h"
+
+namespace {
+
+std::vector<float> g_block;
+
+/* a tuner that hands out the same synthetic block every time.  Like RtlSdrTuner::process
+ * (io/rtlsdrtuner.cxx:265-285) it SWAPS a filled buffer into the output vector instead of
+ * copying: what is timed is the framework, not a 32 MB memcpy of the source's own. */
+class SynthTuner : public Tuner {
+public:
+	SynthTuner(const string &n) : Tuner(n, "SynthTuner") {}
+protected:
+	bool init() { spare = g_block; primed = false; return true; }
+	void deinit() {}
+	bool process(const vector<sample_t> &, vector<sample_t> &out) {
+		if (spare.size() != out.size())
+			return false;
+		out.swap(spare);
+		if (!primed) {                     /* the vector swapped out was the runtime's empty one */
+			spare = g_block;
+			primed = true;
+		}
+		return true;
+	}
+	vector<float> spare;
+	bool primed;
+};
+Tuner *make(const string &n) { return new SynthTuner(n); }
+
+double now()
+{
+	timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+	const unsigned int nrx = argc > 1 ? atoi(argv[1]) : 256;
+	const unsigned int blocks = argc > 2 ? atoi(argv[2]) : 10;
+	const unsigned int frames = argc > 3 ? atoi(argv[3]) : 4000000;
+	const unsigned int fs = 100000000;
+
+	g_block.resize((size_t)frames * 2);
+	unsigned int lcg = 12345;
+	for (size_t n = 0; n < g_block.size(); n++) {
+		lcg = lcg * 1664525u + 1013904223u;
+		g_block[n] = 0.01f * (float)((int)(lcg >> 8) - (1 << 23)) / (float)(1 << 23);
+	}
+	for (unsigned int c = 0; c < nrx; c += 4) {              /* carriers on every 4th channel */
+		double f = -39843750.0 + 312500.0 * c, a = 0.5 / 64;
+		for (unsigned int n = 0; n < frames; n++) {
+			double ph = 2.0 * M_PI * fmod(f * (double)n / fs, 1.0);
+			g_block[2 * n] += (float)(a * cos(ph));
+			g_block[2 * n + 1] += (float)(a * sin(ph));
+		}
+		if (c >= 16)
+			break;                                           /* a few carriers are enough */
+	}
+
+	FrontEnd *fe = new FrontEnd(make);
+	fe->tuner()->setSampleRate(fs);
+	fe->tuner()->setChannels(2);
+	fe->tuner()->setBlockSize(frames * 2);
+	std::vector<Receiver *> rx;
+	for (unsigned int c = 0; c < nrx; c++) {
+		Receiver *r = new Receiver();
+		r->downconverter()->setIF(-39843750 + 312500 * (int)c);
+		r->channelFilter()->setPassband(6400000);
+		r->channelFilter()->setOutputSampleRate(250000);
+		r->audioFilter()->setPassband(8000);
+		r->audioFilter()->setOutputSampleRate(50000);
+		r->demodulator()->setMode(Demodulator::FM);
+		r->stream()->setCapacity(4096);
+		r->setFrontEnd(fe);
+		rx.push_back(r);
+	}
+	if (!fe->tuner()->start()) {
+		fprintf(stderr, "start failed\n");
+		return 1;
+	}
+	Radio::run();                                            /* warm-up (allocations, uploads) */
+	Radio::run();
+	const double t0 = now();
+	for (unsigned int b = 0; b < blocks; b++)
+		Radio::run();
+	const double dt = now() - t0;
+	double sum = 0;
+	unsigned long total = 0;
+	for (size_t n = 0; n < rx.size(); n++) {
+		total += rx[n]->stream()->totalSamples();
+		const vector<float> &a = rx[n]->stream()->samples();
+		for (size_t i = 0; i < a.size(); i++)
+			sum += fabs(a[i]);
+	}
+	printf("{\"receivers\": %u, \"blocks\": %u, \"block_frames\": %u, \"ms_per_block\": %.3f, "
+	       "\"msps_tuner_input\": %.1f, \"audio_samples_per_receiver\": %lu, \"audio_abs_sum\": %.3f}\n",
+	       nrx, blocks, frames, dt / blocks * 1e3, (double)frames * blocks / dt / 1e6,
+	       total / (unsigned long)rx.size(), sum);
+	fe->tuner()->stop();
+	for (size_t n = 0; n < rx.size(); n++)
+		delete rx[n];
+	delete fe;
+	return 0;
+}

@@ -197,12 +197,18 @@ void DspBlock::setChannels(unsigned int channels)
 }
 
 DspSource::DspSource(const string &name, const string &type)
-	: DspBlock(name, type), _blockSize(DEFAULT_BLOCK_SIZE), _epoch(0), _batch(NULL)
+	: DspBlock(name, type), _blockSize(DEFAULT_BLOCK_SIZE), _epoch(0), _batch(NULL), _gpuStage(NULL),
+	  _gpuIndex(-1), _gpuCleanup(NULL)
 {
 }
 
 DspSource::~DspSource()
 {
+	/* consumers may still reference GPU resources while stopping: stop first */
+	if (isRunning())
+		stop();
+	if (_gpuCleanup)
+		_gpuCleanup(this);
 }
 
 /* The reference builds a fresh zero-filled vector of blockSize floats for every call

@@ -130,15 +130,28 @@ public:
 
 	/* number of run() calls so far: the "epoch" the tuner batch keys its launches on */
 	unsigned long epoch() const { return _epoch; }
-	/* per-source tuner batch (created on demand by the first DownConverter) */
+	/* per-source GPU resources, owned by the GPU glue (gpubatch.cxx) and released through
+	 * `_gpuCleanup` when the source dies: the tuner batch (created on demand by the first
+	 * DownConverter), the device copy of the current block shared by every GPU consumer of
+	 * this source, and the GPU the source's blocks run on (-1: not chosen yet) */
 	wrhost::TunerBatch* batch() const { return _batch; }
 	void setBatch(wrhost::TunerBatch *b) { _batch = b; }
+	void* gpuStage() const { return _gpuStage; }
+	void setGpuStage(void *p) { _gpuStage = p; }
+	int gpuIndex() const { return _gpuIndex; }
+	void setGpuIndex(int i) { _gpuIndex = i; }
+	void setGpuCleanup(void (*fn)(DspSource*)) { _gpuCleanup = fn; }
+	/* the vector the source's process() filled for the current block */
+	const vector<sample_t>& currentBlock() const { return _out; }
 
 private:
 	unsigned int		_blockSize;
 	unsigned long		_epoch;
 	vector<sample_t>	_pump;		/* the (zeroed) input vector handed to the source's own process() */
 	wrhost::TunerBatch*	_batch;
+	void*				_gpuStage;
+	int					_gpuIndex;
+	void				(*_gpuCleanup)(DspSource*);
 };
 
 #endif /* DSPBLOCK_H_ */

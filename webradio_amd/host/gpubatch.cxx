@@ -54,12 +54,70 @@ wr_dev *device(int index)
 	return g_devs[index];
 }
 
+struct SourceStage {
+	DevBuf buf;
+	unsigned long epoch;
+	const void *host;
+	size_t floats;
+	SourceStage() : epoch(0), host(NULL), floats(0) {}
+};
+
+static void releaseSource(DspSource *src)
+{
+	delete static_cast<SourceStage *>(src->gpuStage());
+	src->setGpuStage(NULL);
+	TunerBatch::destroyFor(src);
+}
+
 wr_dev *deviceFor(const DspBlock *block)
 {
-	/* a block below a batched source shares the source's GPU */
-	if (wr_dev *d = TunerBatch::batchDeviceOf(block))
-		return d;
-	return device((int)envUnsigned("WEBRADIO_DEVICE", 0));
+	DspSource *src = TunerBatch::rootSource(block);
+	if (!src)
+		return device((int)envUnsigned("WEBRADIO_DEVICE", 0));
+	if (src->gpuIndex() < 0) {
+		int count = deviceCount();
+		if (count <= 0) {
+			LOG_ERROR("no GPU: %s\n", wr_last_error());
+			return NULL;
+		}
+		std::lock_guard<std::mutex> g(g_devLock);
+		int index = getenv("WEBRADIO_DEVICE") ? (int)envUnsigned("WEBRADIO_DEVICE", 0) : (g_batches % count);
+		g_batches++;
+		src->setGpuIndex(index);
+		src->setGpuCleanup(releaseSource);
+	}
+	return device(src->gpuIndex());
+}
+
+const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out)
+{
+	DspSource *src = TunerBatch::rootSource(consumer);
+	if (!src || host.empty() || host.data() != src->currentBlock().data())
+		return NULL;                    /* not fed straight from the source: caller uploads itself */
+	wr_dev *dev = deviceFor(consumer);
+	if (!dev)
+		return NULL;
+	static std::mutex stageLock;
+	std::lock_guard<std::mutex> g(stageLock);
+	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
+	if (!st) {
+		st = new SourceStage();
+		src->setGpuStage(st);
+		src->setGpuCleanup(releaseSource);
+	}
+	if (st->epoch != src->epoch() || st->host != host.data() || st->floats != host.size()) {
+		const size_t bytes = host.size() * sizeof(float);
+		if (!st->buf.reserve(dev, bytes) || wr_dev_upload(dev, st->buf.ptr, host.data(), bytes) != WR_OK) {
+			LOG_ERROR("staging the source block failed: %s\n", wr_last_error());
+			return NULL;
+		}
+		st->epoch = src->epoch();
+		st->host = host.data();
+		st->floats = host.size();
+	}
+	if (dev_out)
+		*dev_out = dev;
+	return (const float *)st->buf.ptr;
 }
 
 bool DevBuf::reserve(wr_dev *d, size_t nbytes)
@@ -99,13 +157,30 @@ TunerBatch::~TunerBatch()
 		wr_tuner_destroy(_tuner);
 }
 
-wr_dev *TunerBatch::batchDeviceOf(const DspBlock *block)
+DspSource *TunerBatch::rootSource(const DspBlock *block)
 {
 	const DspBlock *b = block;
 	while (b && b->_producer)
 		b = b->_producer;
-	const DspSource *src = dynamic_cast<const DspSource *>(b);
+	return const_cast<DspSource *>(dynamic_cast<const DspSource *>(b));
+}
+
+wr_dev *TunerBatch::batchDeviceOf(const DspBlock *block)
+{
+	DspSource *src = rootSource(block);
 	return (src && src->batch()) ? src->batch()->dev() : NULL;
+}
+
+void TunerBatch::destroyFor(DspSource *src)
+{
+	TunerBatch *b = src->batch();
+	if (!b)
+		return;
+	src->setBatch(NULL);
+	for (size_t n = 0; n < b->_channels.size(); n++)
+		delete b->_channels[n];          /* their blocks are gone or stopping */
+	b->_channels.clear();
+	delete b;
 }
 
 /* The shape radio.cxx:68-76 builds, with nothing else attached along the way.  Only
@@ -131,20 +206,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 
 	TunerBatch *batch = src->batch();
 	if (!batch) {
-		/* tuners shard one per GPU: the n-th batched source of the process takes GPU
-		 * n mod count unless WEBRADIO_DEVICE pins it */
-		int count = deviceCount();
-		if (count <= 0) {
-			LOG_ERROR("no GPU: %s\n", wr_last_error());
-			return NULL;
-		}
-		int index;
-		{
-			std::lock_guard<std::mutex> g(g_devLock);
-			index = getenv("WEBRADIO_DEVICE") ? (int)envUnsigned("WEBRADIO_DEVICE", 0) : (g_batches % count);
-			g_batches++;
-		}
-		wr_dev *dev = device(index);
+		wr_dev *dev = deviceFor(mixer);      /* the source's GPU (tuners shard one per GPU) */
 		if (!dev)
 			return NULL;
 		batch = new TunerBatch(src, dev);
@@ -261,7 +323,11 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("block of %u frames exceeds the %zu the tuner batch was sized for\n", nframes, _maxFrames);
 		return false;
 	}
-	if (wr_tuner_submit(_tuner, tunerBuffer.data(), nframes, WR_HOST) != WR_OK) {
+	wr_dev *sdev = NULL;
+	const float *staged = _channels.empty() ? NULL : stagedBlock(_channels[0]->mixer, tunerBuffer, &sdev);
+	int rc = (staged && sdev == _dev) ? wr_tuner_submit(_tuner, staged, nframes, WR_DEVICE)
+	                                  : wr_tuner_submit(_tuner, tunerBuffer.data(), nframes, WR_HOST);
+	if (rc != WR_OK) {
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}

@@ -38,8 +38,15 @@ namespace wrhost {
 /* process-wide device contexts, one per GPU, opened on first use */
 wr_dev *device(int index);
 int deviceCount();
-/* the device a block should use: its source's batch device, else WEBRADIO_DEVICE / 0 */
+/* the device a block should use.  Every block below one DspSource shares that source's GPU:
+ * the n-th source of the process that asks takes GPU n mod count (tuners shard one per GPU),
+ * unless WEBRADIO_DEVICE pins all of them.  Blocks not below a source use WEBRADIO_DEVICE / 0. */
 wr_dev *deviceFor(const DspBlock *block);
+/* Device copy of the source's current block, uploaded once per source block and shared by
+ * every GPU consumer of that source (the SpectrumSink and the tuner batch would otherwise
+ * each push the same 32 MB over PCIe).  Returns NULL if `host` is not that source's current
+ * output vector or the upload failed. */
+const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out);
 
 /* a resizable device buffer */
 struct DevBuf {
@@ -72,6 +79,8 @@ public:
 	static void withdraw(Channel *ch);
 	/* the root source's batch device, or NULL if the block is not below a batched source */
 	static wr_dev *batchDeviceOf(const DspBlock *block);
+	static DspSource *rootSource(const DspBlock *block);
+	static void destroyFor(DspSource *src);
 
 	/* called from DownConverter::process of an enrolled block */
 	bool submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nframes);

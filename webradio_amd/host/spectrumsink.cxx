@@ -9,7 +9,7 @@
 #include "gpubatch.h"
 
 SpectrumSink::SpectrumSink(const string &name)
-	: SampleSink(name, "SpectrumSink"), _fftSize(DEFAULT_FFT_SIZE), _hop(0), _spec(NULL)
+	: SampleSink(name, "SpectrumSink"), _fftSize(DEFAULT_FFT_SIZE), _hop(0), _spec(NULL), _dev(NULL)
 {
 }
 
@@ -42,6 +42,7 @@ bool SpectrumSink::init()
 	wr_dev *dev = wrhost::deviceFor(this);
 	if (!dev)
 		return false;
+	_dev = dev;
 	if (wr_spectrum_create(&_spec, dev, _fftSize, _hop) != WR_OK) {
 		LOG_ERROR("SpectrumSink: %s\n", wr_last_error());
 		_spec = NULL;
@@ -64,7 +65,12 @@ bool SpectrumSink::process(const vector<sample_t> &inBuffer, vector<sample_t> &o
 	std::lock_guard<std::mutex> g(_lock);
 	if (!_spec)
 		return false;
-	if (wr_spectrum_push(_spec, inBuffer.data(), inBuffer.size() / 2, WR_HOST) != WR_OK) {
+	/* fed straight from the tuner: use the device copy every GPU consumer of it shares */
+	wr_dev *sdev = NULL;
+	const float *staged = wrhost::stagedBlock(this, inBuffer, &sdev);
+	int rc = (staged && sdev == _dev) ? wr_spectrum_push(_spec, staged, inBuffer.size() / 2, WR_DEVICE)
+	                                  : wr_spectrum_push(_spec, inBuffer.data(), inBuffer.size() / 2, WR_HOST);
+	if (rc != WR_OK) {
 		LOG_ERROR("SpectrumSink: %s\n", wr_last_error());
 		return false;
 	}

@@ -38,6 +38,7 @@ private:
 	unsigned int	_fftSize;
 	unsigned int	_hop;
 	wr_spectrum*	_spec;
+	wr_dev*			_dev;
 	std::mutex		_lock;		/* getSpectrum comes from HTTP threads (waterfallhandler.cxx:56-57) */
 };
 
