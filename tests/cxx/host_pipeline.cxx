@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "radio.h"
+#include "filetuner.h"
 
 namespace {
 
@@ -202,6 +203,67 @@ int wr_host_run_restart(const float *iq, size_t nframes, unsigned int rate, unsi
 		delete rx[n];
 	delete fe[0];
 	delete fe[1];
+	return rc;
+}
+
+/* BASELINE config 1: one DownConverter + FM demodulator on a recorded RTL-SDR IQ file.
+ * with_frontend = 1: FrontEnd(FileTuner::factory) + Receiver (a SpectrumSink is attached, so
+ * the float block is staged on the GPU once and shared); 0: the bare graph
+ * FileTuner -> Receiver chain, which ships the raw bytes (2 per frame) to the GPU. */
+int wr_host_run_file(const char *path, unsigned int rate, unsigned int block_frames, unsigned int nblocks,
+                     int if_hz, int mode, unsigned int chan_passband, unsigned int chan_rate,
+                     unsigned int audio_passband, unsigned int audio_rate, int with_frontend,
+                     float *audio_out, size_t audio_cap, size_t *audio_len)
+{
+	FrontEnd *fe = NULL;
+	Tuner *tuner;
+	if (with_frontend) {
+		fe = new FrontEnd(FileTuner::factory);
+		tuner = fe->tuner();
+	} else {
+		tuner = FileTuner::factory("file");
+	}
+	tuner->setSubdevice(path);
+	tuner->setSampleRate(rate);
+	tuner->setChannels(2);
+	tuner->setBlockSize(block_frames * 2);
+	Receiver *rx = new Receiver();
+	rx->downconverter()->setIF(if_hz);
+	rx->channelFilter()->setPassband(chan_passband);
+	rx->channelFilter()->setOutputSampleRate(chan_rate);
+	rx->audioFilter()->setPassband(audio_passband);
+	rx->audioFilter()->setOutputSampleRate(audio_rate);
+	rx->demodulator()->setMode((Demodulator::Mode)mode);
+	rx->stream()->setCapacity(audio_cap);
+	if (fe)
+		rx->setFrontEnd(fe);
+	else
+		tuner->connect(rx->input());
+	int rc = 0;
+	if (!tuner->start()) {
+		rc = -1;
+	} else {
+		for (unsigned int b = 0; b < nblocks; b++)
+			if (!tuner->run())
+				rc = -4;
+		/* one more block than the file holds: process() must fail, not crash */
+		if (rc == 0 && tuner->run())
+			rc = -5;
+		const vector<float> &a = rx->stream()->samples();
+		*audio_len = a.size();
+		if (a.size() > audio_cap)
+			rc = -2;
+		else
+			memcpy(audio_out, a.data(), a.size() * sizeof(float));
+		tuner->stop();
+	}
+	if (!fe)
+		tuner->disconnect(rx->input());
+	delete rx;
+	if (fe)
+		delete fe;
+	else
+		delete tuner;
 	return rc;
 }
 

@@ -180,3 +180,41 @@ def test_stop_start_keeps_phase_and_two_front_ends(tmp_path, oracle):
                 a.append(rx.run(iq[2 * (b + t) * block: 2 * (b + t + 1) * block])[0])
             want = np.concatenate(a)
             assert np.array_equal(got[t * len(ifs) + c].view(np.uint32), want.view(np.uint32)), (t, c)
+
+
+FILE_RUNNER = r'''
+import ctypes as C, sys, numpy as np
+lib, path, out = sys.argv[1], sys.argv[2], sys.argv[3]
+p = [int(v) for v in sys.argv[4:]]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+fp = C.POINTER(C.c_float)
+L.wr_host_run_file.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint,
+                               C.c_uint, C.c_int, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+audio = np.zeros(1 << 16, np.float32); n = C.c_size_t()
+rc = L.wr_host_run_file(path.encode(), *p, audio.ctypes.data_as(fp), audio.size, C.byref(n))
+np.savez(out, rc=rc, audio=audio[:n.value], left=L.wr_host_registry_sizes())
+'''
+
+
+@pytest.mark.parametrize("with_frontend", [1, 0])
+def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
+    """BASELINE config 1 end to end: FileTuner replays an RTL-SDR format recording (the committed
+    golden capture), one DownConverter + FM Receiver.  With a FrontEnd the float block is staged
+    once for SpectrumSink and receiver; without it the raw bytes go to the GPU (u8 ingest)."""
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "chain_oracle.npz"))
+    c1 = synth.C1
+    n = int(g["block_frames"])
+    path = str(tmp_path / "capture.bin")
+    g["u8"].tofile(path)
+    out = str(tmp_path / "out.npz")
+    args = [c1["input_rate"], n, 4, c1["if_hz"], 1, c1["chan_passband"], c1["chan_rate"], c1["audio_passband"],
+            c1["audio_rate"], with_frontend]
+    for env, tol in (({"WEBRADIO_NCO_EXACT": "1"}, 4.8e-7), ({}, 1e-5)):
+        subprocess.check_call([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
+                              env=dict(os.environ, WEBRADIO_QUIET="1", **env))
+        r = np.load(out)
+        assert int(r["rc"]) == 0 and int(r["left"]) == 0
+        assert r["audio"].size == g["audio"].size
+        assert np.abs(r["audio"] - g["audio"]).max() <= tol

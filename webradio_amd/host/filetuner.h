@@ -1,0 +1,63 @@
+/*
+ * filetuner.h -- a Tuner that replays a recording in the RTL-SDR byte format (unsigned 8-bit
+ * interleaved IQ, what rtl_sdr(1) writes and what RtlSdrTuner::dataReady receives,
+ * io/rtlsdrtuner.cxx:86-117).  The reference has no file source; BASELINE
+ * config 1 needs one.  Patterned on the reference's RandSource (io/randsource.cxx): a
+ * SampleSource whose process() fills the block.
+ *
+ *   setSubdevice(path)   the file to play (before start(), like every subdevice)
+ *   setLoop(true)        rewind at the end instead of failing process()
+ *
+ * Samples are converted with the reference's rule (u8 - 128) / 128 (rtlsdrtuner.cxx:106).
+ * The raw bytes of the current block stay available (RawU8Block), so the tuner batch can
+ * ship 2 bytes per frame to the GPU and convert there.
+ */
+#ifndef FILETUNER_H_
+#define FILETUNER_H_
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "tuner.h"
+
+using namespace std;
+
+/* implemented by sources that still hold the current block in the RTL-SDR byte format */
+class RawU8Block {
+public:
+	virtual ~RawU8Block() {}
+	/* bytes of the block most recently produced (2 per frame), or NULL */
+	virtual const uint8_t* rawU8(size_t *frames) const = 0;
+};
+
+class FileTuner : public Tuner, public RawU8Block
+{
+public:
+	FileTuner(const string &name = "<undefined>");
+	virtual ~FileTuner();
+
+	void setLoop(bool loop) { _loop = loop; }
+	bool loop() const { return _loop; }
+	unsigned long framesPlayed() const { return _played; }
+
+	const uint8_t* rawU8(size_t *frames) const;
+
+	static Tuner* factory(const string &name);
+
+protected:
+	bool init();
+	void deinit();
+	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer);
+
+private:
+	FILE*			_file;
+	bool			_loop;
+	unsigned long	_played;
+	vector<uint8_t>	_raw;
+	size_t			_rawFrames;
+};
+
+#endif /* FILETUNER_H_ */

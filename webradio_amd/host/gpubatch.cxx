@@ -11,6 +11,7 @@
 #include "debug.h"
 #include "demodulator.h"
 #include "downconverter.h"
+#include "filetuner.h"
 #include "lowpass.h"
 
 namespace wrhost {
@@ -89,7 +90,8 @@ wr_dev *deviceFor(const DspBlock *block)
 	return device(src->gpuIndex());
 }
 
-const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out)
+const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out,
+                         bool only_if_present)
 {
 	DspSource *src = TunerBatch::rootSource(consumer);
 	if (!src || host.empty() || host.data() != src->currentBlock().data())
@@ -100,12 +102,16 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 	static std::mutex stageLock;
 	std::lock_guard<std::mutex> g(stageLock);
 	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
+	if (!st && only_if_present)
+		return NULL;
 	if (!st) {
 		st = new SourceStage();
 		src->setGpuStage(st);
 		src->setGpuCleanup(releaseSource);
 	}
 	if (st->epoch != src->epoch() || st->host != host.data() || st->floats != host.size()) {
+		if (only_if_present)
+			return NULL;
 		const size_t bytes = host.size() * sizeof(float);
 		if (!st->buf.reserve(dev, bytes) || wr_dev_upload(dev, st->buf.ptr, host.data(), bytes) != WR_OK) {
 			LOG_ERROR("staging the source block failed: %s\n", wr_last_error());
@@ -323,10 +329,24 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("block of %u frames exceeds the %zu the tuner batch was sized for\n", nframes, _maxFrames);
 		return false;
 	}
+	/* cheapest way to get the block to the GPU: (1) a device copy some other consumer of the
+	 * source already made this block, (2) the source's raw bytes (2 per frame, converted in
+	 * the kernel's load stage), (3) stage the float block once for everybody */
 	wr_dev *sdev = NULL;
-	const float *staged = _channels.empty() ? NULL : stagedBlock(_channels[0]->mixer, tunerBuffer, &sdev);
-	int rc = (staged && sdev == _dev) ? wr_tuner_submit(_tuner, staged, nframes, WR_DEVICE)
-	                                  : wr_tuner_submit(_tuner, tunerBuffer.data(), nframes, WR_HOST);
+	int rc;
+	const float *staged = _channels.empty() ? NULL : stagedBlock(_channels[0]->mixer, tunerBuffer, &sdev, true);
+	const RawU8Block *raw = dynamic_cast<const RawU8Block *>(_source);
+	size_t rawFrames = 0;
+	const uint8_t *bytes = (raw && !staged) ? raw->rawU8(&rawFrames) : NULL;
+	if (staged && sdev == _dev) {
+		rc = wr_tuner_submit(_tuner, staged, nframes, WR_DEVICE);
+	} else if (bytes && rawFrames == nframes) {
+		rc = wr_tuner_submit_u8(_tuner, bytes, nframes, WR_HOST);
+	} else {
+		staged = _channels.empty() ? NULL : stagedBlock(_channels[0]->mixer, tunerBuffer, &sdev, false);
+		rc = (staged && sdev == _dev) ? wr_tuner_submit(_tuner, staged, nframes, WR_DEVICE)
+		                              : wr_tuner_submit(_tuner, tunerBuffer.data(), nframes, WR_HOST);
+	}
 	if (rc != WR_OK) {
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;

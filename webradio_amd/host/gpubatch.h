@@ -46,7 +46,8 @@ wr_dev *deviceFor(const DspBlock *block);
  * every GPU consumer of that source (the SpectrumSink and the tuner batch would otherwise
  * each push the same 32 MB over PCIe).  Returns NULL if `host` is not that source's current
  * output vector or the upload failed. */
-const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out);
+const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out,
+                         bool only_if_present = false);
 
 /* a resizable device buffer */
 struct DevBuf {
