@@ -59,7 +59,7 @@ struct Chan {
 	bool have[2];
 	float taps[2][WR_FIR_LENGTH];
 	unsigned int decim[2];
-	bool hist_valid;           /* channel filter has seen a block since its last reset */
+	bool cs_hist_reset;        /* channel filter history (LO rows of this slot) must be zeroed */
 	int group;                 /* index into wr_tuner::groups, -1 while unconfigured */
 	int slot;
 	float prev_iq[2];          /* only meaningful while group < 0 (parked state) */
@@ -75,7 +75,7 @@ struct Group {
 	WrGroupDev dev;
 	int parity;                /* index of the current ping-pong buffers (prev_iq, dem) */
 	int last_parity;           /* parity the last submit wrote its demod rows with */
-	int sp;                    /* state set (phase, hist_step, flags) the next block reads */
+	int sp;                    /* state set (phase, LO history) the next block reads */
 	int cb;                    /* chan_iq buffer the next block writes */
 	int last_cb;               /* chan_iq buffer the last submit wrote */
 	hipEvent_t ev_ddc;         /* DDC of the last submit done (main stream) */
@@ -410,10 +410,9 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.phase[0]);
 	(void)hipFree(g->dev.phase[1]);
 	(void)hipFree(g->dev.step);
-	(void)hipFree(g->dev.hist_step[0]);
-	(void)hipFree(g->dev.hist_step[1]);
-	(void)hipFree(g->dev.flags[0]);
-	(void)hipFree(g->dev.flags[1]);
+	(void)hipFree(g->dev.hist_cs[0]);
+	(void)hipFree(g->dev.hist_cs[1]);
+	(void)hipFree(g->dev.flags);
 	(void)hipFree(g->dev.mode);
 	(void)hipFree(g->dev.taps1);
 	(void)hipFree(g->dev.taps2);
@@ -460,10 +459,9 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.phase[0], S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.phase[1], S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.step, S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.hist_step[0], S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.hist_step[1], S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.flags[0], S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.flags[1], S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_cs[0], (size_t)WR_HIST * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_cs[1], (size_t)WR_HIST * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.flags, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
@@ -648,7 +646,7 @@ static int chan_unseat(wr_tuner *t, Chan &c, bool keep_state)
 	g->dirty = true;
 	c.group = -1;
 	c.slot = -1;
-	c.hist_valid = false;
+	c.cs_hist_reset = true;
 	c.prev_dirty = keep_state;
 	c.phase_dirty = true;
 	return WR_OK;
@@ -700,7 +698,7 @@ static int chan_seat(wr_tuner *t, int idx)
 	g->dirty = true;
 	c.group = gi;
 	c.slot = slot;
-	c.hist_valid = false;          /* fresh LowPass::block: zero history (lowpass.cxx:138-139) */
+	c.cs_hist_reset = true;        /* fresh LowPass::block: zero history (lowpass.cxx:138-139) */
 	c.dem_hist_reset = true;
 	c.prev_dirty = true;
 	c.phase_dirty = true;
@@ -881,7 +879,7 @@ static int group_upload(wr_tuner *t, Group *g)
 		Chan &c = t->chans[ci];
 		step[s] = c.stepL;
 		mode[s] = c.mode;
-		flags[s] = 1 | (c.hist_valid ? 2 : 0);
+		flags[s] = 1;
 		for (int j = 0; j < WR_FIR_LENGTH; ++j) {
 			taps1[(size_t)j * S + s] = c.taps[0][j];
 			taps2[(size_t)j * S + s] = c.taps[1][j];
@@ -912,7 +910,7 @@ static int group_upload(wr_tuner *t, Group *g)
 	g->uniform_taps = uniform;
 	/* pageable sources: hipMemcpyAsync stages them before returning */
 	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(g->dev.flags[g->sp], flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.mode, mode.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1, taps1.data(), taps1.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -928,6 +926,12 @@ static int group_upload(wr_tuner *t, Group *g)
 		if (c.prev_dirty) {
 			HIP_TRY(hipMemcpyAsync(g->dev.prev_iq[g->parity] + 2 * s, c.prev_iq, 2 * sizeof(float), hipMemcpyHostToDevice, st));
 			c.prev_dirty = false;
+		}
+		if (c.cs_hist_reset) {
+			/* 63 LO rows of this slot: one float2 per row, stride S float2 */
+			HIP_TRY(hipMemset2DAsync(g->dev.hist_cs[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
+			                         WR_HIST, st));
+			c.cs_hist_reset = false;
 		}
 		if (c.dem_hist_reset) {
 			/* 63 history rows of this slot: one float per row, stride S */
@@ -1077,8 +1081,6 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
 			t->ev_used += 2;
 		}
-		if (!L.k1)
-			HIP_TRY(wrk_tuner_advance(st, L, g->dev));       /* no DDC launch: still advance the NCO */
 		/* demod + audio of this block on the post stream, behind this block's DDC only:
 		 * the next block's DDC (main stream) does not wait for them */
 		if (t->overlap) {
@@ -1094,8 +1096,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		g->last_parity = g->parity;
 		g->last_cb = g->cb;
 		g->sp ^= 1;                    /* the kernels wrote the other state set */
+		hist_written = true;           /* k_tuner_ddc stored the next input history */
 		if (L.k1) {
-			hist_written = true;       /* k_tuner_ddc stored the next input history */
 			g->parity ^= 1;            /* k_tuner_demod filled the other prev_iq / dem history */
 			g->cb ^= 1;
 		}
@@ -1115,7 +1117,6 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		if (!c.in_use || c.group < 0)
 			continue;
 		c.phaseL += (unsigned int)nframes * c.stepL;
-		c.hist_valid = true;
 	}
 	t->submitted = true;
 	return WR_OK;
@@ -1245,7 +1246,7 @@ extern "C" int wr_chan_reset_history(wr_tuner *t, int chan)
 	Chan *c = chan_get(t, chan);
 	if (!c)
 		return fail(WR_ERR_ARG, "wr_chan_reset_history: no channel %d", chan);
-	c->hist_valid = false;
+	c->cs_hist_reset = true;
 	c->dem_hist_reset = true;
 	if (c->group >= 0)
 		t->groups[c->group]->dirty = true;

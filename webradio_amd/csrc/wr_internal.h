@@ -28,12 +28,12 @@ void     wrd_twiddles(unsigned int n, float *tw /* [n/2][2] cos,-sin of 2*pi*k/n
 /* ---- per-slot parameter block of one rate group of a tuner, device SoA ---- */
 struct WrGroupDev {
 	/* all arrays have `slots` entries (slots is a multiple of 64) unless noted */
-	/* the three arrays a block CHANGES come as two sets: a launch reads set `sp` and writes
-	 * set `sp ^ 1`, so consecutive blocks' DDC launches depend only on each other */
+	/* the arrays a block CHANGES come as two sets: a launch reads set `sp` and writes set
+	 * `sp ^ 1`, so consecutive blocks' DDC launches depend only on each other */
 	unsigned int *phase[2];     /* left-aligned phase at block start: DownConverter::phase << 1 */
 	unsigned int *step;         /* phaseStep << 1 (two's complement) for this block */
-	unsigned int *hist_step[2]; /* phaseStep << 1 that was in force during the previous block */
-	int          *flags[2];     /* bit0: slot active; bit1: channel-filter history valid */
+	float        *hist_cs[2];   /* [63][slots][2] LO (cos, sin) each of the last 63 input frames was mixed with */
+	int          *flags;        /* bit0: slot active (host-written only) */
 	int          *mode;         /* wr_mode, or -1 for an idle slot (what the post-DDC kernels test) */
 	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */
 	float        *taps2;        /* [64][slots] audio-filter taps */
@@ -50,7 +50,7 @@ struct WrTunerLaunch {
 	const float *hist;          /* last 63 IQ frames of the previous block (device) */
 	float       *hist_next;     /* receives the history for the next block */
 	int          parity;        /* which of the group's prev_iq / dem ping-pong buffers is current */
-	int          sp;            /* which state set (phase, hist_step, flags) this block reads */
+	int          sp;            /* which state set (phase, LO history) this block reads */
 	int          cb;            /* which chan_iq buffer this block writes */
 	size_t       nframes;
 	unsigned int d1, d2;
@@ -80,7 +80,6 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
                          int num_cus);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
-hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
                           const float *hist, float *hist_next);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,

@@ -28,7 +28,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 
 #define PHASE_FLAG_ACTIVE   1
-#define PHASE_FLAG_HISTORY  2
 
 /* ------------------------------------------------------------------------- */
 /* tier 1: one kernel per reference block                                     */
@@ -260,9 +259,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             float2 *__restrict__ hist_next, size_t nframes, size_t k1,
             unsigned int d1, unsigned int slots, unsigned int groups,
             const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-            const unsigned int *__restrict__ hist_step, const int *__restrict__ flags,
-            unsigned int *__restrict__ phase_next, unsigned int *__restrict__ hist_step_next,
-            int *__restrict__ flags_next,
+            const float2 *__restrict__ hist_cs, const int *__restrict__ flags,
+            unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next,
             const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs)
@@ -298,19 +296,35 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	}
 
 	/* End-of-block state of every channel, written to the OTHER state set so that no reader
-	 * of this launch is disturbed and the next block's launch depends on nothing but this
-	 * one: DownConverter::phase advances by nframes steps (downconverter.cxx:103), the step
-	 * in force is remembered (the next block's filter history was mixed with it), and the
-	 * channel filter now has a history. */
-	if (blockIdx.x == 0) {
+	 * of this launch is disturbed and the next block's launch depends on nothing but this one:
+	 *   - DownConverter::phase advances by nframes steps (downconverter.cxx:103);
+	 *   - the channel filter's history.  The reference keeps the last 63 MIXED frames per
+	 *     receiver (lowpass.cxx:138-142).  Here the raw frames are kept once per tuner and,
+	 *     per channel, the LO value (cos, sin) each of them was mixed with -- so the frames
+	 *     can be re-mixed bit-identically next block whatever happens to the phase step in
+	 *     between (setIF) and however short the blocks are.  A zero LO row = an empty
+	 *     history (a fresh LowPass::block). */
+	{
+		/* spread over the whole grid: 63 x slots LO evaluations are a few per workgroup */
 		const unsigned int nlo = (unsigned int)nframes;
-		for (unsigned int s = threadIdx.x; s < slots; s += blockDim.x) {
-			const int f = flags[s];
-			const unsigned int stp = step[s];
-			const bool act = (f & PHASE_FLAG_ACTIVE) != 0;
-			phase_next[s] = act ? phase[s] + nlo * stp : phase[s];
-			hist_step_next[s] = act ? stp : hist_step[s];
-			flags_next[s] = act ? (f | PHASE_FLAG_HISTORY) : f;
+		const unsigned int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+		for (unsigned int s = gtid; s < slots; s += gsz) {
+			const bool act = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
+			phase_next[s] = act ? phase[s] + nlo * step[s] : phase[s];
+		}
+		for (unsigned int e = gtid; e < WR_HIST * slots; e += gsz) {
+			const unsigned int r = e / slots, s = e - r * slots;
+			const size_t f = nframes + r;                 /* frame index in [hist | cur] */
+			v2f cs = {0.0f, 0.0f};
+			if (flags[s] & PHASE_FLAG_ACTIVE) {
+				if (f < WR_HIST) {
+					const float2 o = hist_cs[f * slots + s];
+					cs = (v2f){o.x, o.y};
+				} else {
+					cs = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
+				}
+			}
+			hist_cs_next[e] = make_float2(cs.x, cs.y);
 		}
 	}
 
@@ -327,7 +341,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	unsigned int loaded_g = 0xFFFFFFFFu;
 	float h[UTAPS ? 1 : WR_FIR_LENGTH];         /* per-lane taps (general case)          */
 	float hlane = 0.0f;                         /* UTAPS: lane j holds the tap of sample j */
-	unsigned int p0 = 0, st = 0, hst = 0;
+	unsigned int p0 = 0, st = 0;
 	int fl = 0;
 	unsigned int buf = 0;
 
@@ -364,7 +378,6 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			}
 			p0 = phase[s];
 			st = step[s];
-			hst = hist_step[s];
 			fl = flags[s];
 			loaded_g = g;
 		}
@@ -463,15 +476,18 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			}
 		} else {
 			/* window reaches into the previous block (only the first ceil(63/D1) frames of
-			 * a block): those frames were mixed with the phase sequence and the phase step
-			 * of that block.  Rare, so taps come straight from memory, not registers. */
+			 * a block): those frames get the LO values they were mixed with back then.
+			 * Rare, so taps come straight from memory, not registers. */
 			for (int j = 0; j < WR_FIR_LENGTH; ++j) {
 				const long long n = n0 + j;
-				const unsigned int P = p0 + (unsigned int)n * (n < 0 ? hst : st);
-				v2f xs = w[j];
-				if (n < 0 && !(fl & PHASE_FLAG_HISTORY))
-					xs = (v2f){0.0f, 0.0f};
-				const v2f cs = nco<NCO>(P, table, hi_l, lo_l);
+				const v2f xs = w[j];
+				v2f cs;
+				if (n < 0) {
+					const float2 o = hist_cs[(size_t)(WR_HIST + n) * slots + s];
+					cs = (v2f){o.x, o.y};
+				} else {
+					cs = nco<NCO>(p0 + (unsigned int)n * st, table, hi_l, lo_l);
+				}
 				if (UTAPS) {
 					/* the window is premultiplied; same operation order as the fast path, so a
 					 * frame gives the same bits wherever the block boundaries fall */
@@ -637,25 +653,6 @@ k_tuner_audio_direct(const float *__restrict__ dem, size_t k2, unsigned int d2, 
 	}
 }
 
-/* a block too short to produce a channel-rate frame still advances the NCO
- * (downconverter.cxx:103 runs per input frame) */
-__global__ void k_tuner_advance(unsigned int slots, unsigned int nframes_lo,
-                                const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-                                const unsigned int *__restrict__ hist_step, const int *__restrict__ flags,
-                                unsigned int *__restrict__ phase_next, unsigned int *__restrict__ hist_step_next,
-                                int *__restrict__ flags_next)
-{
-	unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= slots)
-		return;
-	const int f = flags[s];
-	const unsigned int stp = step[s];
-	const bool act = (f & PHASE_FLAG_ACTIVE) != 0;
-	phase_next[s] = act ? phase[s] + nframes_lo * stp : phase[s];
-	hist_step_next[s] = act ? stp : hist_step[s];
-	flags_next[s] = act ? (f | PHASE_FLAG_HISTORY) : f;
-}
-
 /* strided row gather: dst[r*width + i] = src[r*row_stride + col_offset + i] */
 __global__ void k_gather_rows(const float *__restrict__ src, size_t rows, size_t row_stride,
                               size_t col_offset, unsigned int width, float *__restrict__ dst)
@@ -747,8 +744,8 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
-		L.slots, L.slots_used / 64, G.phase[L.sp], G.step, G.hist_step[L.sp], G.flags[L.sp], G.phase[L.sp ^ 1],
-		G.hist_step[L.sp ^ 1], G.flags[L.sp ^ 1], G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
+		L.slots, L.slots_used / 64, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
+		(float2 *)G.hist_cs[L.sp ^ 1], G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev);
 	return hipGetLastError();
 }
@@ -757,10 +754,14 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
                          int num_cus)
 {
-	if (!L.k1 || !L.slots_used)
+	if (!L.slots_used)
 		return hipSuccess;
+	/* launched even for a block too short to yield a channel-rate frame: workgroup 0 still
+	 * advances the NCO (downconverter.cxx:103 runs per input frame) and rolls the histories */
 	const size_t units = L.k1 * (L.slots_used / 64);
 	unsigned int wgs = (unsigned int)((units + DDC_WAVES - 1) / DDC_WAVES);
+	if (wgs < 1)
+		wgs = 1;
 	if (L.nco_mode == WR_NCO_EXACT) {
 		/* small LDS footprint: two workgroups per CU hide the gather latency */
 		unsigned int cap = (unsigned int)num_cus * 2u;
@@ -819,16 +820,6 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
 	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
 	                                      G.taps2, G.mode, G.audio, L.k2max, L.audio_scale);
-	return hipGetLastError();
-}
-
-hipError_t wrk_tuner_advance(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
-{
-	if (!L.slots)
-		return hipSuccess;
-	k_tuner_advance<<<(L.slots + 255) / 256, 256, 0, st>>>(L.slots, (unsigned int)L.nframes, G.phase[L.sp], G.step,
-	                                                       G.hist_step[L.sp], G.flags[L.sp], G.phase[L.sp ^ 1],
-	                                                       G.hist_step[L.sp ^ 1], G.flags[L.sp ^ 1]);
 	return hipGetLastError();
 }
 
