@@ -76,3 +76,63 @@ def test_random_configuration(dev, oracle, seed):
         ph, _ = t.state(chans[c])
         assert ph == rxs[c].s.phase
     t.destroy()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_spectrum_streams(dev, oracle, seed):
+    """SpectrumSink: random size, hop and push chunking against the oracle (which is fed, for
+    hops below the frame size, the overlapped frames explicitly)."""
+    from webradio_amd.device import Spectrum
+    rng = np.random.default_rng(500 + seed)
+    n = int(2 ** rng.integers(3, 15))
+    hop = int(rng.choice([0, n, n // 2, max(1, n // 4), max(1, (3 * n) // 4)]))
+    total = int(n * 3 + rng.integers(0, 2 * n))
+    iq = synth.fm_stream(total, 2_400_000, [100_000, -450_000], amp=0.3, noise_dbfs=-45, seed=seed)
+    s = Spectrum(dev, n, hop)
+    eff = hop if hop else n
+    pos, frames = 0, 0
+    while pos < total:
+        chunk = int(min(total - pos, rng.integers(1, 2 * n)))
+        s.push_host(iq[2 * pos: 2 * (pos + chunk)])
+        pos += chunk
+        frames = 0 if pos < n else (pos - n) // eff + 1
+        assert s.frames_done() == frames
+        if frames:
+            start = (frames - 1) * eff
+            o = oracle.Spectrum(n)
+            o.process(iq[2 * start: 2 * (start + n)])
+            wb, wd = o.bins(), o.get()
+            peak = np.abs(wb[0::2] + 1j * wb[1::2]).max()
+            assert np.abs(s.get_bins() - wb).max() <= 2e-6 * peak
+            strong = wd >= wd.max() - 60.0
+            assert np.abs(s.get_db() - wd)[strong].max() <= 0.02
+    s.destroy()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_standalone_blocks(dev, oracle, seed):
+    """mix / fir / demod kernels with random geometry: bit-exact (FM within atan2f ulps)."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(1, 30_000))
+    iq = rng.uniform(-1, 1, 2 * n).astype(np.float32)
+    step = oracle.phase_step(int(rng.integers(-1_199_999, 1_199_999)), 2_400_000)
+    ph = int(rng.integers(0, 1 << 31))
+    want, pw = oracle.mix(oracle.sin_table(), ph, step, iq)
+    got, pg = dev.mix(iq, ph, step)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and pg == pw
+    ch, dec = int(rng.integers(1, 4)), int(rng.integers(1, 130))
+    coeff = oracle.lowpass_design(int(rng.integers(0, 1_000_000)), 2_400_000)
+    fir = oracle.Fir(ch, dec, coeff)
+    hist = dev.malloc(63 * ch * 4)
+    frames = int(rng.integers(1, 5000))
+    for _ in range(3):
+        x = rng.uniform(-1, 1, frames * ch).astype(np.float32)
+        assert np.array_equal(dev.fir_decimate(x, ch, dec, coeff, hist).view(np.uint32), fir.process(x).view(np.uint32))
+    dev.free(hist)
+    for mode in range(4):
+        w, _ = oracle.demod(mode, (0.25, -0.5), iq)
+        g, _ = dev.demod(mode, iq, (0.25, -0.5))
+        if mode == capi.WR_FM:
+            assert np.abs(g - w).max() <= FM_ATOL
+        else:
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
