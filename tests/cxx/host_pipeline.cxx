@@ -11,6 +11,9 @@
  */
 #include <string.h>
 
+#include <atomic>
+#include <thread>
+
 #include <vector>
 
 #include "radio.h"
@@ -265,6 +268,78 @@ int wr_host_run_file(const char *path, unsigned int rate, unsigned int block_fra
 	else
 		delete tuner;
 	return rc;
+}
+
+/* Control-plane stress (hard part H7): while the pipeline thread pumps Radio::run(), another
+ * thread hammers the setters the REST handlers call from libmicrohttpd's connection threads
+ * (receiverhandler.cxx:130-137): setIF, setPassband, setModeString.  The reference races here
+ * (SURVEY 3.3); this runtime stages them and applies them at block boundaries.  Returns the
+ * number of setter calls made, or < 0.  audio_out: [nrx][audio_cap] of the LAST block only. */
+long wr_host_setter_stress(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
+                           unsigned int nrx, unsigned int chan_rate, unsigned int audio_rate,
+                           float *audio_out, size_t audio_cap, size_t *audio_len)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	g_pos = 0;
+	FrontEnd *fe = new FrontEnd(makeTuner);
+	fe->tuner()->setSampleRate(rate);
+	fe->tuner()->setChannels(2);
+	fe->tuner()->setBlockSize(block_frames * 2);
+	std::vector<Receiver *> rx(nrx);
+	for (unsigned int n = 0; n < nrx; n++) {
+		rx[n] = new Receiver();
+		rx[n]->channelFilter()->setOutputSampleRate(chan_rate);
+		rx[n]->audioFilter()->setOutputSampleRate(audio_rate);
+		rx[n]->channelFilter()->setPassband(rate / 16);
+		rx[n]->audioFilter()->setPassband(chan_rate / 8);
+		rx[n]->stream()->setCapacity(audio_cap);
+		rx[n]->setFrontEnd(fe);
+	}
+	if (!fe->tuner()->start())
+		return -1;
+	std::atomic<bool> quit(false);
+	std::atomic<long> calls(0);
+	std::thread ctl([&]() {
+		unsigned int lcg = 1;
+		const char *modes[] = { "AM", "FM", "USB", "LSB" };
+		while (!quit.load()) {
+			lcg = lcg * 1664525u + 1013904223u;
+			Receiver *r = rx[(lcg >> 8) % nrx];
+			switch ((lcg >> 4) & 3) {
+			case 0: r->downconverter()->setIF((int)((lcg >> 10) % rate) - (int)(rate / 2)); break;
+			case 1: r->channelFilter()->setPassband(rate / (8 + ((lcg >> 12) & 31))); break;
+			case 2: r->demodulator()->setModeString(modes[(lcg >> 14) & 3]); break;
+			default: r->audioFilter()->setPassband(chan_rate / (4 + ((lcg >> 16) & 15))); break;
+			}
+			calls++;
+		}
+	});
+	long rc = 0;
+	size_t blocks = nframes / block_frames;
+	for (size_t b = 0; b < blocks; b++)
+		Radio::run();
+	quit.store(true);
+	ctl.join();
+	/* one quiet block after the storm: its audio must be what the final settings give */
+	g_pos = 0;
+	for (unsigned int n = 0; n < nrx; n++)
+		rx[n]->stream()->clear();
+	Radio::run();
+	size_t len = rx[0]->stream()->samples().size();
+	for (unsigned int n = 0; n < nrx && rc == 0; n++) {
+		const vector<float> &a = rx[n]->stream()->samples();
+		if (a.size() != len || len > audio_cap)
+			rc = -2;
+		else
+			memcpy(audio_out + (size_t)n * audio_cap, a.data(), len * sizeof(float));
+	}
+	*audio_len = len;
+	fe->tuner()->stop();
+	for (unsigned int n = 0; n < nrx; n++)
+		delete rx[n];
+	delete fe;
+	return rc ? rc : calls.load();
 }
 
 int wr_host_registry_sizes(void)

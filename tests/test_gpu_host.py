@@ -218,3 +218,37 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
         assert int(r["rc"]) == 0 and int(r["left"]) == 0
         assert r["audio"].size == g["audio"].size
         assert np.abs(r["audio"] - g["audio"]).max() <= tol
+
+
+STRESS_RUNNER = r'''
+import ctypes as C, sys, numpy as np
+lib, npz, out = sys.argv[1], sys.argv[2], sys.argv[3]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz); iq = np.ascontiguousarray(d["iq"], np.float32); p = d["params"]
+fp = C.POINTER(C.c_float)
+L.wr_host_setter_stress.restype = C.c_long
+L.wr_host_setter_stress.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, fp, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]
+nrx, cap = int(p[2]), 4096
+audio = np.zeros((nrx, cap), np.float32); n = C.c_size_t()
+calls = L.wr_host_setter_stress(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), nrx, int(p[3]), int(p[4]),
+                                audio.ctypes.data_as(fp), cap, C.byref(n))
+np.savez(out, calls=calls, audio=audio[:, :n.value], left=L.wr_host_registry_sizes())
+'''
+
+
+def test_setters_from_another_thread_while_running(tmp_path):
+    """H7: the REST handlers call setIF/setPassband/setModeString from other threads while the
+    pipeline runs (receiverhandler.cxx:130-137); nothing may crash, hang or produce non-finite
+    audio, and the setters must actually have been interleaved with the blocks."""
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    rate, block = CFG["rate"], CFG["block"]
+    iq = synth.fm_stream(30 * block, rate, [50_000, -75_000], amp=0.3)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, iq=iq, params=np.array([rate, block, 12, CFG["crate"], CFG["arate"]], np.int64))
+    subprocess.check_call([sys.executable, "-c", STRESS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
+                          timeout=300)
+    r = np.load(out)
+    assert int(r["calls"]) > 1000 and int(r["left"]) == 0
+    assert r["audio"].shape == (12, block // 2000) and np.isfinite(r["audio"]).all()
