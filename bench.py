@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=256)
-    ap.add_argument("--nco", choices=["split", "exact"], default="split")
+    ap.add_argument("--nco", choices=["rotate", "split", "exact"], default="rotate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2)
     ap.add_argument("--profile-stride", type=int, default=4,
@@ -93,7 +93,7 @@ def main():
     x = synth.fm_stream_torch(n, cfg["input_rate"], ifs[::4], "cuda", seed=12345 + rank)
     stream = torch.cuda.current_stream().cuda_stream
     dev = Device(device_index, stream)
-    nco = capi.WR_NCO_SPLIT if args.nco == "split" else capi.WR_NCO_EXACT
+    nco = {"rotate": capi.WR_NCO_ROTATE, "split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT}[args.nco]
     tuner = Tuner(dev, cfg["input_rate"], args.channels, n, nco)
     for f in ifs:
         tuner.add_receiver(f, cfg["chan_passband"], cfg["chan_rate"], capi.WR_FM, cfg["audio_passband"],
@@ -137,7 +137,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.channels == 256 and args.nco == "split":
+            if args.channels == 256 and args.nco == tj.get("nco", "split"):
                 traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None

@@ -68,9 +68,14 @@ enum wr_nco {
 	WR_NCO_SPLIT = 0,        /* default: exact integer phase, sin/cos from two 256-entry
 	                            LDS tables (coarse x fine angle addition); LO within
 	                            3.5e-7 of the reference table entry */
-	WR_NCO_EXACT = 1         /* the reference's own 65536-entry sinf table, gathered from
+	WR_NCO_EXACT = 1,        /* the reference's own 65536-entry sinf table, gathered from
 	                            global memory, unfused multiply/add in the reference's
 	                            order: channel-filter output is bit-identical */
+	WR_NCO_ROTATE = 2        /* the same table index sequence as the reference (exact integer
+	                            phase), but each LO value is reached by turning the previous
+	                            one by one of the two table angles the step allows, folded
+	                            into the FIR as a Horner recurrence: no table access per tap.
+	                            Channel IQ within 4e-6 relative of the reference */
 };
 
 enum wr_where { WR_HOST = 0, WR_DEVICE = 1 };
@@ -172,7 +177,9 @@ int wr_chan_set_mode(wr_tuner *tuner, int chan, int mode);
 int wr_tuner_keep_stages(wr_tuner *tuner, unsigned int stage_mask);
 
 /* streaming state of one channel: DownConverter::phase (downconverter.h:58),
- * Demodulator::prev_i/q (demodulator.h:60-61) */
+ * Demodulator::prev_i/q (demodulator.h:60-61).  (The reference never sets the phase from
+ * outside; under WR_NCO_ROTATE doing so also empties the channel filter's history, because
+ * that mode keeps the NCO's turn into the next frame rather than its value.) */
 int wr_chan_get_state(wr_tuner *tuner, int chan, unsigned int *phase, float *prev_iq /* [2] */);
 int wr_chan_set_state(wr_tuner *tuner, int chan, unsigned int phase, const float *prev_iq);
 

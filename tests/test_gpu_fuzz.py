@@ -23,7 +23,7 @@ def test_random_configuration(dev, oracle, seed):
     fs, crate, arate = RATES[seed % len(RATES)]
     d1, d2 = fs // crate, crate // arate
     nchan = int(rng.choice([1, 2, 5, 33, 64, 70]))
-    nco = capi.WR_NCO_EXACT if seed % 2 == 0 else capi.WR_NCO_SPLIT
+    nco = (capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE)[seed % 3]
     base = d1 * d2
     block = int(rng.choice([base * 3, base * 7 + int(rng.integers(0, base)), 4096, 10_000]))
     block = max(block, 1)

@@ -29,7 +29,7 @@ def _sequential(dev, nco):
     return a
 
 
-@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT])
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
 def test_time_shard_single_rank_bit_identical(dev, nco):
     iq = _stream()
     shard = timeshard.TunerShard(dev, FS, IFS, 128_000, 5_000, capi.WR_FM, 160, 1_000, T + timeshard.halo_frames(D1, D2), nco)

@@ -80,9 +80,10 @@ def test_exact_mode_bit_exact_iq(dev, oracle):
         assert gph == oph and gprev[0] == opi and gprev[1] == opq
 
 
-def test_split_mode_within_tolerance(dev, oracle):
+@pytest.mark.parametrize("nco", [capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
+def test_fast_nco_modes_within_tolerance(dev, oracle, nco):
     cfg = _mini_c2(64)
-    results, states, car = _run_both(dev, oracle, capi.WR_NCO_SPLIT, cfg, [capi.WR_FM, capi.WR_AM], [80_000, 80_000])
+    results, states, car = _run_both(dev, oracle, nco, cfg, [capi.WR_FM, capi.WR_AM], [80_000, 80_000])
     worst_iq = 0.0
     for blk in results:
         for c, ((wa, wc, wd), (ga, gc, gd)) in enumerate(blk):
@@ -102,7 +103,7 @@ def test_c1_single_receiver_u8_file(dev, oracle):
     c1 = synth.C1
     n = int(g["block_frames"])
     iq = oracle.u8_to_float(g["u8"])
-    for nco, exact in ((capi.WR_NCO_EXACT, True), (capi.WR_NCO_SPLIT, False)):
+    for nco, exact in ((capi.WR_NCO_EXACT, True), (capi.WR_NCO_SPLIT, False), (capi.WR_NCO_ROTATE, False)):
         t = Tuner(dev, c1["input_rate"], 1, n, nco)
         ch = t.add_receiver(c1["if_hz"], c1["chan_passband"], c1["chan_rate"], capi.WR_FM,
                             c1["audio_passband"], c1["audio_rate"])
@@ -121,7 +122,7 @@ def test_c1_single_receiver_u8_file(dev, oracle):
             assert np.abs(audio - g["audio"]).max() <= AUDIO_ATOL
 
 
-@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT])
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
 def test_block_split_invariance(dev, nco):
     """Size-independent property: a stream cut into different block sizes (multiples of
     D1*D2) gives bit-identical output -- the 63-frame history, the closed-form phase and
@@ -232,7 +233,7 @@ def test_errors(dev):
     t.destroy()
 
 
-@pytest.mark.parametrize("nco", [capi.WR_NCO_SPLIT])
+@pytest.mark.parametrize("nco", [capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
 def test_c2_full_size_properties(dev, oracle, nco):
     """BASELINE config 2 at full size (256 channels, 4 M-frame block off 100 Msps), input
     generated on the device.  The CPU oracle needs minutes for this, so:
@@ -275,7 +276,7 @@ def test_c2_full_size_properties(dev, oracle, nco):
         assert np.abs(outs[nco][c][1][: wa.size] - wa).max() <= AUDIO_ATOL
 
 
-@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT])
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
 def test_u8_ingest_equals_converting_first(dev, oracle, nco):
     """SURVEY 8f-1: the RTL-SDR byte format goes straight into the DDC kernel's load stage;
     the (u8 - 128)/128 rule of rtlsdrtuner.cxx:106 is exact in float, so the result is
@@ -312,7 +313,7 @@ def test_u8_ingest_equals_converting_first(dev, oracle, nco):
             assert np.array_equal(outs[1][b][0][0].view(np.uint32), wc.view(np.uint32))
 
 
-@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT])
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
 def test_mixed_passbands_within_one_lane_group(dev, oracle, nco):
     """Receivers of one tuner with DIFFERENT channel/audio passbands (setPassband per receiver,
     receiverhandler.cxx:133-134): same rates -> same rate group, but the taps differ per lane,

@@ -8,7 +8,7 @@ from webradio_amd.device import Device, Tuner
 c2 = synth.C2
 fs, n = c2["input_rate"], c2["block_frames"]
 nch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-modes = {"split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT}
+modes = {"split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT, "rotate": capi.WR_NCO_ROTATE}
 which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["split", "exact"]
 ifs = synth.c2_ifs(nch)
 stream = torch.cuda.current_stream().cuda_stream
@@ -17,12 +17,14 @@ x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
 torch.cuda.synchronize()
 for name in which:
     t = Tuner(dev, fs, nch, n, modes[name])
-    for f in ifs:
-        t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
-    for _ in range(2):
+    mixed = os.environ.get("QT_MIXED") == "1"     # per-lane taps: a different passband per channel
+    for i, f in enumerate(ifs):
+        t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0), c2["chan_rate"], capi.WR_FM,
+                       c2["audio_passband"], c2["audio_rate"])
+    for _ in range(4):
         t.submit_device(x, n)
     torch.cuda.synchronize()
-    reps = 10 if name == "split" else 3
+    reps = 3 if name == "exact" else 20
     t.profile(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

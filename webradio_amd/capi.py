@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwebradio_amd.so")
 WR_OK, WR_ERR_ARG, WR_ERR_HIP, WR_ERR_STATE, WR_ERR_NOMEM, WR_ERR_NODEV, WR_ERR_RATE = range(7)
 WR_AM, WR_FM, WR_USB, WR_LSB = range(4)
 WR_STAGE_CHAN_IQ, WR_STAGE_DEMOD, WR_STAGE_AUDIO = 1, 2, 3
-WR_NCO_SPLIT, WR_NCO_EXACT = 0, 1
+WR_NCO_SPLIT, WR_NCO_EXACT, WR_NCO_ROTATE = 0, 1, 2
 WR_HOST, WR_DEVICE = 0, 1
 WR_FIR_LENGTH = 64
 WR_TABLE_SIZE = 65536

@@ -412,6 +412,8 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.step);
 	(void)hipFree(g->dev.hist_cs[0]);
 	(void)hipFree(g->dev.hist_cs[1]);
+	(void)hipFree(g->dev.hist_lo[0]);
+	(void)hipFree(g->dev.hist_lo[1]);
 	(void)hipFree(g->dev.flags);
 	(void)hipFree(g->dev.mode);
 	(void)hipFree(g->dev.taps1);
@@ -461,6 +463,8 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.step, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.hist_cs[0], (size_t)WR_HIST * S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.hist_cs[1], (size_t)WR_HIST * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_lo[0], (size_t)WR_HIST * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.hist_lo[1], (size_t)WR_HIST * S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.flags, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
@@ -488,7 +492,7 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 {
 	if (!tuner || !dev || !input_rate || !max_channels || !max_block_frames)
 		return fail(WR_ERR_ARG, "wr_tuner_create: bad argument");
-	if (nco_mode != WR_NCO_SPLIT && nco_mode != WR_NCO_EXACT)
+	if (nco_mode != WR_NCO_SPLIT && nco_mode != WR_NCO_EXACT && nco_mode != WR_NCO_ROTATE)
 		return fail(WR_ERR_ARG, "wr_tuner_create: bad nco_mode %d", nco_mode);
 	*tuner = nullptr;
 	if (dev_bind(dev))
@@ -922,6 +926,10 @@ static int group_upload(wr_tuner *t, Group *g)
 		if (c.phase_dirty) {
 			HIP_TRY(hipMemcpyAsync(g->dev.phase[g->sp] + s, &c.phaseL, sizeof(unsigned int), hipMemcpyHostToDevice, st));
 			c.phase_dirty = false;
+			/* ROTATE keeps the turn INTO the next frame; a phase set from outside breaks that
+			 * chain, so the channel filter starts from an empty history (see wr_chan_set_state) */
+			if (t->nco_mode == WR_NCO_ROTATE)
+				c.cs_hist_reset = true;
 		}
 		if (c.prev_dirty) {
 			HIP_TRY(hipMemcpyAsync(g->dev.prev_iq[g->parity] + 2 * s, c.prev_iq, 2 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -930,6 +938,8 @@ static int group_upload(wr_tuner *t, Group *g)
 		if (c.cs_hist_reset) {
 			/* 63 LO rows of this slot: one float2 per row, stride S float2 */
 			HIP_TRY(hipMemset2DAsync(g->dev.hist_cs[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
+			                         WR_HIST, st));
+			HIP_TRY(hipMemset2DAsync(g->dev.hist_lo[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
 			                         WR_HIST, st));
 			c.cs_hist_reset = false;
 		}

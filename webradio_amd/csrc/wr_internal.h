@@ -32,7 +32,9 @@ struct WrGroupDev {
 	 * `sp ^ 1`, so consecutive blocks' DDC launches depend only on each other */
 	unsigned int *phase[2];     /* left-aligned phase at block start: DownConverter::phase << 1 */
 	unsigned int *step;         /* phaseStep << 1 (two's complement) for this block */
-	float        *hist_cs[2];   /* [63][slots][2] LO (cos, sin) each of the last 63 input frames was mixed with */
+	float        *hist_cs[2];   /* [63][slots][2] LO (cos, sin) each of the last 63 input frames was mixed with;
+	                               WR_NCO_ROTATE: the TURN (cos, sin) into frame r - 62 of the next block */
+	float        *hist_lo[2];   /* WR_NCO_ROTATE only: [63][slots][2] the LO values (segment anchors) */
 	int          *flags;        /* bit0: slot active (host-written only) */
 	int          *mode;         /* wr_mode, or -1 for an idle slot (what the post-DDC kernels test) */
 	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */

@@ -162,8 +162,13 @@ __device__ __forceinline__ v2f nco(unsigned int P, const float *__restrict__ tab
 		cs.x = table[(P + 0x40000000u) >> 16];
 		return cs;
 	} else {
-		const v2f a = hi_l[(P >> 24) << 5];              /* cis(2*pi*coarse/256) */
-		const v2f b = lo_l[((P >> 16) & 255u) << 5];      /* cis(2*pi*fine/65536) */
+		/* SPLIT: 32 interleaved copies of each table (see k_tuner_ddc); ROTATE looks the LO up
+		 * only a few times per output frame and keeps one copy (a 64-lane gather from the
+		 * global table costs the CU's L1 about a cycle per lane, an LDS gather a few cycles
+		 * in all) */
+		constexpr unsigned int SH = (NCO == WR_NCO_SPLIT) ? 5u : 0u;
+		const v2f a = hi_l[(P >> 24) << SH];              /* cis(2*pi*coarse/256) */
+		const v2f b = lo_l[((P >> 16) & 255u) << SH];      /* cis(2*pi*fine/65536) */
 		/* (ax + i ay)(bx + i by) as two packed ops */
 		const v2f rot = {-a.y, a.x};
 		return __builtin_elementwise_fma(rot, b.yy, a * b.xx);
@@ -193,6 +198,68 @@ __device__ __forceinline__ void mac(v2f xs, v2f cs, float hj, v2f &acc)
 		asm("v_fmac_f32 %0, %1, %2" : "+v"(acc.y) : "v"(hj), "v"(m.y));
 	}
 }
+
+/* ROTATE NCO.  The reference's LO index advances by S = step >> 16 table entries per input
+ * frame, plus one whenever the 16 fraction bits of the left-aligned phase carry
+ * (downconverter.cxx:100-103: index = phase >> 15, phase += phase_step).  So the LO of frame m
+ * is the LO of frame m-1 turned by one of just two angles, rot[0] = cis(2 pi S / 65536) or
+ * rot[1] = cis(2 pi (S+1) / 65536) -- both taken from the reference's own table -- and
+ *
+ *     sum_m u[m] conj(LO[m])  =  conj(LO[n]) * ( ... ((u[n-63] r[n-62] + u[n-62]) r[n-61] + ...) r[n] + u[n] )
+ *
+ * with r[m] the turn INTO frame m: a Horner recurrence of one integer add-with-carry, two
+ * selects and four FMAs per tap, no table access at all.  Which table entry every frame is
+ * mixed with is exactly the reference's; only float rounding differs: a product of turns
+ * stands where the reference has one table entry, and the rounding of the turn itself
+ * (|r| - 1 up to 4e-8) compounds along the chain.  To bound that, the 64 taps are cut into
+ * ROT_Q segments of ROT_SEG taps, each its own recurrence closed with the table's LO value of
+ * its last frame: at most ROT_SEG - 1 turns between a frame and its anchor (measured: within
+ * 5e-7 absolute of the bit-exact path on +/-0.4 signals), and ROT_Q independent chains.
+ *
+ * rot_index(): table index of the turn into frame m >= 1 of the current block, for phase p0
+ * at frame 0. */
+__device__ __forceinline__ unsigned int rot_index(unsigned int p0, unsigned int st, unsigned int m)
+{
+	const unsigned int P = p0 + m * st;
+	return (st >> 16) + (((P & 0xFFFFu) < (st & 0xFFFFu)) ? 1u : 0u);
+}
+
+__device__ __forceinline__ v2f rot_into(unsigned int p0, unsigned int st, unsigned int m,
+                                        const float *__restrict__ table)
+{
+	const unsigned int idx = rot_index(p0, st, m);
+	v2f r;
+	r.y = table[idx & 0xFFFFu];
+	r.x = table[(idx + 16384u) & 0xFFFFu];
+	return r;
+}
+
+/* one Horner step A := A * r + u, and the closing multiplication by conj(LO); spelled once so
+ * that the fast and the block-boundary path round identically */
+__device__ __forceinline__ void horner_step(v2f &A, float rc, float rs, v2f u)
+{
+	const float tr = __builtin_fmaf(-A.y, rs, u.x);
+	const float ti = __builtin_fmaf(A.x, rs, u.y);
+	const float ar = __builtin_fmaf(A.x, rc, tr);
+	const float ai = __builtin_fmaf(A.y, rc, ti);
+	A.x = ar;
+	A.y = ai;
+}
+
+/* y += A * conj(LO) */
+__device__ __forceinline__ void horner_close(v2f &y, v2f A, v2f cs)
+{
+	const float yr = __builtin_fmaf(A.y, cs.y, __builtin_fmaf(A.x, cs.x, y.x));
+	const float yi = __builtin_fmaf(-A.x, cs.y, __builtin_fmaf(A.y, cs.x, y.y));
+	y.x = yr;
+	y.y = yi;
+}
+
+#ifndef ROT_SEG
+#define ROT_SEG 16
+#endif
+#define ROT_Q   (WR_FIR_LENGTH / ROT_SEG)
+#define SLOW_CH (UTAPS ? 8 : 4)           /* taps per memory round of the block-boundary paths */
 
 /* SPLIT NCO: issue the two LDS gathers for left-aligned phase P.  LDS byte address =
  * table base | index << 8 | (lane & 31) << 3; the index byte of P is dropped straight
@@ -249,11 +316,16 @@ __device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, co
 /* LDS plan of k_tuner_ddc: [0, 128 KiB) the two replicated NCO tables (SPLIT only),
  * then one private 2 x 512 B sample window per wave (double buffered across units). */
 #define DDC_TABLE_BYTES   (2u * WR_SPLIT_N * 32u * 8u)
+#ifndef DDC_WAVES
 #define DDC_WAVES         16u
+#endif
+#ifndef DDC_ROTATE_WGS_PER_CU
+#define DDC_ROTATE_WGS_PER_CU 1u
+#endif
 #define DDC_LDS_BYTES     (DDC_TABLE_BYTES + DDC_WAVES * 2u * 512u)
 
 template <int NCO, bool UTAPS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && UTAPS ? DDC_ROTATE_WGS_PER_CU * DDC_WAVES / 4u : DDC_WAVES / 4u)))
 k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist,
             float2 *__restrict__ hist_next, size_t nframes, size_t k1,
@@ -261,6 +333,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
             const float2 *__restrict__ hist_cs, const int *__restrict__ flags,
             unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next,
+            const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
             const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs)
@@ -277,15 +350,23 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			lds[WR_SPLIT_N * 32u + e] = (v2f){lv.x, lv.y};
 		}
 		__syncthreads();
+	} else if (NCO == WR_NCO_ROTATE) {
+		for (unsigned int e = threadIdx.x; e < WR_SPLIT_N; e += blockDim.x) {
+			const float2 hv = hi_cs[e], lv = lo_cs[e];
+			lds[e] = (v2f){hv.x, hv.y};
+			lds[WR_SPLIT_N + e] = (v2f){lv.x, lv.y};
+		}
+		__syncthreads();
 	}
-	const v2f *hi_l = lds + (lane & 31u);
-	const v2f *lo_l = lds + WR_SPLIT_N * 32u + (lane & 31u);
+	const v2f *hi_l = (NCO == WR_NCO_ROTATE) ? lds : lds + (lane & 31u);
+	const v2f *lo_l = (NCO == WR_NCO_ROTATE) ? lds + WR_SPLIT_N : lds + WR_SPLIT_N * 32u + (lane & 31u);
 	/* the same two bases as LDS byte addresses (the dynamic LDS block starts at 0: it is
 	 * the kernel's only LDS, so byte 1 of both is free for the table index) */
 	const unsigned int a_hi = (unsigned int)(uintptr_t)hi_l;
 	const unsigned int a_lo = (unsigned int)(uintptr_t)lo_l;
 	/* this wave's sample windows: 64 x float2 each, [buffer][tap] */
-	v2f *win = lds + (NCO == WR_NCO_SPLIT ? DDC_TABLE_BYTES / 8u : 0u) + wave * 128u;
+	v2f *win = lds + (NCO == WR_NCO_SPLIT ? DDC_TABLE_BYTES / 8u : NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N : 0u)
+	           + wave * 128u;
 
 	/* the tuner's next input history = last 63 frames of [hist | cur] (lowpass.cxx:138-142
 	 * keeps them per LowPass; here once per tuner).  It goes to the OTHER history buffer,
@@ -316,10 +397,30 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			const unsigned int r = e / slots, s = e - r * slots;
 			const size_t f = nframes + r;                 /* frame index in [hist | cur] */
 			v2f cs = {0.0f, 0.0f};
+			if (NCO == WR_NCO_ROTATE) {
+				/* ROTATE also keeps the LO values themselves: the segment anchors */
+				v2f lo = {0.0f, 0.0f};
+				if (flags[s] & PHASE_FLAG_ACTIVE) {
+					if (f < WR_HIST) {
+						const float2 o = hist_lo[f * slots + s];
+						lo = (v2f){o.x, o.y};
+					} else {
+						lo = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
+					}
+				}
+				hist_lo_next[e] = make_float2(lo.x, lo.y);
+			}
 			if (flags[s] & PHASE_FLAG_ACTIVE) {
 				if (f < WR_HIST) {
 					const float2 o = hist_cs[f * slots + s];
 					cs = (v2f){o.x, o.y};
+				} else if (NCO == WR_NCO_ROTATE) {
+					/* ROTATE keeps turns, not LO values: row r = the turn into frame r - 62 of the
+					 * next block, i.e. into frame f - 62 >= 1 of this one.  (Row 62 is the turn
+					 * into the next block's first frame: made with THIS block's step, as the
+					 * reference adds phase_step right after using a frame.)  A zero row = nothing
+					 * before that frame counts, which is also how a fresh channel starts. */
+					cs = rot_into(phase[s], step[s], (unsigned int)(f - (WR_HIST - 1)), table);
 				} else {
 					cs = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
 				}
@@ -328,22 +429,27 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		}
 	}
 
-	/* Units (g, k) are dealt g-major, round-robin over the waves of the grid: a wave walks
-	 * u = first, first + stride, ... where u = g*k1 + k.  (g, k) is carried incrementally:
-	 * a 64-bit division per unit would cost as much as eight taps. */
+	/* Units (g, k) are dealt so that a wave keeps ONE lane group for its whole life: wave w of
+	 * the grid takes g = w mod groups and walks k = w / groups, + waves_per_group, ...  Its
+	 * per-channel state (phase, step, taps, turns) is loaded once, before the loop -- a
+	 * reload costs two dependent memory latencies, and with a plain round-robin over all
+	 * units it came every few units.  Waves with the same k (neighbours in a workgroup) read
+	 * the same window at about the same time: one HBM read, the rest L1/L2 hits. */
 	const unsigned int k1u = (unsigned int)k1;
-	const unsigned int stride = gridDim.x * waves_per_wg;
-	const unsigned int first = blockIdx.x * waves_per_wg + wave;
-	const unsigned int stride_g = stride / k1u, stride_k = stride % k1u;
-	unsigned int g = first / k1u, k = first % k1u;
+	const unsigned int nwaves = gridDim.x * waves_per_wg;
+	const unsigned int wid = blockIdx.x * waves_per_wg + wave;
+	const unsigned int wpg = nwaves / groups;            /* >= 1: the launcher sees to it */
+	const unsigned int g = wid % groups;
+	unsigned int k = wid / groups;
+	if (k >= wpg)
+		k = k1u;                                         /* the few waves left over stay idle */
 
-	/* a wave keeps to one lane group where it can, so its per-channel state stays put */
-	unsigned int loaded_g = 0xFFFFFFFFu;
 	float h[UTAPS ? 1 : WR_FIR_LENGTH];         /* per-lane taps (general case)          */
 	float hlane = 0.0f;                         /* UTAPS: lane j holds the tap of sample j */
 	unsigned int p0 = 0, st = 0;
 	int fl = 0;
 	unsigned int buf = 0;
+	v2f rot0 = {1.0f, 0.0f}, rot1 = {1.0f, 0.0f};   /* ROTATE: the two possible turns per frame */
 
 	/* sample `lane` of the window of unit (gg, kk) (frame index n0 + lane): from the current
 	 * block, or from the previous block's last 63 frames.  (The tuner's history buffer starts
@@ -356,18 +462,11 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	/* the window of the NEXT unit is fetched while this one is computed: its global-load
 	 * latency would otherwise sit in front of every unit */
 	float2 xnext = make_float2(0.0f, 0.0f);
-	if (g < groups)
+	if (k < k1u)
 		xnext = window_sample(k);
-
-	for (; g < groups; buf ^= 1u) {
-		const unsigned int s = g * 64u + lane;
-		/* the unit after this one */
-		unsigned int gn = g + stride_g, kn = k + stride_k;
-		if (kn >= k1u) {
-			kn -= k1u;
-			++gn;
-		}
-		if (g != loaded_g) {
+	const unsigned int s = g * 64u + lane;
+	if (k < k1u) {
+		{
 			if (UTAPS) {
 				/* every slot of the group carries the same taps (host guarantee) */
 				hlane = taps1[(size_t)(WR_FIR_LENGTH - 1 - lane) * slots + g * 64u];
@@ -379,8 +478,16 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			p0 = phase[s];
 			st = step[s];
 			fl = flags[s];
-			loaded_g = g;
+			if (NCO == WR_NCO_ROTATE) {
+				const unsigned int S = st >> 16;
+				rot0 = (v2f){table[(S + 16384u) & 0xFFFFu], table[S]};
+				rot1 = (v2f){table[(S + 16385u) & 0xFFFFu], table[(S + 1u) & 0xFFFFu]};
+			}
 		}
+	}
+
+	for (; k < k1u; buf ^= 1u) {
+		const unsigned int kn = k + wpg;              /* the unit after this one */
 
 		/* ---- the window: sample j of this output frame goes to lane j, then to LDS.
 		 * Every lane needs every sample; a tap reads its sample back with a broadcast
@@ -389,15 +496,25 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		 * order), no 64-lane vector broadcast loads (8 B x 64 lanes of return bandwidth
 		 * per tap). */
 		const long long n0 = (long long)k * d1 - WR_HIST;   /* input frame of tap j = 0 */
+		/* Order matters for the wait counters: (1) the window fetched during the previous unit
+		 * is consumed, (2) ROTATE's segment anchors are looked up, (3) the next unit's window
+		 * prefetch goes out last -- so that waiting for the anchors never waits for it. */
 		{
 			const float2 xf = xnext;
-			if (gn < groups)
-				xnext = window_sample(kn);
 			if (UTAPS)
 				win[buf * 64u + lane] = (v2f){hlane * xf.x, hlane * xf.y};
 			else
 				win[buf * 64u + lane] = (v2f){xf.x, xf.y};
 		}
+		v2f csq[ROT_Q];
+		if (NCO == WR_NCO_ROTATE && n0 >= 0) {
+			const unsigned int P0 = p0 + (unsigned int)n0 * st;
+#pragma unroll
+			for (int q = 0; q < ROT_Q; ++q)
+				csq[q] = nco<NCO>(P0 + (unsigned int)(q * ROT_SEG + ROT_SEG - 1) * st, table, hi_l, lo_l);
+		}
+		if (kn < k1u)
+			xnext = window_sample(kn);
 		const lds_v2f *w = (const lds_v2f *)(win + buf * 64u);
 		v2f acc = {0.0f, 0.0f};
 
@@ -459,6 +576,90 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 					}
 				}
 			}
+		} else if (n0 >= 0 && NCO == WR_NCO_ROTATE) {
+			const unsigned int P0 = p0 + (unsigned int)n0 * st;
+			unsigned int F = P0 << 16;                /* the 16 fraction bits, left-aligned */
+			const unsigned int fstep = st << 16;
+			const lds_v4f *w4 = (const lds_v4f *)(win + buf * 64u);
+			v2f A = {0.0f, 0.0f}, Aq[ROT_Q];
+#pragma unroll
+			for (int jp = 0; jp < WR_FIR_LENGTH / 2; ++jp) {
+				const v4f x2 = w4[jp];
+#pragma unroll
+				for (int jj = 0; jj < 2; ++jj) {
+					const int j = 2 * jp + jj;
+					v2f u = jj ? (v2f){x2.z, x2.w} : (v2f){x2.x, x2.y};
+					if (!UTAPS) {
+						const float hj = h[UTAPS ? 0 : WR_FIR_LENGTH - 1 - j];
+						u = u * hj;
+					}
+					if (j % ROT_SEG == 0) {
+						if (j)
+							F += fstep;                 /* a segment starts afresh: no turn */
+						A = u;
+					} else {
+						unsigned int F2;
+						const bool carry = __builtin_uadd_overflow(F, fstep, &F2);
+						F = F2;
+						horner_step(A, carry ? rot1.x : rot0.x, carry ? rot1.y : rot0.y, u);
+					}
+					if (j % ROT_SEG == ROT_SEG - 1)
+						Aq[j / ROT_SEG] = A;
+				}
+			}
+			/* closed at the end, in segment order: nothing in the tap loop waits for memory */
+#pragma unroll
+			for (int q = 0; q < ROT_Q; ++q)
+				horner_close(acc, Aq[q], csq[q]);
+		} else if (NCO == WR_NCO_ROTATE) {
+			/* window reaches into the previous block: the turns into frames <= 0 and the LO of
+			 * anchors < 0 are the ones kept from back then (whatever the step was), the rest
+			 * follow from the phase.  Same steps in the same order as above, so a frame's bits
+			 * do not depend on where the block boundaries fall.
+			 * Only the first ceil(63/D1) frames of a block come here, but the wave that gets one
+			 * still has its share of ordinary units to do, so this path is on the kernel's
+			 * critical path: everything it needs from memory is fetched SLOW_CH taps at a time,
+			 * branch-free, before the arithmetic (one memory latency per chunk, not per tap). */
+			v2f A = {0.0f, 0.0f};
+			const float *hc = (const float *)hist_cs;
+#pragma clang loop unroll(disable)
+			for (int jb = 0; jb < WR_FIR_LENGTH; jb += SLOW_CH) {
+				v2f r[SLOW_CH];
+				float hj[UTAPS ? 1 : SLOW_CH];
+#pragma unroll
+				for (int jj = 0; jj < SLOW_CH; ++jj) {
+					const int j = jb + jj;
+					const long long n = n0 + j;
+					if (!UTAPS)
+						hj[UTAPS ? 0 : jj] = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
+					/* (the turn into a segment's first frame is fetched too, and not used) */
+					const unsigned int idx = rot_index(p0, st, (unsigned int)n);
+					const bool old = n <= 0;                         /* wave-uniform */
+					const size_t row = old ? (size_t)(WR_HIST - 1 + (n < -(long long)(WR_HIST - 1) ? -(long long)(WR_HIST - 1) : n)) : 0;
+					const float *pc = old ? hc + 2 * (row * slots + s) : table + ((idx + 16384u) & 0xFFFFu);
+					const float *ps = old ? pc + 1 : table + (idx & 0xFFFFu);
+					r[jj] = (v2f){*pc, *ps};
+				}
+				const bool closes = (jb + SLOW_CH) % ROT_SEG == 0;   /* a segment ends with this chunk */
+				const long long nl = n0 + jb + SLOW_CH - 1;
+				const float2 olo = hist_lo[(size_t)(nl < 0 ? WR_HIST + nl : 0) * slots + s];
+#pragma unroll
+				for (int jj = 0; jj < SLOW_CH; ++jj) {
+					const int j = jb + jj;
+					v2f u = w[j];
+					if (!UTAPS)
+						u = u * hj[UTAPS ? 0 : jj];
+					if (jj == 0 && jb % ROT_SEG == 0)
+						A = u;
+					else
+						horner_step(A, r[jj].x, r[jj].y, u);
+				}
+				if (closes) {
+					const v2f cs = (nl < 0) ? (v2f){olo.x, olo.y}
+					                        : nco<NCO>(p0 + (unsigned int)nl * st, table, hi_l, lo_l);
+					horner_close(acc, A, cs);
+				}
+			}
 		} else if (n0 >= 0) {
 			/* EXACT: the reference's table and the reference's roundings, tap by tap */
 			unsigned int P = p0 + (unsigned int)n0 * st;
@@ -476,32 +677,40 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			}
 		} else {
 			/* window reaches into the previous block (only the first ceil(63/D1) frames of
-			 * a block): those frames get the LO values they were mixed with back then.
-			 * Rare, so taps come straight from memory, not registers. */
-			for (int j = 0; j < WR_FIR_LENGTH; ++j) {
-				const long long n = n0 + j;
-				const v2f xs = w[j];
-				v2f cs;
-				if (n < 0) {
-					const float2 o = hist_cs[(size_t)(WR_HIST + n) * slots + s];
-					cs = (v2f){o.x, o.y};
-				} else {
-					cs = nco<NCO>(p0 + (unsigned int)n * st, table, hi_l, lo_l);
+			 * a block): those frames get the LO values they were mixed with back then.  The
+			 * history rows are fetched SLOW_CH at a time before they are used (see above). */
+#pragma clang loop unroll(disable)
+			for (int jb = 0; jb < WR_FIR_LENGTH; jb += SLOW_CH) {
+				float2 o[SLOW_CH];
+				float hj[UTAPS ? 1 : SLOW_CH];
+#pragma unroll
+				for (int jj = 0; jj < SLOW_CH; ++jj) {
+					const int j = jb + jj;
+					const long long n = n0 + j;
+					o[jj] = hist_cs[(size_t)(n < 0 ? WR_HIST + n : 0) * slots + s];
+					if (!UTAPS)
+						hj[UTAPS ? 0 : jj] = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
 				}
-				if (UTAPS) {
-					/* the window is premultiplied; same operation order as the fast path, so a
-					 * frame gives the same bits wherever the block boundaries fall */
-					acc.x = __builtin_fmaf(xs.y, cs.y, __builtin_fmaf(xs.x, cs.x, acc.x));
-					acc.y = __builtin_fmaf(-xs.x, cs.y, __builtin_fmaf(xs.y, cs.x, acc.y));
-				} else {
-					const float hj = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
-					mac<NCO>(xs, cs, hj, acc);
+#pragma unroll
+				for (int jj = 0; jj < SLOW_CH; ++jj) {
+					const int j = jb + jj;
+					const long long n = n0 + j;
+					const v2f xs = w[j];
+					const v2f cs = (n < 0) ? (v2f){o[jj].x, o[jj].y}
+					                       : nco<NCO>(p0 + (unsigned int)n * st, table, hi_l, lo_l);
+					if (UTAPS) {
+						/* the window is premultiplied; same operation order as the fast path, so a
+						 * frame gives the same bits wherever the block boundaries fall */
+						acc.x = __builtin_fmaf(xs.y, cs.y, __builtin_fmaf(xs.x, cs.x, acc.x));
+						acc.y = __builtin_fmaf(-xs.x, cs.y, __builtin_fmaf(xs.y, cs.x, acc.y));
+					} else {
+						mac<NCO>(xs, cs, hj[UTAPS ? 0 : jj], acc);
+					}
 				}
 			}
 		}
 		if (fl & PHASE_FLAG_ACTIVE)
 			chan_iq[(size_t)k * slots + s] = make_float2(acc.x, acc.y);
-		g = gn;
 		k = kn;
 	}
 }
@@ -732,7 +941,8 @@ template <int NCO, bool UTAPS>
 static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaunch &L, const WrGroupDev &G,
                              const float *table_dev, const float *hi_dev, const float *lo_dev)
 {
-	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES : (DDC_WAVES * 2u * 512u);
+	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
+	                   : (DDC_WAVES * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u);
 	static bool attr_set = false;
 	if (!attr_set && lds > 64 * 1024) {
 		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_ddc<NCO, UTAPS>,
@@ -745,7 +955,8 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
 		L.slots, L.slots_used / 64, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
-		(float2 *)G.hist_cs[L.sp ^ 1], G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
+		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
+		(float2 *)G.chan_iq[L.cb], table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev);
 	return hipGetLastError();
 }
@@ -760,14 +971,25 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 	 * advances the NCO (downconverter.cxx:103 runs per input frame) and rolls the histories */
 	const size_t units = L.k1 * (L.slots_used / 64);
 	unsigned int wgs = (unsigned int)((units + DDC_WAVES - 1) / DDC_WAVES);
-	if (wgs < 1)
-		wgs = 1;
+	/* every lane group needs at least one wave of its own (the kernel deals waves to groups) */
+	const unsigned int min_wgs = (L.slots_used / 64 + DDC_WAVES - 1) / DDC_WAVES;
+	if (wgs < min_wgs)
+		wgs = min_wgs;
 	if (L.nco_mode == WR_NCO_EXACT) {
 		/* small LDS footprint: two workgroups per CU hide the gather latency */
 		unsigned int cap = (unsigned int)num_cus * 2u;
 		if (wgs > cap)
 			wgs = cap;
 		return launch_ddc<WR_NCO_EXACT, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
+	}
+	if (L.nco_mode == WR_NCO_ROTATE) {
+		/* uniform taps: 64 VGPRs, two workgroups per CU; per-lane taps need 64 more registers */
+		unsigned int cap = (unsigned int)num_cus * (L.uniform_taps ? DDC_ROTATE_WGS_PER_CU : 1u);
+		if (wgs > cap)
+			wgs = cap;
+		if (L.uniform_taps)
+			return launch_ddc<WR_NCO_ROTATE, true>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
+		return launch_ddc<WR_NCO_ROTATE, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
 	}
 	/* the replicated tables take 128 KiB: one persistent workgroup per CU */
 	unsigned int cap = (unsigned int)num_cus;

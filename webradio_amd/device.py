@@ -93,7 +93,7 @@ class Device:
 class Tuner:
     """wr_tuner: every Receiver chain of one tuner, evaluated by one launch sequence."""
 
-    def __init__(self, dev, input_rate, max_channels, max_block_frames, nco=capi.WR_NCO_SPLIT):
+    def __init__(self, dev, input_rate, max_channels, max_block_frames, nco=capi.WR_NCO_ROTATE):
         self.dev = dev
         self.lib = dev.lib
         h = C.c_void_p()

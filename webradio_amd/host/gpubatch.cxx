@@ -226,7 +226,12 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 		if (batch->_maxFrames == 0)
 			batch->_maxFrames = 1;
 		unsigned int maxch = envUnsigned("WEBRADIO_MAX_CHANNELS", 1024);
-		int nco = envUnsigned("WEBRADIO_NCO_EXACT", 0) ? WR_NCO_EXACT : WR_NCO_SPLIT;
+		int nco = WR_NCO_ROTATE;
+		const char *want = getenv("WEBRADIO_NCO");
+		if (envUnsigned("WEBRADIO_NCO_EXACT", 0) || (want && !strcmp(want, "exact")))
+			nco = WR_NCO_EXACT;
+		else if (want && !strcmp(want, "split"))
+			nco = WR_NCO_SPLIT;
 		if (wr_tuner_create(&batch->_tuner, batch->_dev, batch->_rate, maxch, batch->_maxFrames, nco) != WR_OK) {
 			LOG_ERROR("wr_tuner_create: %s\n", wr_last_error());
 			batch->_tuner = NULL;
