@@ -37,6 +37,7 @@ def _run_both(dev, oracle, nco, cfg, modes, blocks, seed=0, carriers=None):
     nchan = len(cfg["ifs"])
     maxblk = max(blocks)
     t = Tuner(dev, fs, max(nchan, 1), maxblk, nco)
+    t.keep_stages(capi.WR_STAGE_DEMOD)
     rxs, chans = [], []
     for c, f in enumerate(cfg["ifs"]):
         m = modes[c % len(modes)]
@@ -173,6 +174,7 @@ def test_setters_apply_at_block_boundary(dev, oracle):
     the old phase step (lowpass.cxx:138-142 keeps MIXED samples)."""
     fs = 2_000_000
     t = Tuner(dev, fs, 2, 40_000, capi.WR_NCO_EXACT)
+    t.keep_stages(capi.WR_STAGE_DEMOD)
     rx = oracle.Receiver(fs, 50_000, 128_000, 5_000, oracle.AM, 160, 1_000)
     ch = t.add_receiver(50_000, 128_000, 5_000, capi.WR_AM, 160, 1_000)
     pos = 0
@@ -380,3 +382,4 @@ def test_audio_scale_for_the_encoder(dev, oracle):
     want = (rx.run(iq)[0].astype(np.float64) * 32768.0).astype(np.float32)
     assert np.array_equal(t.fetch(ch, capi.WR_STAGE_AUDIO, 100), want)
     t.destroy()
+

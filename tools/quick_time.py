@@ -17,6 +17,8 @@ x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
 torch.cuda.synchronize()
 for name in which:
     t = Tuner(dev, fs, nch, n, modes[name])
+    if os.environ.get("QT_KEEP") == "1":
+        t.keep_stages(capi.WR_STAGE_DEMOD)
     mixed = os.environ.get("QT_MIXED") == "1"     # per-lane taps: a different passband per channel
     for i, f in enumerate(ifs):
         t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0), c2["chan_rate"], capi.WR_FM,

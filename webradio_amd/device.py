@@ -117,6 +117,13 @@ class Tuner:
         check(self.lib.wr_chan_set_mode(self.h, ch, mode))
         return ch
 
+    def keep_stages(self, *stages):
+        """Ask for intermediate stages (capi.WR_STAGE_DEMOD ...) to be kept for fetch()."""
+        mask = 0
+        for st in stages:
+            mask |= 1 << st
+        check(self.lib.wr_tuner_keep_stages(self.h, mask))
+
     def remove_receiver(self, ch):
         check(self.lib.wr_chan_remove(self.h, ch))
 
