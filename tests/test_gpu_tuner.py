@@ -32,12 +32,15 @@ def _mini_c2(nchan):
     return dict(fs=fs, ifs=ifs, chan_pb=128_000, chan_rate=5_000, audio_pb=160, audio_rate=1_000)
 
 
-def _run_both(dev, oracle, nco, cfg, modes, blocks, seed=0, carriers=None):
+def _run_both(dev, oracle, nco, cfg, modes, blocks, seed=0, carriers=None, keep_demod=True):
+    """keep_demod: the demodulator output is fetched too (demod and audio filter then run as
+    two kernels); without it the fused k_tuner_post runs and the demod entry of `got` is None."""
     fs = cfg["fs"]
     nchan = len(cfg["ifs"])
     maxblk = max(blocks)
     t = Tuner(dev, fs, max(nchan, 1), maxblk, nco)
-    t.keep_stages(capi.WR_STAGE_DEMOD)
+    if keep_demod:
+        t.keep_stages(capi.WR_STAGE_DEMOD)
     rxs, chans = [], []
     for c, f in enumerate(cfg["ifs"]):
         m = modes[c % len(modes)]
@@ -56,7 +59,7 @@ def _run_both(dev, oracle, nco, cfg, modes, blocks, seed=0, carriers=None):
             k1 = n // rxs[c].d1
             got = (t.fetch(chans[c], capi.WR_STAGE_AUDIO, k1 // rxs[c].d2 + 1),
                    t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * k1 + 2),
-                   t.fetch(chans[c], capi.WR_STAGE_DEMOD, k1 + 1))
+                   t.fetch(chans[c], capi.WR_STAGE_DEMOD, k1 + 1) if keep_demod else None)
             blk.append((want, got))
         results.append(blk)
     states = [(t.state(ch), (rx.s.phase, rx.s.prev_i, rx.s.prev_q)) for ch, rx in zip(chans, rxs)]
@@ -383,3 +386,51 @@ def test_audio_scale_for_the_encoder(dev, oracle):
     assert np.array_equal(t.fetch(ch, capi.WR_STAGE_AUDIO, 100), want)
     t.destroy()
 
+
+
+def _cfg_d2(d2):
+    """fs 2 Msps, D1 = 400 -> 5 kHz, then audio decimation d2"""
+    cfg = _mini_c2(8)
+    cfg["audio_rate"] = 5_000 // d2 if 5_000 % d2 == 0 else None
+    return cfg
+
+
+@pytest.mark.parametrize("d2,blocks", [(5, [40_000, 40_000, 40_000]), (5, [4_400, 36_000, 400, 800, 20_000, 1_600]),
+                                       (5, [399, 401, 12_345, 63 * 400, 64 * 400 + 7]), (1, [20_000, 20_000]),
+                                       (2, [20_400, 20_400]), (4, [20_000, 20_000]), (10, [40_000, 40_000])])
+def test_fused_post_stage_equals_two_kernel_path(dev, oracle, d2, blocks):
+    """k_tuner_post (demod + audio filter in one pass, the default for small audio decimations)
+    against the two-kernel path that keeps the demodulator output, and both against the oracle:
+    all four detectors, blocks shorter than the audio filter's history, channel-rate frame
+    counts that are not multiples of the audio decimation, a decimation outside the fused set."""
+    cfg = _cfg_d2(d2)
+    modes = [capi.WR_FM, capi.WR_AM, capi.WR_USB, capi.WR_LSB]
+    fused, fstates, _ = _run_both(dev, oracle, capi.WR_NCO_EXACT, cfg, modes, blocks, keep_demod=False)
+    kept, kstates, _ = _run_both(dev, oracle, capi.WR_NCO_EXACT, cfg, modes, blocks, keep_demod=True)
+    same_size = len(set(blocks)) == 1      # (the reference's history breaks when the size changes: Q7)
+    for fb, kb in zip(fused, kept):
+        for c, ((wa, wc, wd), (fa, fc, _)) in enumerate(fb):
+            ka = kb[c][1][0]
+            assert fa.size == wa.size == ka.size
+            assert np.array_equal(fa.view(np.uint32), ka.view(np.uint32)), c
+            if not same_size:
+                continue
+            assert np.array_equal(fc.view(np.uint32), wc.view(np.uint32)), c
+            if modes[c % 4] == capi.WR_FM:
+                assert np.abs(fa - wa).max() <= 2 * FM_ATOL
+            else:
+                assert np.array_equal(fa.view(np.uint32), wa.view(np.uint32)), c
+    for (fst, _), (kst, _) in zip(fstates, kstates):
+        assert fst[0] == kst[0] and tuple(fst[1]) == tuple(kst[1])
+
+
+def test_demod_fetch_needs_keep(dev):
+    t = Tuner(dev, 2_000_000, 1, 4000)
+    ch = t.add_receiver(1000, 128_000, 5_000, capi.WR_AM, 160, 1_000)
+    t.submit_host(np.zeros(8000, np.float32))
+    with pytest.raises(capi.WrError):
+        t.fetch(ch, capi.WR_STAGE_DEMOD, 10)
+    t.keep_stages(capi.WR_STAGE_DEMOD)
+    t.submit_host(np.zeros(8000, np.float32))
+    assert t.fetch(ch, capi.WR_STAGE_DEMOD, 10).size == 10
+    t.destroy()

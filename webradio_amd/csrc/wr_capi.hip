@@ -75,6 +75,7 @@ struct Group {
 	WrGroupDev dev;
 	int parity;                /* index of the current ping-pong buffers (prev_iq, dem) */
 	int last_parity;           /* parity the last submit wrote its demod rows with */
+	bool last_demod_kept = false; /* the last submit left its demod rows in HBM */
 	int sp;                    /* state set (phase, LO history) the next block reads */
 	int cb;                    /* chan_iq buffer the next block writes */
 	int last_cb;               /* chan_iq buffer the last submit wrote */
@@ -1097,12 +1098,22 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			HIP_TRY(hipEventRecord(g->ev_ddc, st));
 			HIP_TRY(hipStreamWaitEvent(ps, g->ev_ddc, 0));
 		}
-		HIP_TRY(wrk_tuner_demod(ps, L, g->dev));
-		if (t->overlap) {
-			HIP_TRY(hipEventRecord(g->ev_demod[g->cb], ps));
-			g->ev_demod_valid[g->cb] = true;
+		/* demodulator output wanted (wr_tuner_keep_stages), an unusual audio decimation, or the
+		 * two-stream schedule: demod and audio filter as two kernels with the demod rows in HBM;
+		 * otherwise one fused pass */
+		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || t->overlap
+		                         || !wrk_tuner_post_supported(L.d2);
+		if (two_kernels) {
+			HIP_TRY(wrk_tuner_demod(ps, L, g->dev));
+			if (t->overlap) {
+				HIP_TRY(hipEventRecord(g->ev_demod[g->cb], ps));
+				g->ev_demod_valid[g->cb] = true;
+			}
+			HIP_TRY(wrk_tuner_audio(ps, L, g->dev));
+		} else {
+			HIP_TRY(wrk_tuner_post(ps, L, g->dev));
 		}
-		HIP_TRY(wrk_tuner_audio(ps, L, g->dev));
+		g->last_demod_kept = two_kernels;
 		g->last_parity = g->parity;
 		g->last_cb = g->cb;
 		g->sp ^= 1;                    /* the kernels wrote the other state set */
@@ -1172,6 +1183,9 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 		if (stage == WR_STAGE_CHAN_IQ)
 			HIP_TRY(wrk_gather_rows(d->stream, g->dev.chan_iq[g->last_cb], g->last_k1, S * 2, (size_t)c->slot * 2, 2,
 			                        d->scratch));
+		else if (!g->last_demod_kept)
+			return fail(WR_ERR_STATE, "wr_chan_fetch: the demodulator output was not kept "
+			            "(call wr_tuner_keep_stages(tuner, 1u << WR_STAGE_DEMOD) before submitting)");
 		else
 			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem[g->last_parity] + (size_t)WR_HIST * S, g->last_k1, S,
 			                        (size_t)c->slot, 1, d->scratch));

@@ -82,6 +82,8 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
                          int num_cus);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+hipError_t wrk_tuner_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+bool wrk_tuner_post_supported(unsigned int d2);
 hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
                           const float *hist, float *hist_next);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,

@@ -846,6 +846,114 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 	}
 }
 
+/*
+ * k_tuner_post<D2>: Demodulator::process and the audio LowPass::process in one pass
+ * (dsp/demodulator.cxx:77-115 feeding dsp/lowpass.cxx:131-162), for the common small audio
+ * decimations and when nobody asked for the demodulator's own output (wr_tuner_keep_stages).
+ * The demod rows of a tile are computed from the channel IQ rows straight into LDS: the
+ * 4 B/frame/channel demod array makes no round trip through HBM and one launch goes away.
+ * Rows a tile shares with its neighbour (the FIR overlap) are demodulated by both.
+ *
+ *   blockIdx.x <  ntiles : POST_TK audio frames x 64 slots.
+ *        stage  : all 8 waves; thread (row, lane) takes rows row, row+8, ... of the tile.  Row rr
+ *                 of [history | current] is dem_hist[rr] for rr < 63, else the demodulated
+ *                 channel frame rr - 63 (its predecessor re-read from L1/L2, or prev_iq).
+ *        filter : POST_TK / POST_B waves; thread (lane, group of POST_B consecutive frames):
+ *                 the lane's 64 taps in registers, each staged row read from LDS ONCE and
+ *                 applied to every frame of the group that uses it.  D2 is a template
+ *                 parameter so that which tap meets which row is resolved at compile time.
+ *                 Per frame the products are added oldest-first, unfused, as lowpass.cxx does.
+ *   blockIdx.x == ntiles : what the block leaves behind per lane group, as k_tuner_demod does:
+ *                 the last 63 demod outputs (audio filter history) and the last channel
+ *                 frame (Demodulator::prev_i/q), into the other ping-pong set.
+ */
+#define POST_TK 16u
+#define POST_B 4u
+#define POST_THREADS 512u
+__device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
+                                          unsigned int s, int m, const float2 *__restrict__ prev_iq,
+                                          const float *__restrict__ dem_hist, size_t rr)
+{
+	if (rr < WR_HIST)
+		return dem_hist[rr * slots + s];
+	const size_t kk = rr - WR_HIST;
+	if (kk >= k1)
+		return 0.0f;                                    /* beyond the block: never read by lowpass.cxx */
+	const float2 z = chan_iq[kk * slots + s];
+	const float2 zp = kk ? chan_iq[(kk - 1u) * slots + s] : prev_iq[s];
+	return demod_one(m, z.x, z.y, zp.x, zp.y);
+}
+
+template <unsigned int D2>
+__global__ void __launch_bounds__(POST_THREADS)
+k_tuner_post(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
+             const int *__restrict__ mode, const float2 *__restrict__ prev_iq, float2 *__restrict__ prev_next,
+             const float *__restrict__ dem_hist, float *__restrict__ dem_hist_next,
+             size_t k2, unsigned int ntiles, const float *__restrict__ taps2, float *__restrict__ audio,
+             size_t k2max, float scale)
+{
+	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
+	constexpr unsigned int NROW = POST_THREADS / 64u;
+	__shared__ float stage[NEED * 64u];
+	__shared__ float tile[POST_TK * 65u];
+	const unsigned int lane = threadIdx.x & 63u;        /* slot within the group */
+	const unsigned int row = threadIdx.x >> 6;
+	const unsigned int g = blockIdx.y;
+	const unsigned int s = g * 64u + lane;
+	const int m = mode[s];                              /* < 0: idle slot */
+
+	if (blockIdx.x == ntiles) {
+		if (m < 0)
+			return;
+		const size_t first = k1;                        /* the last 63 rows of [history | current] */
+#pragma unroll
+		for (unsigned int r = row; r < WR_HIST; r += NROW)   /* unrolled: one memory round, not eight */
+			dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r);
+		if (row == 0)
+			prev_next[s] = k1 ? chan_iq[(size_t)(k1 - 1u) * slots + s] : prev_iq[s];
+		return;
+	}
+
+	const size_t kbase = (size_t)blockIdx.x * POST_TK;
+	const size_t r0 = kbase * D2;
+#pragma unroll 4
+	for (unsigned int r = row; r < NEED; r += NROW)
+		stage[r * 64u + lane] = (m >= 0) ? post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, r0 + r) : 0.0f;
+	__syncthreads();
+	if (row < POST_TK / POST_B) {
+		float h[WR_FIR_LENGTH];
+#pragma unroll
+		for (int j = 0; j < WR_FIR_LENGTH; ++j)
+			h[j] = taps2[(size_t)j * slots + s];
+		float acc[POST_B];
+#pragma unroll
+		for (unsigned int o = 0; o < POST_B; ++o)
+			acc[o] = 0.0f;
+		const float *x = stage + (row * POST_B * D2) * 64u + lane;
+#pragma unroll
+		for (unsigned int r = 0; r < (POST_B - 1u) * D2 + WR_FIR_LENGTH; ++r) {
+			const float xv = x[r * 64u];
+#pragma unroll
+			for (unsigned int o = 0; o < POST_B; ++o) {
+				if (r >= o * D2 && r - o * D2 < WR_FIR_LENGTH)
+					acc[o] = acc[o] + h[WR_FIR_LENGTH - 1u - (r - o * D2)] * xv;
+			}
+		}
+#pragma unroll
+		for (unsigned int o = 0; o < POST_B; ++o)
+			tile[(row * POST_B + o) * 65u + lane] = acc[o];
+	}
+	__syncthreads();
+	/* transposed write: POST_TK consecutive frames of one slot per POST_TK threads */
+	for (unsigned int e = threadIdx.x; e < 64u * POST_TK; e += POST_THREADS) {
+		const unsigned int sl = e / POST_TK, kk = e - sl * POST_TK;
+		const unsigned int so = g * 64u + sl;
+		const size_t k = kbase + kk;
+		if (k < k2 && mode[so] >= 0)
+			audio[(size_t)so * k2max + k] = (scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * scale;
+	}
+}
+
 /* The same filter without LDS, for the overlapped schedule: while block b+1's DDC holds
  * 144 KiB of every CU's LDS, block b's audio filter can only share the CUs if it needs
  * none.  Thread = (slot lane, AUD_DQ consecutive output frames): taps in registers, the
@@ -1037,6 +1145,39 @@ hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 		(const float2 *)G.chan_iq[L.cb], (unsigned int)L.k1, L.slots, G.mode, (const float2 *)G.prev_iq[p],
 		(float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1]);
 	return hipGetLastError();
+}
+
+template <unsigned int D2>
+static hipError_t launch_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
+{
+	const int p = L.parity;
+	const unsigned int ntiles = (unsigned int)((L.k2 + POST_TK - 1) / POST_TK);
+	dim3 grid(ntiles + 1u, L.slots_used / 64);
+	k_tuner_post<D2><<<grid, POST_THREADS, 0, st>>>(
+		(const float2 *)G.chan_iq[L.cb], (unsigned int)L.k1, L.slots, G.mode, (const float2 *)G.prev_iq[p],
+		(float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1], L.k2, ntiles, G.taps2, G.audio, L.k2max, L.audio_scale);
+	return hipGetLastError();
+}
+
+/* audio decimations k_tuner_post is instantiated for (anything else takes the two-kernel path) */
+bool wrk_tuner_post_supported(unsigned int d2)
+{
+	return d2 >= 1 && d2 <= 6;
+}
+
+hipError_t wrk_tuner_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
+{
+	if (!L.k1 || !L.slots_used)
+		return hipSuccess;
+	switch (L.d2) {
+	case 1: return launch_post<1>(st, L, G);
+	case 2: return launch_post<2>(st, L, G);
+	case 3: return launch_post<3>(st, L, G);
+	case 4: return launch_post<4>(st, L, G);
+	case 5: return launch_post<5>(st, L, G);
+	case 6: return launch_post<6>(st, L, G);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
