@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--nco", choices=["rotate", "split", "exact"], default="rotate")
+    ap.add_argument("--resident-blocks", type=int, default=12,
+                    help="consecutive blocks of the stream kept in HBM and cycled through (12 x 32 MB is "
+                         "more than the 256 MB Infinity Cache holds, so every step reads its block from HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2)
     ap.add_argument("--profile-stride", type=int, default=4,
@@ -90,7 +93,9 @@ def main():
     n = cfg["block_frames"]
     ifs = synth.c2_ifs(args.channels)
     # one independent tuner per GPU: its own stream of FM carriers, seed 12345 + tuner index
-    x = synth.fm_stream_torch(n, cfg["input_rate"], ifs[::4], "cuda", seed=12345 + rank)
+    nb = max(1, args.resident_blocks)
+    stream_iq = synth.fm_stream_torch(n * nb, cfg["input_rate"], ifs[::4], "cuda", seed=12345 + rank)
+    blocks = [stream_iq[2 * n * b: 2 * n * (b + 1)] for b in range(nb)]
     stream = torch.cuda.current_stream().cuda_stream
     dev = Device(device_index, stream)
     nco = {"rotate": capi.WR_NCO_ROTATE, "split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT}[args.nco]
@@ -105,13 +110,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = 0
     for _ in range(args.warmup):
-        tuner.submit_device(x, n)
+        tuner.submit_device(blocks[step % nb], n)
+        step += 1
     tuner.profile(max(1, args.profile_stride))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tuner.submit_device(x, n)
+        tuner.submit_device(blocks[step % nb], n)
+        step += 1
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -160,6 +168,7 @@ def main():
                             % args.channels,
                 "channels": args.channels,
                 "block_frames": n,
+                "resident_blocks": nb,
                 "nco": args.nco,
                 "tuners_per_gpu": 1,
                 "parallelism": "one tuner per GPU, no collective",

@@ -65,13 +65,13 @@ enum wr_stage {
 
 /* how the NCO sine/cosine of dsp/downconverter.cxx:100-101 is obtained */
 enum wr_nco {
-	WR_NCO_SPLIT = 0,        /* default: exact integer phase, sin/cos from two 256-entry
+	WR_NCO_SPLIT = 0,        /* exact integer phase, sin/cos from two 256-entry
 	                            LDS tables (coarse x fine angle addition); LO within
 	                            3.5e-7 of the reference table entry */
 	WR_NCO_EXACT = 1,        /* the reference's own 65536-entry sinf table, gathered from
 	                            global memory, unfused multiply/add in the reference's
 	                            order: channel-filter output is bit-identical */
-	WR_NCO_ROTATE = 2        /* the same table index sequence as the reference (exact integer
+	WR_NCO_ROTATE = 2        /* what the host runtime and bench.py use: the same table index sequence as the reference (exact integer
 	                            phase), but each LO value is reached by turning the previous
 	                            one by one of the two table angles the step allows, folded
 	                            into the FIR as a Horner recurrence: no table access per tap.
