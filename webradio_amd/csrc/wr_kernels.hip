@@ -465,13 +465,23 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	const unsigned int k1u = (unsigned int)k1;
 	const unsigned int nwaves = gridDim.x * waves_per_wg;
 	const unsigned int wid = blockIdx.x * waves_per_wg + wave;
-	const unsigned int wpg = nwaves / groups;            /* >= 1: the launcher sees to it */
-	const unsigned int g = wid % groups;
-	unsigned int k = wid / groups;
+	/* ROTATE with per-lane taps keeps the taps of ONE lane group in LDS (16 KiB) instead of 64
+	 * registers per lane: there a whole workgroup keeps to one group */
+	constexpr bool LTAPS = (NCO == WR_NCO_ROTATE) && !UTAPS;
+	const unsigned int wpg = LTAPS ? (gridDim.x / groups) * waves_per_wg : nwaves / groups;   /* >= 1: see the launcher */
+	const unsigned int g = LTAPS ? blockIdx.x % groups : wid % groups;
+	unsigned int k = LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
 	if (k >= wpg)
 		k = k1u;                                         /* the few waves left over stay idle */
+	const float *ltaps = (const float *)(lds + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N : 0u) + waves_per_wg * 128u);
+	if (LTAPS) {
+		float *lt = (float *)(lds + 2u * WR_SPLIT_N + waves_per_wg * 128u);
+		for (unsigned int e = threadIdx.x; e < WR_FIR_LENGTH * 64u; e += blockDim.x)
+			lt[e] = taps1[(size_t)(e >> 6) * slots + g * 64u + (e & 63u)];
+		__syncthreads();
+	}
 
-	float h[UTAPS ? 1 : WR_FIR_LENGTH];         /* per-lane taps (general case)          */
+	float h[(UTAPS || LTAPS) ? 1 : WR_FIR_LENGTH];   /* per-lane taps in registers (SPLIT / EXACT) */
 	float hlane = 0.0f;                         /* UTAPS: lane j holds the tap of sample j */
 	unsigned int p0 = 0, st = 0;
 	int fl = 0;
@@ -499,7 +509,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 				hlane = taps1[(size_t)(WR_FIR_LENGTH - 1 - lane) * slots + g * 64u];
 			} else {
 #pragma unroll
-				for (int j = 0; j < (UTAPS ? 1 : WR_FIR_LENGTH); ++j)
+				for (int j = 0; j < ((UTAPS || LTAPS) ? 1 : WR_FIR_LENGTH); ++j)
 					h[j] = taps1[(size_t)j * slots + s];
 			}
 			p0 = phase[s];
@@ -597,7 +607,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 					} else {
 						const float mi = __builtin_fmaf(xs.y, sn, xs.x * c);
 						const float mq = __builtin_fmaf(-xs.x, sn, xs.y * c);
-						const float hj = h[UTAPS ? 0 : WR_FIR_LENGTH - 1 - j];
+						const float hj = h[(UTAPS || LTAPS) ? 0 : WR_FIR_LENGTH - 1 - j];
 						acc.x = __builtin_fmaf(hj, mi, acc.x);
 						acc.y = __builtin_fmaf(hj, mq, acc.y);
 					}
@@ -616,10 +626,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 				for (int jj = 0; jj < 2; ++jj) {
 					const int j = 2 * jp + jj;
 					v2f u = jj ? (v2f){x2.z, x2.w} : (v2f){x2.x, x2.y};
-					if (!UTAPS) {
-						const float hj = h[UTAPS ? 0 : WR_FIR_LENGTH - 1 - j];
-						u = u * hj;
-					}
+					if (!UTAPS)
+						u = u * ltaps[(WR_FIR_LENGTH - 1 - j) * 64 + lane];   /* one LDS word per tap */
 					if (j % ROT_SEG == 0) {
 						if (j)
 							F += fstep;                 /* a segment starts afresh: no turn */
@@ -698,7 +706,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 					const v2f xs = w[j];
 					const v2f cs = nco<NCO>(P, table, hi_l, lo_l);
 					P += st;
-					mac<NCO>(xs, cs, h[UTAPS ? 0 : WR_FIR_LENGTH - 1 - j], acc);
+					mac<NCO>(xs, cs, h[(UTAPS || LTAPS) ? 0 : WR_FIR_LENGTH - 1 - j], acc);
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
@@ -1077,7 +1085,8 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
                              const float *table_dev, const float *hi_dev, const float *lo_dev)
 {
 	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
-	                   : (DDC_WAVES * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u);
+	                   : (DDC_WAVES * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
+	                     + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
 	static bool attr_set = false;
 	if (!attr_set && lds > 64 * 1024) {
 		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_ddc<NCO, UTAPS>,
@@ -1124,6 +1133,12 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 			wgs = cap;
 		if (L.uniform_taps)
 			return launch_ddc<WR_NCO_ROTATE, true>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
+		/* per-lane taps live in LDS, one lane group per WORKGROUP: a whole number of
+		 * workgroups per group, at least one */
+		const unsigned int ngroups = L.slots_used / 64;
+		wgs = (wgs / ngroups) * ngroups;
+		if (wgs < ngroups)
+			wgs = ngroups;
 		return launch_ddc<WR_NCO_ROTATE, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
 	}
 	/* the replicated tables take 128 KiB: one persistent workgroup per CU */
