@@ -209,6 +209,24 @@ int wr_chan_slot(wr_tuner *tuner, int chan, int *slot);
  * lands at out_host + s * (*chan_stride); *slots_used rows are copied.  Synchronises. */
 int wr_tuner_fetch_audio_all(wr_tuner *tuner, float *out_host, size_t out_capacity,
                              size_t *chan_stride, size_t *frames, unsigned int *slots_used);
+/* ---- audio sink boundary: a ring of pinned host buffers ----
+ * With a ring of `depth` >= 1 slots, every wr_tuner_submit* queues ONE asynchronous
+ * device-to-host copy of all channels' audio into the next free slot, behind the block's
+ * kernels on the tuner's stream, and returns without waiting: the consumer side (the 256
+ * AudioStreamManager sinks of a tuner, web/audiostream.cxx:65-73, or a recorder) takes the
+ * blocks in order with acquire/release, typically from another thread or one block later,
+ * so that the copy and the consumers overlap the next block's kernels.  Like the reference's
+ * tuner ring (io/rtlsdrtuner.cxx:100-117) a full ring drops the NEW block's audio and counts
+ * an overrun.  Blocks submitted while the tuner's channels do not all share one pair of
+ * decimations are not queued (fetch per channel then).  depth 0 frees the ring. */
+int wr_tuner_audio_ring(wr_tuner *tuner, unsigned int depth);
+/* oldest block not yet released: waits for its copy, then channel slot s (wr_chan_slot) is at
+ * (*audio_host) + s * (*chan_stride), *frames floats each; *seq counts submits from 0 (gaps =
+ * overruns).  WR_ERR_STATE when nothing is queued.  The slot stays valid until released. */
+int wr_tuner_audio_ring_acquire(wr_tuner *tuner, const float **audio_host, size_t *chan_stride,
+                                size_t *frames, unsigned int *slots_used, unsigned long long *seq);
+int wr_tuner_audio_ring_release(wr_tuner *tuner);
+int wr_tuner_audio_ring_stats(wr_tuner *tuner, unsigned int *queued, unsigned long long *overruns);
 /* LowPass::deinit + init (dsp/lowpass.cxx:118-129, 81-116): both filter histories of the
  * channel become empty again; NCO phase and Demodulator prev_i/q are kept (quirk Q5). */
 int wr_chan_reset_history(wr_tuner *tuner, int chan);

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 /* ------------------------------------------------------------------ errors -- */
@@ -114,6 +115,20 @@ struct wr_tuner {
 	size_t ev_used;                /* events recorded and not yet read */
 	double prof_ms;
 	unsigned int prof_n;
+	/* pinned audio ring (wr_tuner_audio_ring) */
+	struct RingSlot {
+		float *host = nullptr;         /* pinned, [max slots][k2max] floats */
+		size_t cap = 0;                /* floats */
+		hipEvent_t done = nullptr;     /* the copy into this slot */
+		size_t stride = 0, frames = 0;
+		unsigned int slots = 0;
+		unsigned long long seq = 0;
+	};
+	std::vector<RingSlot> ring;
+	unsigned int ring_head = 0, ring_count = 0;    /* next slot to fill, slots queued */
+	bool ring_held = false;                        /* oldest slot handed out, not yet released */
+	unsigned long long ring_seq = 0, ring_overruns = 0;
+	std::mutex ring_lock;                          /* producer (submit) vs consumer thread */
 };
 
 struct wr_spectrum {
@@ -560,6 +575,11 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 		(void)hipStreamDestroy(t->post_stream);
 	for (hipEvent_t e : t->ev)
 		(void)hipEventDestroy(e);
+	for (wr_tuner::RingSlot &r : t->ring) {
+		if (r.done)
+			(void)hipEventDestroy(r.done);
+		(void)hipHostFree(r.host);
+	}
 	(void)hipFree(t->in_stage);
 	(void)hipFree(t->in_hist[0]);
 	(void)hipFree(t->in_hist[1]);
@@ -569,6 +589,7 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 
 static int tuner_join(wr_tuner *t);
 static int tuner_quiesce(wr_tuner *t);
+static int ring_push(wr_tuner *t);
 
 static Chan *chan_get(wr_tuner *t, int chan)
 {
@@ -1140,6 +1161,11 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		c.phaseL += (unsigned int)nframes * c.stepL;
 	}
 	t->submitted = true;
+	if (!t->ring.empty()) {
+		int rc = ring_push(t);
+		if (rc)
+			return rc;
+	}
 	return WR_OK;
 }
 
@@ -1254,6 +1280,146 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+/* ---- pinned audio ring ---- */
+
+static Group *single_group(wr_tuner *t)
+{
+	Group *g = nullptr;
+	for (Group *x : t->groups)
+		if (x->active > 0) {
+			if (g)
+				return nullptr;
+			g = x;
+		}
+	return g;
+}
+
+/* queue the copy of the block just submitted (called at the end of tuner_submit) */
+static int ring_push(wr_tuner *t)
+{
+	std::lock_guard<std::mutex> lk(t->ring_lock);
+	const unsigned long long seq = t->ring_seq++;
+	Group *g = single_group(t);
+	if (!g)
+		return WR_OK;                           /* no or several rate groups: not queued (see the header) */
+	if (t->ring_count == t->ring.size()) {
+		++t->ring_overruns;                     /* io/rtlsdrtuner.cxx:100-117: the new block is dropped */
+		return WR_OK;
+	}
+	wr_tuner::RingSlot &r = t->ring[t->ring_head];
+	const unsigned int used = group_slots_used(g);
+	const size_t need = (size_t)used * g->last_k2;
+	if (need > r.cap) {
+		(void)hipHostFree(r.host);
+		r.host = nullptr;
+		r.cap = 0;
+		const size_t want = (size_t)g->slots * g->k2max;
+		HIP_TRY(hipHostMalloc((void **)&r.host, (want ? want : 1) * sizeof(float), hipHostMallocDefault));
+		r.cap = want;
+	}
+	hipStream_t st = t->overlap ? t->post_stream : t->dev->stream;
+	if (need)
+		HIP_TRY(hipMemcpy2DAsync(r.host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
+		                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(r.done, st));
+	r.stride = r.frames = g->last_k2;
+	r.slots = used;
+	r.seq = seq;
+	t->ring_head = (t->ring_head + 1) % (unsigned int)t->ring.size();
+	++t->ring_count;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_audio_ring(wr_tuner *t, unsigned int depth)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (depth > 1024)
+		return fail(WR_ERR_ARG, "wr_tuner_audio_ring: depth %u", depth);
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	{
+		int rc = tuner_quiesce(t);               /* no copy may be in flight into a slot we free */
+		if (rc)
+			return rc;
+	}
+	std::lock_guard<std::mutex> lk(t->ring_lock);
+	if (t->ring_held)
+		return fail(WR_ERR_STATE, "wr_tuner_audio_ring: a slot is still acquired");
+	for (wr_tuner::RingSlot &r : t->ring) {
+		if (r.done)
+			(void)hipEventDestroy(r.done);
+		(void)hipHostFree(r.host);
+	}
+	t->ring.clear();
+	t->ring.resize(depth);
+	for (wr_tuner::RingSlot &r : t->ring)
+		HIP_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+	t->ring_head = t->ring_count = 0;
+	t->ring_seq = t->ring_overruns = 0;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_audio_ring_acquire(wr_tuner *t, const float **audio_host, size_t *chan_stride,
+                                           size_t *frames, unsigned int *slots_used, unsigned long long *seq)
+{
+	if (!t || !audio_host || !chan_stride || !frames || !slots_used)
+		return fail(WR_ERR_ARG, "wr_tuner_audio_ring_acquire: bad argument");
+	hipEvent_t ev;
+	wr_tuner::RingSlot *r;
+	{
+		std::lock_guard<std::mutex> lk(t->ring_lock);
+		if (t->ring.empty())
+			return fail(WR_ERR_STATE, "wr_tuner_audio_ring_acquire: no ring (wr_tuner_audio_ring)");
+		if (t->ring_held)
+			return fail(WR_ERR_STATE, "wr_tuner_audio_ring_acquire: release the previous slot first");
+		if (!t->ring_count)
+			return fail(WR_ERR_STATE, "wr_tuner_audio_ring_acquire: nothing queued");
+		const unsigned int n = (unsigned int)t->ring.size();
+		r = &t->ring[(t->ring_head + n - t->ring_count) % n];
+		ev = r->done;
+		t->ring_held = true;
+	}
+	/* wait outside the lock: the producer may queue further blocks meanwhile */
+	hipError_t e = hipEventSynchronize(ev);
+	if (e != hipSuccess) {
+		std::lock_guard<std::mutex> lk(t->ring_lock);
+		t->ring_held = false;
+		return fail(WR_ERR_HIP, "wr_tuner_audio_ring_acquire: %s", hipGetErrorString(e));
+	}
+	*audio_host = r->host;
+	*chan_stride = r->stride;
+	*frames = r->frames;
+	*slots_used = r->slots;
+	if (seq)
+		*seq = r->seq;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_audio_ring_release(wr_tuner *t)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	std::lock_guard<std::mutex> lk(t->ring_lock);
+	if (!t->ring_held)
+		return fail(WR_ERR_STATE, "wr_tuner_audio_ring_release: nothing acquired");
+	t->ring_held = false;
+	--t->ring_count;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_audio_ring_stats(wr_tuner *t, unsigned int *queued, unsigned long long *overruns)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	std::lock_guard<std::mutex> lk(t->ring_lock);
+	if (queued)
+		*queued = t->ring_count;
+	if (overruns)
+		*overruns = t->ring_overruns;
 	return WR_OK;
 }
 

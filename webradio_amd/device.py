@@ -124,6 +124,28 @@ class Tuner:
             mask |= 1 << st
         check(self.lib.wr_tuner_keep_stages(self.h, mask))
 
+    def audio_ring(self, depth):
+        """Pinned host ring for the audio of every submit (0 = off)."""
+        check(self.lib.wr_tuner_audio_ring(self.h, depth))
+
+    def ring_acquire(self):
+        """Oldest queued block: (audio[slots][frames] copy, seq).  Call ring_release() after."""
+        p = C.POINTER(C.c_float)()
+        stride, frames, slots, seq = C.c_size_t(), C.c_size_t(), C.c_uint(), C.c_ulonglong()
+        check(self.lib.wr_tuner_audio_ring_acquire(self.h, C.byref(p), C.byref(stride), C.byref(frames),
+                                                   C.byref(slots), C.byref(seq)))
+        n = slots.value * stride.value
+        a = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+        return a.reshape(slots.value, stride.value)[:, : frames.value], seq.value
+
+    def ring_release(self):
+        check(self.lib.wr_tuner_audio_ring_release(self.h))
+
+    def ring_stats(self):
+        q, o = C.c_uint(), C.c_ulonglong()
+        check(self.lib.wr_tuner_audio_ring_stats(self.h, C.byref(q), C.byref(o)))
+        return q.value, o.value
+
     def remove_receiver(self, ch):
         check(self.lib.wr_chan_remove(self.h, ch))
 

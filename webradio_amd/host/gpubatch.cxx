@@ -153,7 +153,7 @@ void DevBuf::release()
 
 TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
-	  _submitOk(false), _audioStride(0), _audioFrames(0), _audioSlots(0)
+	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0)
 {
 }
 
@@ -237,6 +237,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 			batch->_tuner = NULL;
 			return NULL;
 		}
+		wr_tuner_audio_ring(batch->_tuner, 2);
 	}
 	int id = -1;
 	if (wr_chan_add(batch->_tuner, &id) != WR_OK) {
@@ -334,6 +335,11 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("block of %u frames exceeds the %zu the tuner batch was sized for\n", nframes, _maxFrames);
 		return false;
 	}
+	if (_ringHeld) {
+		wr_tuner_audio_ring_release(_tuner);      /* last block's audio has been handed out */
+		_ringHeld = false;
+		_audioSlots = 0;
+	}
 	/* cheapest way to get the block to the GPU: (1) a device copy some other consumer of the
 	 * source already made this block, (2) the source's raw bytes (2 per frame, converted in
 	 * the kernel's load stage), (3) stage the float block once for everybody */
@@ -356,9 +362,23 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
-	/* one transfer brings back the audio of every channel */
+	/* one transfer brings back the audio of every channel: through the tuner's pinned ring
+	 * (queued behind the kernels by the submit itself), read in place until the next block */
 	size_t stride = 0, frames = 0;
 	unsigned int slots = 0;
+	{
+		const float *p = NULL;
+		unsigned long long seq = 0;
+		if (wr_tuner_audio_ring_acquire(_tuner, &p, &stride, &frames, &slots, &seq) == WR_OK) {
+			_ringHeld = true;
+			_audioPtr = p;
+			_audioStride = stride;
+			_audioFrames = frames;
+			_audioSlots = slots;
+			_submitOk = true;
+			return true;
+		}
+	}
 	if (wr_tuner_fetch_audio_all(_tuner, NULL, 0, &stride, &frames, &slots) != WR_OK && frames * slots == 0) {
 		/* several rate groups: fall back to per-channel fetches in audio() */
 		_audioSlots = 0;
@@ -370,6 +390,7 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 	    wr_tuner_fetch_audio_all(_tuner, _audio.data(), _audio.size(), &stride, &frames, &slots) != WR_OK) {
 		_audioSlots = 0;                /* per-channel fallback */
 	} else {
+		_audioPtr = _audio.data();
 		_audioStride = stride;
 		_audioFrames = frames;
 		_audioSlots = slots;
@@ -388,7 +409,7 @@ bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 	int slot = -1;
 	if (_audioSlots && wr_chan_slot(_tuner, ch->id, &slot) == WR_OK && (unsigned int)slot < _audioSlots &&
 	    _audioFrames == out.size()) {
-		memcpy(out.data(), _audio.data() + (size_t)slot * _audioStride, out.size() * sizeof(float));
+		memcpy(out.data(), _audioPtr + (size_t)slot * _audioStride, out.size() * sizeof(float));
 		return true;
 	}
 	size_t got = 0;

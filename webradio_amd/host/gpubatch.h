@@ -108,7 +108,9 @@ private:
 	unsigned long _submittedEpoch;
 	bool _submitOk;
 	std::vector<Channel *> _channels;
-	std::vector<float> _audio;        /* [slot][frames] of the last submit */
+	std::vector<float> _audio;        /* [slot][frames] of the last submit (fallback without the ring) */
+	const float *_audioPtr;           /* where audio() reads: a pinned ring slot, or _audio */
+	bool _ringHeld;                   /* a slot of the tuner's pinned audio ring is acquired */
 	size_t _audioStride, _audioFrames;
 	unsigned int _audioSlots;
 	std::mutex _lock;
