@@ -102,7 +102,7 @@ __global__ void k_copy_f32(const float *__restrict__ src, float *__restrict__ ds
 
 /* atan2f(y, x) / (2 pi), the FM discriminator's angle in cycles (dsp/demodulator.cxx:96-99:
  * atan2f(..) / M_PI / 2.0).  The library atan2f costs about 150 instructions a frame, which made
- * the demodulator compute-bound; this one is ~40: one IEEE division into [0, 1], an odd
+ * the demodulator compute-bound; this one is ~30: one reciprocal-multiply into [0, 1], an odd
  * minimax polynomial (degree 17, fitted to 6e-9; 1.0e-7 rad worst case evaluated in float),
  * and the octant/quadrant reflections done in cycles, where the constants 1/4 and 1/2 are
  * exact.  Signed zeros follow atan2f: (+0, -0) -> +1/2, (-0, +0) -> -0.  Worst difference
@@ -112,7 +112,11 @@ __device__ __forceinline__ float fm_angle_cycles(float y, float x)
 {
 	const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
 	const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
-	const float r = (mx == 0.0f) ? 0.0f : mn / mx;
+	/* mn / mx with one v_rcp_f32 (1 ulp) instead of the IEEE division sequence; operands are
+	 * brought into the normal range first so that a vanishing signal cannot overflow the
+	 * reciprocal (0/0 -> 0: atan2f(+-0, +-0) only depends on the signs) */
+	const float sc = (mx < 0x1p-100f) ? 0x1p100f : 1.0f;
+	const float r = (mx == 0.0f) ? 0.0f : (mn * sc) * __builtin_amdgcn_rcpf(mx * sc);
 	const float t = r * r;
 	float p = 0.002456712769344449f;
 	p = __builtin_fmaf(p, t, -0.014401308260858059f);
@@ -924,15 +928,18 @@ k_tuner_post(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int s
 
 	const size_t kbase = (size_t)blockIdx.x * POST_TK;
 	const size_t r0 = kbase * D2;
+	/* the filter waves fetch their taps first: the latency hides behind the stage phase */
+	float h[WR_FIR_LENGTH];
+	if (row < POST_TK / POST_B) {
+#pragma unroll
+		for (int j = 0; j < WR_FIR_LENGTH; ++j)
+			h[j] = taps2[(size_t)j * slots + s];
+	}
 #pragma unroll 4
 	for (unsigned int r = row; r < NEED; r += NROW)
 		stage[r * 64u + lane] = (m >= 0) ? post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, r0 + r) : 0.0f;
 	__syncthreads();
 	if (row < POST_TK / POST_B) {
-		float h[WR_FIR_LENGTH];
-#pragma unroll
-		for (int j = 0; j < WR_FIR_LENGTH; ++j)
-			h[j] = taps2[(size_t)j * slots + s];
 		float acc[POST_B];
 #pragma unroll
 		for (unsigned int o = 0; o < POST_B; ++o)
@@ -1022,6 +1029,26 @@ __global__ void k_gather_rows(const float *__restrict__ src, size_t rows, size_t
 /* launchers                                                                   */
 /* ------------------------------------------------------------------------- */
 
+/* hipFuncAttributeMaxDynamicSharedMemorySize is a per-device setting of the loaded code object:
+ * a process that drives several GPUs (the host runtime gives every tuner its own) has to set
+ * it once on each.  `done` is the call site's own flag array. */
+#define WR_MAX_DEVICES 64
+static hipError_t allow_lds(const void *fn, size_t bytes, bool (&done)[WR_MAX_DEVICES])
+{
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return e;
+	if (dev < 0 || dev >= WR_MAX_DEVICES)
+		return hipErrorInvalidDevice;
+	if (done[dev])
+		return hipSuccess;
+	e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess)
+		done[dev] = true;
+	return e;
+}
+
 static inline unsigned int grid_for(size_t n, unsigned int block, unsigned int cap)
 {
 	size_t g = (n + block - 1) / block;
@@ -1087,13 +1114,11 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
 	                   : (DDC_WAVES * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
 	                     + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
-	static bool attr_set = false;
-	if (!attr_set && lds > 64 * 1024) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_ddc<NCO, UTAPS>,
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	static bool attr_done[WR_MAX_DEVICES];
+	if (lds > 64 * 1024) {
+		hipError_t e = allow_lds((const void *)k_tuner_ddc<NCO, UTAPS>, lds, attr_done);
 		if (e != hipSuccess)
 			return e;
-		attr_set = true;
 	}
 	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
@@ -1213,14 +1238,12 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	/* LDS sized to what this decimation needs, so that two workgroups fit a CU when D2 is small */
 	const unsigned int need = (tk - 1u) * L.d2 + WR_FIR_LENGTH;
 	const size_t lds = ((size_t)need * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
-	static bool attr_set = false;
-	if (!attr_set) {
+	static bool attr_done[WR_MAX_DEVICES];
+	{
 		const size_t lds_max = ((size_t)AUD_ROWS * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
-		hipError_t e = hipFuncSetAttribute((const void *)k_tuner_audio,
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+		hipError_t e = allow_lds((const void *)k_tuner_audio, lds_max, attr_done);
 		if (e != hipSuccess)
 			return e;
-		attr_set = true;
 	}
 	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
 	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
