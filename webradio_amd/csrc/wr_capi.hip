@@ -1498,7 +1498,7 @@ extern "C" int wr_spectrum_create(wr_spectrum **spec, wr_dev *dev, unsigned int 
 	wrd_spectrum_window(fft_size, win.data());
 	if (sub)
 		wrd_twiddles(sub, tws.data());
-	p.work_frames = (p.n2 == 1) ? 0 : 64;
+	p.work_frames = (p.n2 == 1) ? 0 : 1;        /* grown on demand by wr_spectrum_batch_db */
 	hipError_t e = hipSuccess;
 	do {
 		if ((e = hipMalloc((void **)&p.tw_n, fft_size * sizeof(float))) != hipSuccess) break;
@@ -1666,6 +1666,26 @@ extern "C" int wr_spectrum_batch_db(wr_spectrum *s, const float *iq_dev, size_t 
 		return fail(WR_ERR_ARG, "wr_spectrum_batch_db: bad argument");
 	if (dev_bind(s->dev))
 		return WR_ERR_HIP;
+	/* the two-pass transforms keep their intermediate in `work`: room for the whole batch, up
+	 * to 128 MB (it then still sits in the 256 MB Infinity Cache between the passes), means one
+	 * pair of launches per call instead of one per 64 frames */
+	WrFftPlan &p = s->plan;
+	if (p.n2 != 1 && p.work_frames < nframes_fft) {
+		const size_t frame_bytes = (size_t)p.n * 2 * sizeof(float);
+		size_t want = ((size_t)128 << 20) / frame_bytes;
+		if (want < 1)
+			want = 1;
+		if (want > nframes_fft)
+			want = nframes_fft;
+		if (want > p.work_frames) {
+			HIP_TRY(hipStreamSynchronize(s->dev->stream));
+			(void)hipFree(p.work);
+			p.work = nullptr;
+			p.work_frames = 0;
+			HIP_TRY(hipMalloc((void **)&p.work, want * frame_bytes));
+			p.work_frames = want;
+		}
+	}
 	HIP_TRY(wrk_fft_frames(s->dev->stream, s->plan, iq_dev, s->hop, nframes_fft, nullptr, db_dev));
 	return WR_OK;
 }
