@@ -100,6 +100,13 @@ int wr_sin_table(float *table_host);
  * integer cut-off bin of lowpass.cxx:167 */
 int wr_lowpass_design(unsigned int passband, unsigned int input_rate,
                       float *coeff_host /* [64] */, unsigned int *maxbin_out);
+/* the same with LowPass::_firLength = fir_length instead of the compiled-in 64: the
+ * reference's FIXME "Make runtime variable" (dsp/lowpass.cxx:38-39) acted on -- every
+ * expression of init()/recalculate() is already written in terms of _firLength.  A power of
+ * two (the mask logic of lowpass.cxx:172,184) in [2, WR_FIR_MAX]. */
+#define WR_FIR_MAX 1024
+int wr_lowpass_design_n(unsigned int fir_length, unsigned int passband, unsigned int input_rate,
+                        float *coeff_host /* [fir_length] */, unsigned int *maxbin_out);
 /* SpectrumSink::init window (io/spectrumsink.cxx:71-74); window[fft_size] */
 int wr_spectrum_window(unsigned int fft_size, float *window_host);
 
@@ -130,6 +137,10 @@ int wr_mix(wr_dev *dev, const float *in_dev, float *out_dev, size_t nframes,
 int wr_fir_decimate(wr_dev *dev, const float *in_dev, size_t nframes, unsigned int channels,
                     unsigned int decimation, const float *coeff_host /* [64] */,
                     float *history_dev, float *out_dev);
+/* the same for fir_length taps: history_dev holds (fir_length-1)*channels floats */
+int wr_fir_decimate_n(wr_dev *dev, const float *in_dev, size_t nframes, unsigned int channels,
+                      unsigned int decimation, unsigned int fir_length, const float *coeff_host /* [fir_length] */,
+                      float *history_dev, float *out_dev);
 
 /* Demodulator::process (dsp/demodulator.cxx:77-115).  prev_io[2] = {prev_i,prev_q}
  * (host), updated on return. */

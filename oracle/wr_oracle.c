@@ -73,7 +73,11 @@ void wro_mix(const float *table, unsigned int *phase, int phase_step,
  * float; the division is float/float. */
 void wro_lowpass_window(float *window)
 {
-	const unsigned int L = WRO_FIR_LENGTH;
+	wro_lowpass_window_n(WRO_FIR_LENGTH, window);
+}
+
+void wro_lowpass_window_n(unsigned int L, float *window)
+{
 	for (unsigned int n = 0; n < L; n++) {
 		double arg = 2 * M_PI * (double)(float)n / (double)(float)(L - 1);
 		float w = (float)(0.54 - 0.46 * (double)cosf((float)arg));
@@ -86,7 +90,11 @@ void wro_lowpass_window(float *window)
  * the product wraps modulo 2^32, small passbands give 0 -> all-zero taps). */
 unsigned wro_lowpass_maxbin(unsigned int passband, unsigned int input_rate)
 {
-	unsigned int L = WRO_FIR_LENGTH;
+	return wro_lowpass_maxbin_n(WRO_FIR_LENGTH, passband, input_rate);
+}
+
+unsigned wro_lowpass_maxbin_n(unsigned int L, unsigned int passband, unsigned int input_rate)
+{
 	return L * passband / input_rate / 2;
 }
 
@@ -98,17 +106,21 @@ unsigned wro_lowpass_maxbin(unsigned int passband, unsigned int input_rate)
  * within ~1 float ulp of any correct float transform of this 0/1 input. */
 void wro_lowpass_design(unsigned int passband, unsigned int input_rate, float *coeff)
 {
-	const unsigned int L = WRO_FIR_LENGTH;
+	wro_lowpass_design_n(WRO_FIR_LENGTH, passband, input_rate, coeff);
+}
+
+void wro_lowpass_design_n(unsigned int L, unsigned int passband, unsigned int input_rate, float *coeff)
+{
 	const unsigned int mask = L - 1;
-	unsigned int maxbin = wro_lowpass_maxbin(passband, input_rate);
-	float spec[WRO_FIR_LENGTH];
-	float window[WRO_FIR_LENGTH];
+	unsigned int maxbin = wro_lowpass_maxbin_n(L, passband, input_rate);
+	float spec[WRO_FIR_MAX];
+	float window[WRO_FIR_MAX];
 
 	memset(spec, 0, sizeof(spec));
 	for (unsigned int n = 0; n < L / 2 + 1; n++)
 		spec[n] = spec[(L - n) & mask] = (n < maxbin) ? 1.0f : 0.0f;
 
-	wro_lowpass_window(window);
+	wro_lowpass_window_n(L, window);
 
 	for (unsigned int n = 0; n < L; n++) {
 		unsigned int bin = (n + L / 2) & mask;
@@ -127,9 +139,17 @@ void wro_lowpass_design(unsigned int passband, unsigned int input_rate, float *c
 void wro_fir_init(wro_fir *f, unsigned int channels, unsigned int decimation,
                   const float *coeff)
 {
+	wro_fir_init_n(f, channels, decimation, coeff, WRO_FIR_LENGTH);
+}
+
+void wro_fir_init_n(wro_fir *f, unsigned int channels, unsigned int decimation,
+                    const float *coeff, unsigned int L)
+{
 	f->channels = channels;
 	f->decimation = decimation;
-	memcpy(f->coeff, coeff, sizeof(f->coeff));
+	f->length = L;
+	memset(f->coeff, 0, sizeof(f->coeff));
+	memcpy(f->coeff, coeff, L * sizeof(float));
 	f->block = NULL;
 	f->block_len = 0;
 }
@@ -150,7 +170,7 @@ void wro_fir_free(wro_fir *f)
  *    sample first, channels interleaved. */
 size_t wro_fir_process(wro_fir *f, const float *in, size_t in_floats, float *out)
 {
-	const unsigned int L = WRO_FIR_LENGTH;
+	const unsigned int L = f->length;
 	const unsigned int ch = f->channels;
 	const size_t hist = (size_t)ch * (L - 1);
 	const size_t want = in_floats + hist;

@@ -35,6 +35,7 @@ extern "C" {
 #endif
 
 #define WRO_FIR_LENGTH   64          /* lowpass.cxx:39 */
+#define WRO_FIR_MAX      1024        /* largest _firLength the _n variants take (a power of two, lowpass.cxx:172) */
 #define WRO_TABLE_SIZE   65536       /* downconverter.cxx:35,49 (LOOKUP_BITS 16) */
 
 enum wro_mode { WRO_AM = 0, WRO_FM = 1, WRO_USB = 2, WRO_LSB = 3 };   /* demodulator.h:40-46 */
@@ -52,17 +53,27 @@ void     wro_lowpass_window(float *window /* [64] */);
 unsigned wro_lowpass_maxbin(unsigned int passband, unsigned int input_rate);
 void     wro_lowpass_design(unsigned int passband, unsigned int input_rate,
                             float *coeff /* [64] */);
+/* the same three with LowPass::_firLength = L instead of the compiled-in 64 -- what the
+ * reference's own code computes once its FIXME (lowpass.cxx:38 "Make runtime variable") is
+ * acted on: every expression there is already written in terms of _firLength */
+void     wro_lowpass_window_n(unsigned int L, float *window /* [L] */);
+unsigned wro_lowpass_maxbin_n(unsigned int L, unsigned int passband, unsigned int input_rate);
+void     wro_lowpass_design_n(unsigned int L, unsigned int passband, unsigned int input_rate,
+                              float *coeff /* [L] */);
 
 /* ---- a4: LowPass::process (lowpass.cxx:131-162) ---- */
 typedef struct wro_fir {
 	unsigned int channels;           /* inputChannels() */
 	unsigned int decimation;         /* DspBlock::decimation() */
-	float        coeff[WRO_FIR_LENGTH];
+	unsigned int length;             /* LowPass::_firLength (64 unless wro_fir_init_n) */
+	float        coeff[WRO_FIR_MAX];
 	float       *block;              /* history + current block (lowpass.h:64) */
 	size_t       block_len;          /* floats */
 } wro_fir;
 void     wro_fir_init(wro_fir *f, unsigned int channels, unsigned int decimation,
                       const float *coeff);
+void     wro_fir_init_n(wro_fir *f, unsigned int channels, unsigned int decimation,
+                        const float *coeff, unsigned int L);
 void     wro_fir_free(wro_fir *f);
 /* out must hold (in_floats/channels/decimation)*channels floats, as sized by
  * DspBlock::run (dspblock.cxx:177-184).  Returns output float count. */

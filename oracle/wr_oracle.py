@@ -27,8 +27,8 @@ def build(ref=True):
 
 
 class FirState(C.Structure):
-    _fields_ = [("channels", C.c_uint), ("decimation", C.c_uint), ("coeff", C.c_float * 64),
-                ("block", _fp), ("block_len", C.c_size_t)]
+    _fields_ = [("channels", C.c_uint), ("decimation", C.c_uint), ("length", C.c_uint),
+                ("coeff", C.c_float * 1024), ("block", _fp), ("block_len", C.c_size_t)]
 
 
 class SpectrumState(C.Structure):
@@ -58,6 +58,8 @@ def lib():
         L.wro_phase_step.argtypes = [C.c_int, C.c_uint]
         L.wro_lowpass_maxbin.restype = C.c_uint
         L.wro_lowpass_maxbin.argtypes = [C.c_uint, C.c_uint]
+        L.wro_lowpass_maxbin_n.restype = C.c_uint
+        L.wro_lowpass_maxbin_n.argtypes = [C.c_uint, C.c_uint, C.c_uint]
         L.wro_fir_process.restype = C.c_size_t
         L.wro_receiver_run.restype = C.c_size_t
         L.wro_bench_receivers.restype = C.c_double
@@ -101,10 +103,21 @@ def lowpass_maxbin(passband, rate):
     return lib().wro_lowpass_maxbin(int(passband), int(rate))
 
 
-def lowpass_design(passband, rate):
-    c = np.empty(64, np.float32)
-    lib().wro_lowpass_design(C.c_uint(passband), C.c_uint(rate), _p(c))
+def lowpass_design(passband, rate, length=64):
+    """LowPass::recalculate with _firLength = length (a power of two; 64 is what the reference compiles in)"""
+    c = np.empty(length, np.float32)
+    lib().wro_lowpass_design_n(C.c_uint(length), C.c_uint(passband), C.c_uint(rate), _p(c))
     return c
+
+
+def lowpass_window_n(length):
+    w = np.empty(length, np.float32)
+    lib().wro_lowpass_window_n(C.c_uint(length), _p(w))
+    return w
+
+
+def lowpass_maxbin_n(length, passband, rate):
+    return lib().wro_lowpass_maxbin_n(int(length), int(passband), int(rate))
 
 
 class Fir:
@@ -113,7 +126,8 @@ class Fir:
     def __init__(self, channels, decimation, coeff):
         self.s = FirState()
         coeff = _f32(coeff)
-        lib().wro_fir_init(C.byref(self.s), C.c_uint(channels), C.c_uint(decimation), _p(coeff))
+        lib().wro_fir_init_n(C.byref(self.s), C.c_uint(channels), C.c_uint(decimation), _p(coeff),
+                             C.c_uint(coeff.size))
         self.channels, self.decimation = channels, decimation
 
     def process(self, x):

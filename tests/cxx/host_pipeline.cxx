@@ -9,6 +9,7 @@
  *   oracle/_ref/libwr_boundary.so   with the REFERENCE's radio.cxx, compiled unchanged
  *                                   from /root/reference/src/radio.cxx (the drop-in proof)
  */
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -88,6 +89,11 @@ int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int
 		rx[n]->audioFilter()->setOutputSampleRate(audio_rate);
 		rx[n]->demodulator()->setMode((Demodulator::Mode)modes[n]);
 		rx[n]->stream()->setCapacity(audio_cap);
+		/* test hook for LowPass::setFirLength (an extension) */
+		if (getenv("WR_TEST_FIR_LENGTH")) {
+			rx[n]->channelFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH")));
+			rx[n]->audioFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH")));
+		}
 		rx[n]->setFrontEnd(fe);
 	}
 	int rc = 0;

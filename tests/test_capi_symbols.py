@@ -73,6 +73,21 @@ def test_design_helpers_match_oracle(oracle):
         # both accumulated in double: equal up to one float rounding
         assert np.allclose(coeff, ref, rtol=0, atol=4e-9), (pb, rate, np.abs(coeff - ref).max())
 
+    # LowPass::_firLength as a run-time value (the reference's FIXME, lowpass.cxx:38-39): same
+    # agreement at every power of two, and fir_length = 64 is the plain entry point bit for bit
+    for L in (2, 4, 16, 64, 128, 256, 1024):
+        c = np.empty(L, np.float32)
+        for pb, rate in cases:
+            assert lib.wr_lowpass_design_n(L, pb, rate, capi.ptr(c), C.byref(mb)) == 0
+            assert mb.value == oracle.lowpass_maxbin_n(L, pb, rate)
+            ref = oracle.lowpass_design(pb, rate, L)
+            assert np.allclose(c, ref, rtol=0, atol=1e-8 * max(1, L // 64)), (L, pb, rate, np.abs(c - ref).max())
+            if L == 64:
+                assert lib.wr_lowpass_design(pb, rate, capi.ptr(coeff), None) == 0
+                assert np.array_equal(c.view(np.uint32), coeff.view(np.uint32))
+    for bad in (0, 1, 3, 96, 2048):
+        assert lib.wr_lowpass_design_n(bad, 1000, 48000, capi.ptr(coeff), None) == capi.WR_ERR_ARG
+
     for n in (8, 512, 65536):
         w = np.empty(n, np.float32)
         assert lib.wr_spectrum_window(n, capi.ptr(w)) == 0

@@ -56,6 +56,27 @@ def test_fir_bit_exact_streaming(dev, oracle, channels, decim, blocks):
         dev.free(hist)
 
 
+@pytest.mark.parametrize("length", [2, 16, 128, 512, 1024])
+def test_fir_other_lengths_bit_exact(dev, oracle, length):
+    """LowPass::_firLength as a run-time value (SURVEY 8f-4; the reference's FIXME at
+    lowpass.cxx:38-39): wr_fir_decimate_n against the oracle's LowPass::process with the same
+    length, streaming, blocks shorter than the history included."""
+    rng = np.random.default_rng(length)
+    coeff = oracle.lowpass_design(150_000, 2_048_000, length)
+    for channels, decim in ((1, 5), (2, 8)):
+        fir = oracle.Fir(channels, decim, coeff)
+        hist = dev.malloc(max(4, (length - 1) * channels * 4))
+        try:
+            for _ in range(4):
+                frames = decim * 37
+                x = rng.uniform(-1, 1, frames * channels).astype(np.float32)
+                want = fir.process(x)
+                got = dev.fir_decimate(x, channels, decim, coeff, hist)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        finally:
+            dev.free(hist)
+
+
 def test_fir_block_size_change_keeps_true_history(dev, oracle):
     """Deliberate deviation: when the block size changes mid-stream
     the reference resizes its buffer BEFORE saving the history (lowpass.cxx:138-141) and so

@@ -91,6 +91,35 @@ def test_fused_receivers_match_oracle(tmp_path, oracle):
             assert np.abs(got[c] - want[c]).max() <= 2e-6, c
 
 
+def test_runtime_fir_length_through_the_host_classes(tmp_path, oracle):
+    """LowPass::setFirLength(128) on both filters of every Receiver (SURVEY 8f-4, the reference's
+    FIXME at lowpass.cxx:38-39): such chains run block by block (the fused kernels are built for
+    64 taps), bit-identical for the linear detectors to the reference's algorithm with
+    _firLength = 128."""
+    L = 128
+    ifs, modes = [50_000, -75_000, 10], [0, 2, 3]
+    rate, block, cpb, crate, apb, arate = CFG["rate"], CFG["block"], CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"]
+    iq = synth.fm_stream(3 * block, rate, ifs[:2], amp=0.3)
+    got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
+                  env={"WR_TEST_FIR_LENGTH": str(L)})
+    table = oracle.sin_table()
+    for c, (f, m) in enumerate(zip(ifs, modes)):
+        f1 = oracle.Fir(2, rate // crate, oracle.lowpass_design(cpb, rate, L))
+        f2 = oracle.Fir(1, crate // arate, oracle.lowpass_design(apb, crate, L))
+        phase, prev, want = 0, (0.0, 0.0), []
+        for b in range(3):
+            mixed, phase = oracle.mix(table, phase, oracle.phase_step(f, rate), iq[2 * b * block: 2 * (b + 1) * block])
+            d, prev = oracle.demod(m, prev, f1.process(mixed))
+            want.append(f2.process(d))
+        want = np.concatenate(want)
+        assert got[c].size == want.size
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
+    # and it is not the 64-tap result
+    base, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
+                   env={"WEBRADIO_NO_FUSION": "1"})
+    assert np.abs(base - got).max() > 1e-4
+
+
 def test_unfused_blocks_are_bit_exact(tmp_path, oracle):
     """WEBRADIO_NO_FUSION=1: each block runs its own kernel on host vectors, exactly the
     reference's dataflow -- AM/USB/LSB chains are bit-identical."""

@@ -185,3 +185,24 @@ def test_receiver_chain_wiring(oracle):
     assert np.array_equal(chan, c) and np.array_equal(dem, d) and np.array_equal(audio, a)
     # first FM sample: atan2f of signed zeros (prev_i = prev_q = 0): 0 or +-0.5
     assert dem[0] in (0.0, 0.5, -0.5)
+
+
+def test_lowpass_design_other_lengths_against_numpy(oracle):
+    """LowPass::init/recalculate with _firLength = L (lowpass.cxx:102-110,164-189 are written in
+    terms of _firLength; only the constant at :39 fixes it to 64): an independent restatement
+    with numpy's inverse FFT."""
+    for L in (8, 64, 128, 512):
+        for pb, rate in ((200_000, 2_048_000), (6_400_000, 100_000_000), (8_000, 48_000), (1, 1_000_000)):
+            maxbin = (L * pb % 2 ** 32) // rate // 2
+            assert oracle.lowpass_maxbin_n(L, pb, rate) == maxbin
+            spec = np.zeros(L)
+            for n in range(L // 2 + 1):
+                spec[n] = spec[(L - n) % L] = 1.0 if n < maxbin else 0.0
+            impulse = np.fft.ifft(spec) * L                       # FFTW_BACKWARD is unnormalised
+            n = np.arange(L)
+            window = (0.54 - 0.46 * np.cos(2 * np.pi * n / (L - 1))) / L
+            want = impulse.real[(n + L // 2) % L] * window
+            got = oracle.lowpass_design(pb, rate, L)
+            assert np.abs(got - want).max() <= 2e-7 * max(1.0, np.abs(want).max() * L / 64), (L, pb, rate)
+    assert np.array_equal(oracle.lowpass_design(200_000, 2_048_000, 64), oracle.lowpass_design(200_000, 2_048_000))
+    assert np.array_equal(oracle.lowpass_window_n(64), oracle.lowpass_window())

@@ -32,6 +32,7 @@ SIGNATURES = {
     "wr_phase_step": (C.c_int, [C.c_int, _u32, C.POINTER(C.c_int)]),
     "wr_sin_table": (C.c_int, [_vp]),
     "wr_lowpass_design": (C.c_int, [_u32, _u32, _vp, C.POINTER(_u32)]),
+    "wr_lowpass_design_n": (C.c_int, [_u32, _u32, _u32, _vp, C.POINTER(_u32)]),
     "wr_spectrum_window": (C.c_int, [_u32, _vp]),
     "wr_dev_open": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
     "wr_dev_close": (C.c_int, [_vp]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "wr_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wr_mix": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_u32), C.c_int]),
     "wr_fir_decimate": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _vp, _vp]),
+    "wr_fir_decimate_n": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp]),
     "wr_demod": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _vp]),
     "wr_u8_to_f32": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wr_tuner_create": (C.c_int, [C.POINTER(_vp), _vp, _u32, _u32, _sz, C.c_int]),

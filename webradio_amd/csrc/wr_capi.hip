@@ -48,7 +48,7 @@ struct wr_dev {
 	float *hi_cs, *lo_cs;      /* [256][2] split NCO tables */
 	float *scratch;            /* growable scratch */
 	size_t scratch_floats;
-	float *coeff;              /* [64] staging for wr_fir_decimate */
+	float *coeff;              /* [WR_FIR_MAX] staging for wr_fir_decimate */
 };
 
 struct Chan {
@@ -213,9 +213,28 @@ extern "C" int wr_lowpass_design(unsigned int passband, unsigned int input_rate,
 {
 	if (!coeff_host || !input_rate)
 		return fail(WR_ERR_ARG, "wr_lowpass_design: bad argument");
-	wrd_lowpass_design(passband, input_rate, coeff_host);
+	wrd_lowpass_design(WR_FIR_LENGTH, passband, input_rate, coeff_host);
 	if (maxbin_out)
-		*maxbin_out = wrd_lowpass_maxbin(passband, input_rate);
+		*maxbin_out = wrd_lowpass_maxbin(WR_FIR_LENGTH, passband, input_rate);
+	return WR_OK;
+}
+
+static bool fir_length_ok(unsigned int n)
+{
+	return n >= 2 && n <= WR_FIR_MAX && (n & (n - 1)) == 0;
+}
+
+extern "C" int wr_lowpass_design_n(unsigned int fir_length, unsigned int passband, unsigned int input_rate,
+                                   float *coeff_host, unsigned int *maxbin_out)
+{
+	if (!coeff_host || !input_rate)
+		return fail(WR_ERR_ARG, "wr_lowpass_design_n: bad argument");
+	if (!fir_length_ok(fir_length))
+		return fail(WR_ERR_ARG, "wr_lowpass_design_n: fir_length %u is not a power of two in [2, %d]", fir_length,
+		            WR_FIR_MAX);
+	wrd_lowpass_design(fir_length, passband, input_rate, coeff_host);
+	if (maxbin_out)
+		*maxbin_out = wrd_lowpass_maxbin(fir_length, passband, input_rate);
 	return WR_OK;
 }
 
@@ -267,7 +286,7 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 		if ((e = hipMalloc((void **)&d->table, WR_TABLE_SIZE * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMalloc((void **)&d->hi_cs, 2 * WR_SPLIT_N * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMalloc((void **)&d->lo_cs, 2 * WR_SPLIT_N * sizeof(float))) != hipSuccess) break;
-		if ((e = hipMalloc((void **)&d->coeff, WR_FIR_LENGTH * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&d->coeff, WR_FIR_MAX * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMemcpy(d->table, table.data(), WR_TABLE_SIZE * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
 		if ((e = hipMemcpy(d->hi_cs, hi.data(), 2 * WR_SPLIT_N * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
 		if ((e = hipMemcpy(d->lo_cs, lo.data(), 2 * WR_SPLIT_N * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
@@ -365,21 +384,31 @@ extern "C" int wr_mix(wr_dev *d, const float *in_dev, float *out_dev, size_t nfr
 	return WR_OK;
 }
 
-extern "C" int wr_fir_decimate(wr_dev *d, const float *in_dev, size_t nframes, unsigned int channels,
-                               unsigned int decimation, const float *coeff_host, float *history_dev,
-                               float *out_dev)
+extern "C" int wr_fir_decimate_n(wr_dev *d, const float *in_dev, size_t nframes, unsigned int channels,
+                                 unsigned int decimation, unsigned int fir_length, const float *coeff_host,
+                                 float *history_dev, float *out_dev)
 {
 	if (!d || !coeff_host || !history_dev || !channels || !decimation ||
 	    (nframes && (!in_dev || !out_dev)))
 		return fail(WR_ERR_ARG, "wr_fir_decimate: bad argument");
-	int rc = dev_scratch(d, (size_t)WR_HIST * channels);
+	if (!fir_length_ok(fir_length))
+		return fail(WR_ERR_ARG, "wr_fir_decimate: fir_length %u is not a power of two in [2, %d]", fir_length,
+		            WR_FIR_MAX);
+	int rc = dev_scratch(d, (size_t)(fir_length - 1) * channels);
 	if (rc)
 		return rc;
-	HIP_TRY(hipMemcpyAsync(d->coeff, coeff_host, WR_FIR_LENGTH * sizeof(float),
-	                       hipMemcpyHostToDevice, d->stream));
-	HIP_TRY(wrk_fir(d->stream, in_dev, nframes, channels, decimation, d->coeff, history_dev, out_dev));
-	HIP_TRY(wrk_hist_update(d->stream, in_dev, nframes, channels, history_dev, d->scratch));
+	HIP_TRY(hipMemcpyAsync(d->coeff, coeff_host, fir_length * sizeof(float), hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(wrk_fir(d->stream, in_dev, nframes, channels, decimation, fir_length, d->coeff, history_dev, out_dev));
+	HIP_TRY(wrk_hist_update(d->stream, in_dev, nframes, channels, fir_length, history_dev, d->scratch));
 	return WR_OK;
+}
+
+extern "C" int wr_fir_decimate(wr_dev *d, const float *in_dev, size_t nframes, unsigned int channels,
+                               unsigned int decimation, const float *coeff_host, float *history_dev,
+                               float *out_dev)
+{
+	return wr_fir_decimate_n(d, in_dev, nframes, channels, decimation, WR_FIR_LENGTH, coeff_host, history_dev,
+	                         out_dev);
 }
 
 extern "C" int wr_demod(wr_dev *d, int mode, const float *in_dev, size_t nframes, float *prev_io,
@@ -788,7 +817,7 @@ extern "C" int wr_chan_set_filter(wr_tuner *t, int chan, int stage, unsigned int
 	if (in_rate / decim != out_rate || in_rate % out_rate)
 		return fail(WR_ERR_RATE, "Sample rates must be integer related (%u -> %u)", in_rate, out_rate);
 	float coeff[WR_FIR_LENGTH];
-	wrd_lowpass_design(passband, in_rate, coeff);
+	wrd_lowpass_design(WR_FIR_LENGTH, passband, in_rate, coeff);
 	return set_taps_common(t, chan, stage, coeff, decim);
 }
 

@@ -39,25 +39,26 @@ int wrd_phase_step(int if_hz, unsigned int input_rate)
 
 /* dsp/lowpass.cxx:167 -- 32-bit unsigned arithmetic, evaluated left to right, so the
  * product wraps for passbands above 2^32/64 Hz and narrow passbands give bin 0. */
-unsigned wrd_lowpass_maxbin(unsigned int passband, unsigned int input_rate)
+unsigned wrd_lowpass_maxbin(unsigned int L, unsigned int passband, unsigned int input_rate)
 {
-	unsigned int scaled = (unsigned int)WR_FIR_LENGTH * passband;
+	unsigned int scaled = L * passband;               /* wraps modulo 2^32 like lowpass.cxx:167 */
 	return scaled / input_rate / 2u;
 }
 
 /* LowPass::init window (dsp/lowpass.cxx:104-110) and LowPass::recalculate
  * (dsp/lowpass.cxx:164-189).
  *
- * The reference fills a 64-bin real, even spectrum with ones below `maxbin`, runs an
- * unnormalised inverse DFT and keeps Re(impulse[(n+32)&63]) * window[n].  For that
- * 0/1 even spectrum the inverse DFT has the closed form of a Dirichlet kernel,
- *      impulse[m] = e0 + 2*sum_{b=1}^{maxbin-1} cos(2*pi*b*m/64)      (+ Nyquist term)
- * which is what is evaluated here (in double, narrowed once).  Bins run to 32
- * inclusive (lowpass.cxx:173), so maxbin = 33 would also switch the Nyquist bin on. */
-void wrd_lowpass_design(unsigned int passband, unsigned int input_rate, float *coeff)
+ * The reference fills an L-bin real, even spectrum (L = _firLength, 64 as compiled) with ones
+ * below `maxbin`, runs an unnormalised inverse DFT and keeps Re(impulse[(n+L/2)&(L-1)]) *
+ * window[n].  For that 0/1 even spectrum the inverse DFT has the closed form of a Dirichlet
+ * kernel,
+ *      impulse[m] = e0 + 2*sum_{b=1}^{maxbin-1} cos(2*pi*b*m/L)      (+ Nyquist term)
+ * which is what is evaluated here (in double, narrowed once).  Bins run to L/2 inclusive
+ * (lowpass.cxx:173), so maxbin = L/2+1 would also switch the Nyquist bin on.  L is a power of
+ * two (the mask logic of lowpass.cxx:172,184). */
+void wrd_lowpass_design(unsigned int L, unsigned int passband, unsigned int input_rate, float *coeff)
 {
-	const unsigned int L = WR_FIR_LENGTH;
-	const unsigned int maxbin = wrd_lowpass_maxbin(passband, input_rate);
+	const unsigned int maxbin = wrd_lowpass_maxbin(L, passband, input_rate);
 
 	for (unsigned int n = 0; n < L; ++n) {
 		/* window sample, float arithmetic where the reference's is float */
@@ -70,10 +71,10 @@ void wrd_lowpass_design(unsigned int passband, unsigned int input_rate, float *c
 		if (maxbin > 0)
 			acc += 1.0;                                   /* bin 0 */
 		for (unsigned int b = 1; b < maxbin && b < L / 2; ++b) {
-			unsigned int turn = (b * m) & (L - 1);        /* exact reduction of b*m/64 turns */
+			unsigned int turn = (b * m) & (L - 1);        /* exact reduction of b*m/L turns */
 			acc += 2.0 * cos(2.0 * kPi * (double)turn / (double)L);
 		}
-		if (maxbin > L / 2)                               /* bin 32 switched on */
+		if (maxbin > L / 2)                               /* bin L/2 switched on */
 			acc += (m & 1u) ? -1.0 : 1.0;
 		coeff[n] = (float)acc * w;
 	}

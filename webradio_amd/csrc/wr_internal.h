@@ -19,8 +19,8 @@
 /* ---- host design math (wr_design.cpp) ---- */
 void     wrd_sin_table(float *table);
 int      wrd_phase_step(int if_hz, unsigned int input_rate);
-unsigned wrd_lowpass_maxbin(unsigned int passband, unsigned int input_rate);
-void     wrd_lowpass_design(unsigned int passband, unsigned int input_rate, float *coeff);
+unsigned wrd_lowpass_maxbin(unsigned int fir_length, unsigned int passband, unsigned int input_rate);
+void     wrd_lowpass_design(unsigned int fir_length, unsigned int passband, unsigned int input_rate, float *coeff);
 void     wrd_spectrum_window(unsigned int n, float *window);
 void     wrd_split_tables(float *hi_cs /* [256][2] cos,sin */, float *lo_cs /* [256][2] */);
 void     wrd_twiddles(unsigned int n, float *tw /* [n/2][2] cos,-sin of 2*pi*k/n */);
@@ -70,9 +70,10 @@ struct WrTunerLaunch {
 hipError_t wrk_mix(hipStream_t st, const float *in, float *out, size_t nframes,
                    unsigned int phase, int step, const float *table_dev);
 hipError_t wrk_fir(hipStream_t st, const float *in, size_t nframes, unsigned int channels,
-                   unsigned int decim, const float *coeff_dev, const float *hist_dev, float *out);
+                   unsigned int decim, unsigned int fir_length, const float *coeff_dev, const float *hist_dev,
+                   float *out);
 hipError_t wrk_hist_update(hipStream_t st, const float *in, size_t nframes, unsigned int channels,
-                           float *hist_dev, float *scratch_dev);
+                           unsigned int fir_length, float *hist_dev, float *scratch_dev);
 hipError_t wrk_demod(hipStream_t st, int mode, const float *in, size_t nframes, float prev_i,
                      float prev_q, float *out);
 hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t count);

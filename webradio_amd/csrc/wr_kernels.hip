@@ -54,42 +54,44 @@ k_mix(const float2 *__restrict__ in, float2 *__restrict__ out, size_t nframes,
 	}
 }
 
-/* LowPass::process (dsp/lowpass.cxx:131-162): out[k][c] = sum_j coeff[63-j] *
+/* LowPass::process (dsp/lowpass.cxx:131-162): out[k][c] = sum_j coeff[L-1-j] *
  * block[(k*D + j)][c], accumulated oldest sample first starting from 0.0f.
- * block = [63 history frames][input]; one thread per output float. */
+ * block = [L-1 history frames][input]; one thread per output float.  L = _firLength is a
+ * run-time value here (the reference compiles in 64, lowpass.cxx:38-39). */
 __global__ void __launch_bounds__(256)
 k_fir(const float *__restrict__ in, size_t outfloats, unsigned int channels, unsigned int decim,
-      const float *__restrict__ coeff, const float *__restrict__ hist, float *__restrict__ out)
+      unsigned int L, const float *__restrict__ coeff, const float *__restrict__ hist, float *__restrict__ out)
 {
-	__shared__ float taps[WR_FIR_LENGTH];
-	if (threadIdx.x < WR_FIR_LENGTH)
-		taps[threadIdx.x] = coeff[threadIdx.x];
+	__shared__ float taps[WR_FIR_MAX];
+	for (unsigned int j = threadIdx.x; j < L; j += blockDim.x)
+		taps[j] = coeff[j];
 	__syncthreads();
+	const unsigned int nh = L - 1u;
 	size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < outfloats; o += stride) {
 		size_t k = o / channels;
 		unsigned int c = (unsigned int)(o - k * channels);
 		size_t first = k * decim;               /* index into [hist|in] in frames */
 		float acc = 0.0f;
-		for (unsigned int j = 0; j < WR_FIR_LENGTH; ++j) {
+		for (unsigned int j = 0; j < L; ++j) {
 			size_t f = first + j;
-			float x = (f < WR_HIST) ? hist[f * channels + c] : in[(f - WR_HIST) * channels + c];
-			acc = acc + taps[WR_FIR_LENGTH - 1 - j] * x;
+			float x = (f < nh) ? hist[f * channels + c] : in[(f - nh) * channels + c];
+			acc = acc + taps[L - 1u - j] * x;
 		}
 		out[o] = acc;
 	}
 }
 
-/* next history = last 63 frames of [hist|in] (dsp/lowpass.cxx:138-142); written to
+/* next history = last L-1 frames of [hist|in] (dsp/lowpass.cxx:138-142); written to
  * scratch first because for short blocks source and destination overlap */
-__global__ void k_hist_build(const float *__restrict__ in, size_t nframes, unsigned int channels,
+__global__ void k_hist_build(const float *__restrict__ in, size_t nframes, unsigned int channels, unsigned int nh,
                              const float *__restrict__ hist, float *__restrict__ scratch)
 {
-	unsigned int total = WR_HIST * channels;
+	unsigned int total = nh * channels;
 	for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
 		size_t f = nframes + e / channels;      /* frame index in [hist|in] */
 		unsigned int c = e % channels;
-		scratch[e] = (f < WR_HIST) ? hist[f * channels + c] : in[(f - WR_HIST) * channels + c];
+		scratch[e] = (f < nh) ? hist[f * channels + c] : in[(f - nh) * channels + c];
 	}
 }
 
@@ -1070,21 +1072,25 @@ hipError_t wrk_mix(hipStream_t st, const float *in, float *out, size_t nframes,
 }
 
 hipError_t wrk_fir(hipStream_t st, const float *in, size_t nframes, unsigned int channels,
-                   unsigned int decim, const float *coeff_dev, const float *hist_dev, float *out)
+                   unsigned int decim, unsigned int fir_length, const float *coeff_dev, const float *hist_dev,
+                   float *out)
 {
 	size_t outfloats = (nframes / decim) * channels;
 	if (!outfloats)
 		return hipSuccess;
-	k_fir<<<grid_for(outfloats, 256, 4096), 256, 0, st>>>(in, outfloats, channels, decim, coeff_dev,
+	k_fir<<<grid_for(outfloats, 256, 4096), 256, 0, st>>>(in, outfloats, channels, decim, fir_length, coeff_dev,
 	                                                      hist_dev, out);
 	return hipGetLastError();
 }
 
 hipError_t wrk_hist_update(hipStream_t st, const float *in, size_t nframes, unsigned int channels,
-                           float *hist_dev, float *scratch_dev)
+                           unsigned int fir_length, float *hist_dev, float *scratch_dev)
 {
-	unsigned int total = WR_HIST * channels;
-	k_hist_build<<<grid_for(total, 256, 64), 256, 0, st>>>(in, nframes, channels, hist_dev, scratch_dev);
+	unsigned int total = (fir_length - 1u) * channels;
+	if (!total)
+		return hipSuccess;
+	k_hist_build<<<grid_for(total, 256, 64), 256, 0, st>>>(in, nframes, channels, fir_length - 1u, hist_dev,
+	                                                      scratch_dev);
 	k_copy_f32<<<grid_for(total, 256, 64), 256, 0, st>>>(scratch_dev, hist_dev, total);
 	return hipGetLastError();
 }

@@ -69,9 +69,9 @@ class Device:
         nout = (nframes // decimation) * channels
         din = self.upload(x)
         dout = self.malloc(max(nout * 4, 4))
-        coeff = np.ascontiguousarray(coeff, dtype=np.float32)
-        check(self.lib.wr_fir_decimate(self.h, C.c_void_p(din), nframes, channels, decimation,
-                                       ptr(coeff), C.c_void_p(history_dev), C.c_void_p(dout)))
+        coeff = np.ascontiguousarray(coeff, dtype=np.float32)     # its length is LowPass::_firLength
+        check(self.lib.wr_fir_decimate_n(self.h, C.c_void_p(din), nframes, channels, decimation, coeff.size,
+                                         ptr(coeff), C.c_void_p(history_dev), C.c_void_p(dout)))
         out = self.download(dout, nout)
         self.free(din)
         self.free(dout)

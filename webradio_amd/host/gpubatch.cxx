@@ -209,6 +209,8 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 		return NULL;
 	if (f1->_channel || dm->_channel || f2->_channel)
 		return NULL;
+	if (f1->firLength() != WR_FIR_LENGTH || f2->firLength() != WR_FIR_LENGTH)
+		return NULL;                         /* the fused kernels are built for the reference's 64 taps */
 
 	TunerBatch *batch = src->batch();
 	if (!batch) {

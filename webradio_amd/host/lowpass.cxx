@@ -1,7 +1,8 @@
 /*
- * lowpass.cxx -- host side of the 64-tap decimating FIR block (webradio src/dsp/lowpass.cxx).
- * Tap design is one-off host work (wr_lowpass_design restates lowpass.cxx:164-197); the
- * filtering runs on the GPU, fused into the tuner batch or as wr_fir_decimate.
+ * lowpass.cxx -- host side of the decimating FIR block (webradio src/dsp/lowpass.cxx; 64 taps
+ * unless setFirLength says otherwise).  Tap design is one-off host work (wr_lowpass_design_n
+ * restates lowpass.cxx:164-197); the filtering runs on the GPU, fused into the tuner batch
+ * (64 taps) or as wr_fir_decimate_n.
  */
 #include "lowpass.h"
 
@@ -9,7 +10,7 @@
 #include "gpubatch.h"
 
 LowPass::LowPass(const string &name)
-	: DspBlock(name, "LowPass"), _passband(0), _reqDecimation(0), _reqOutputRate(DEFAULT_SAMPLE_RATE),
+	: DspBlock(name, "LowPass"), _firLength(WR_FIR_LENGTH), _passband(0), _reqDecimation(0), _reqOutputRate(DEFAULT_SAMPLE_RATE),
 	  _channel(NULL), _stage(-1), _in(new wrhost::DevBuf()), _out(new wrhost::DevBuf()),
 	  _history(new wrhost::DevBuf())
 {
@@ -27,6 +28,17 @@ void LowPass::setPassband(unsigned int hz)
 	_passband = hz;
 	if (isRunning())
 		recalculate();
+}
+
+void LowPass::setFirLength(unsigned int n)
+{
+	if (isRunning())
+		return;
+	if (n < 2 || n > WR_FIR_MAX || (n & (n - 1)) != 0) {
+		LOG_ERROR("FIR length %u is not a power of two in [2, %d]\n", n, WR_FIR_MAX);
+		return;
+	}
+	_firLength = n;
 }
 
 /* asking for a decimation cancels a requested rate and vice versa; both are ignored while
@@ -62,7 +74,7 @@ bool LowPass::init()
 	if (!_channel) {
 		/* stand-alone: an empty history, as a fresh LowPass::block (lowpass.cxx:138-139) */
 		wr_dev *dev = wrhost::deviceFor(this);
-		const size_t bytes = (size_t)(WR_FIR_LENGTH - 1) * inputChannels() * sizeof(float);
+		const size_t bytes = (size_t)(_firLength - 1) * inputChannels() * sizeof(float);
 		if (!dev)
 			return false;
 		_history->release();             /* wr_dev_malloc zero-fills */
@@ -83,8 +95,8 @@ void LowPass::deinit()
 
 void LowPass::recalculate()
 {
-	_coeff.resize(WR_FIR_LENGTH);
-	wr_lowpass_design(_passband, inputSampleRate(), _coeff.data(), NULL);
+	_coeff.resize(_firLength);
+	wr_lowpass_design_n(_firLength, _passband, inputSampleRate(), _coeff.data(), NULL);
 	wrhost::TunerBatch::markDirty(_channel);
 }
 
@@ -103,7 +115,7 @@ bool LowPass::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuf
 	if (!dev || !_in->reserve(dev, inBytes) || !_out->reserve(dev, outBytes) || !_history->ptr)
 		return false;
 	if (wr_dev_upload(dev, _in->ptr, inBuffer.data(), inBytes) != WR_OK ||
-	    wr_fir_decimate(dev, (const float *)_in->ptr, nframes, ch, decimation(), _coeff.data(),
+	    wr_fir_decimate_n(dev, (const float *)_in->ptr, nframes, ch, decimation(), _firLength, _coeff.data(),
 	                    (float *)_history->ptr, (float *)_out->ptr) != WR_OK ||
 	    wr_dev_download(dev, outBuffer.data(), _out->ptr, outBytes) != WR_OK) {
 		LOG_ERROR("LowPass: %s\n", wr_last_error());

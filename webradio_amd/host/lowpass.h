@@ -25,6 +25,13 @@ public:
 	void setPassband(unsigned int hz);
 	void setDecimation(unsigned int n);
 	void setOutputSampleRate(unsigned int hz);
+	/* The reference compiles the FIR length in ("FIXME: Make runtime variable",
+	 * dsp/lowpass.cxx:38-39) although init()/recalculate()/process() are written in terms of
+	 * _firLength.  Extension: a power of two in [2, 1024], default 64, ignored while running.
+	 * A chain whose filters are not both 64 taps long runs block by block instead of inside the
+	 * fused tuner batch. */
+	void setFirLength(unsigned int n);
+	unsigned int firLength() const { return _firLength; }
 
 private:
 	bool init();
@@ -32,10 +39,11 @@ private:
 	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer);
 	void recalculate();
 
+	unsigned int	_firLength;
 	unsigned int	_passband;
 	unsigned int	_reqDecimation;
 	unsigned int	_reqOutputRate;
-	vector<float>	_coeff;			/* 64 taps, lowpass.cxx:183-189 */
+	vector<float>	_coeff;			/* _firLength taps, lowpass.cxx:183-189 */
 	wrhost::Channel*	_channel;
 	int				_stage;			/* 0 channel filter, 1 audio filter of an enrolled chain */
 	wrhost::DevBuf*	_in;
