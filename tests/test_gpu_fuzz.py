@@ -2,6 +2,8 @@
 IFs over the whole band (negative, zero, near Nyquist), passbands incl. the degenerate
 maxbin = 0, all four detectors mixed in one tuner, decimations below and above the FIR length,
 ragged block sizes, retunes / mode / passband changes between blocks."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,7 @@ RATES = [  # (fs, chan_rate, audio_rate): integer related
 ]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "12"))))
 def test_random_configuration(dev, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     fs, crate, arate = RATES[seed % len(RATES)]
@@ -39,6 +41,8 @@ def test_random_configuration(dev, oracle, seed):
     for c in range(nchan):
         rxs.append(oracle.Receiver(fs, ifs[c], cpbs[c], crate, modes[c], apbs[c], arate))
         chans.append(t.add_receiver(ifs[c], cpbs[c], crate, modes[c], apbs[c], arate))
+    # the audio filter is linear: an error of e in its input gives at most e * sum|taps| out
+    again = [max(1.0, float(np.abs(oracle.lowpass_design(apbs[c], crate)).sum())) for c in range(nchan)]
     carriers = [ifs[c] for c in range(0, nchan, max(1, nchan // 4))][:4]
     # a channel that has ever run the FM detector carries device-atan2f values in its audio
     # filter history: within tolerance, no longer bit-exact
@@ -71,14 +75,15 @@ def test_random_configuration(dev, oracle, seed):
             else:
                 assert np.abs(gc - wc).max() <= 1e-6, (seed, b, c)
                 if modes[c] != capi.WR_FM and wa.size:
-                    assert np.abs(ga - wa).max() <= 2e-6, (seed, b, c)
+                    # detector input within 1e-6 (USB/LSB add two components: 2e-6)
+                    assert np.abs(ga - wa).max() <= 2e-6 * again[c], (seed, b, c)
     for c in range(nchan):
         ph, _ = t.state(chans[c])
         assert ph == rxs[c].s.phase
     t.destroy()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "8"))))
 def test_random_spectrum_streams(dev, oracle, seed):
     """SpectrumSink: random size, hop and push chunking against the oracle (which is fed, for
     hops below the frame size, the overlapped frames explicitly)."""
@@ -109,7 +114,7 @@ def test_random_spectrum_streams(dev, oracle, seed):
     s.destroy()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "6"))))
 def test_random_standalone_blocks(dev, oracle, seed):
     """mix / fir / demod kernels with random geometry: bit-exact (FM within atan2f ulps)."""
     rng = np.random.default_rng(900 + seed)
