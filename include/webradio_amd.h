@@ -75,7 +75,7 @@ enum wr_nco {
 	                            phase), but each LO value is reached by turning the previous
 	                            one by one of the two table angles the step allows, folded
 	                            into the FIR as a Horner recurrence: no table access per tap.
-	                            Channel IQ within 4e-6 relative of the reference */
+	                            Channel IQ within 2e-7 of the bit-exact path for |x| <= 1 */
 };
 
 enum wr_where { WR_HOST = 0, WR_DEVICE = 1 };

@@ -45,6 +45,7 @@ struct wr_dev {
 	bool own_stream;
 	int num_cus;
 	float *table;              /* [65536] reference sine table */
+	float *table_turn;         /* [65536] correctly rounded sin(2 pi i / 65536): WR_NCO_ROTATE's turns */
 	float *hi_cs, *lo_cs;      /* [256][2] split NCO tables */
 	float *scratch;            /* growable scratch */
 	size_t scratch_floats;
@@ -278,12 +279,15 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	d->stream = (hipStream_t)hip_stream;
 	d->own_stream = false;
 
-	std::vector<float> table(WR_TABLE_SIZE), hi(2 * WR_SPLIT_N), lo(2 * WR_SPLIT_N);
+	std::vector<float> table(WR_TABLE_SIZE), turn(WR_TABLE_SIZE), hi(2 * WR_SPLIT_N), lo(2 * WR_SPLIT_N);
 	wrd_sin_table(table.data());
+	wrd_sin_table_rounded(turn.data());
 	wrd_split_tables(hi.data(), lo.data());
 	int rc = WR_OK;
 	do {
 		if ((e = hipMalloc((void **)&d->table, WR_TABLE_SIZE * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMalloc((void **)&d->table_turn, WR_TABLE_SIZE * sizeof(float))) != hipSuccess) break;
+		if ((e = hipMemcpy(d->table_turn, turn.data(), WR_TABLE_SIZE * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
 		if ((e = hipMalloc((void **)&d->hi_cs, 2 * WR_SPLIT_N * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMalloc((void **)&d->lo_cs, 2 * WR_SPLIT_N * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMalloc((void **)&d->coeff, WR_FIR_MAX * sizeof(float))) != hipSuccess) break;
@@ -307,6 +311,7 @@ extern "C" int wr_dev_close(wr_dev *d)
 	(void)hipSetDevice(d->device);
 	(void)hipStreamSynchronize(d->stream);
 	(void)hipFree(d->table);
+	(void)hipFree(d->table_turn);
 	(void)hipFree(d->hi_cs);
 	(void)hipFree(d->lo_cs);
 	(void)hipFree(d->coeff);
@@ -1137,7 +1142,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		hipStream_t ps = t->overlap ? t->post_stream : st;
 		if (t->overlap && g->ev_demod_valid[g->cb])
 			HIP_TRY(hipStreamWaitEvent(st, g->ev_demod[g->cb], 0));
-		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, d->table, d->hi_cs, d->lo_cs, d->num_cus));
+		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
+		                      d->num_cus));
 		if (prof_now) {
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
 			t->ev_used += 2;

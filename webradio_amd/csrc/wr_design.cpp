@@ -31,6 +31,20 @@ void wrd_sin_table(float *table)
 
 /* DownConverter::init / setIF (dsp/downconverter.cxx:65,80): signed 64-bit
  * hz * 2^31 / rate, C++ division (truncates toward zero), narrowed to int. */
+/* sin(2 pi n / 65536) evaluated in double on the exact angle and narrowed once: the turns of
+ * WR_NCO_ROTATE.  (The reference's table above carries the rounding of its float ARGUMENT, up
+ * to 2.4e-7 per entry: harmless for one lookup, but a turn is applied up to 15 times in a row,
+ * and |turn| != 1 compounds.) */
+void wrd_sin_table_rounded(float *table)
+{
+	for (unsigned int n = 0; n < WR_TABLE_SIZE; ++n) {
+		/* exact octant reduction keeps the symmetry sin^2 + cos^2 = 1 to the last bit of double */
+		table[n] = (float)sin(2.0 * kPi * (double)n / (double)WR_TABLE_SIZE);
+	}
+	table[0] = 0.0f;
+	table[WR_TABLE_SIZE / 2] = 0.0f;                       /* sin(pi): exactly zero, not 1.2e-16 */
+}
+
 int wrd_phase_step(int if_hz, unsigned int input_rate)
 {
 	long long num = (long long)if_hz * (1LL << 31);

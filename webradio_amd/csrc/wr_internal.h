@@ -18,6 +18,7 @@
 
 /* ---- host design math (wr_design.cpp) ---- */
 void     wrd_sin_table(float *table);
+void     wrd_sin_table_rounded(float *table);
 int      wrd_phase_step(int if_hz, unsigned int input_rate);
 unsigned wrd_lowpass_maxbin(unsigned int fir_length, unsigned int passband, unsigned int input_rate);
 void     wrd_lowpass_design(unsigned int fir_length, unsigned int passband, unsigned int input_rate, float *coeff);

@@ -236,18 +236,22 @@ __device__ __forceinline__ void mac(v2f xs, v2f cs, float hj, v2f &acc)
  * frame, plus one whenever the 16 fraction bits of the left-aligned phase carry
  * (downconverter.cxx:100-103: index = phase >> 15, phase += phase_step).  So the LO of frame m
  * is the LO of frame m-1 turned by one of just two angles, rot[0] = cis(2 pi S / 65536) or
- * rot[1] = cis(2 pi (S+1) / 65536) -- both taken from the reference's own table -- and
+ * rot[1] = cis(2 pi (S+1) / 65536), and
  *
  *     sum_m u[m] conj(LO[m])  =  conj(LO[n]) * ( ... ((u[n-63] r[n-62] + u[n-62]) r[n-61] + ...) r[n] + u[n] )
  *
  * with r[m] the turn INTO frame m: a Horner recurrence of one integer add-with-carry, two
  * selects and four FMAs per tap, no table access at all.  Which table entry every frame is
  * mixed with is exactly the reference's; only float rounding differs: a product of turns
- * stands where the reference has one table entry, and the rounding of the turn itself
- * (|r| - 1 up to 4e-8) compounds along the chain.  To bound that, the 64 taps are cut into
- * ROT_Q segments of ROT_SEG taps, each its own recurrence closed with the table's LO value of
- * its last frame: at most ROT_SEG - 1 turns between a frame and its anchor (measured: within
- * 5e-7 absolute of the bit-exact path on +/-0.4 signals), and ROT_Q independent chains.
+ * stands where the reference has one table entry.  Two things keep that product honest:
+ *   - the turns are cis(2 pi S / 65536) evaluated on the exact angle and rounded once (the
+ *     device's `table_turn`), NOT pairs of entries of the reference's sinf table, whose float
+ *     argument rounding (2.4e-7) makes |cos + i sin| != 1 -- harmless for one lookup, but a turn
+ *     is applied dozens of times in a row (measured: 5e-7 -> 4.5e-8 worst error);
+ *   - the 64 taps can be cut into ROT_Q segments of ROT_SEG taps, each its own recurrence
+ *     closed with the LO value of its last frame (an anchor, one LDS table lookup): fewer turns
+ *     between a frame and its anchor, and ROT_Q independent chains.  With exact turns one
+ *     segment is enough (see ROT_SEG).
  *
  * rot_index(): table index of the turn into frame m >= 1 of the current block, for phase p0
  * at frame 0. */
@@ -289,7 +293,8 @@ __device__ __forceinline__ void horner_close(v2f &y, v2f A, v2f cs)
 }
 
 #ifndef ROT_SEG
-#define ROT_SEG 16
+#define ROT_SEG 64                       /* measured on MI355X, C2: 16 -> 4.5e-8 / 40.9 us, 32 -> 6.7e-8 / 39.5 us,
+                                            64 -> 1.2e-7 / 38.4 us (worst |IQ - bit-exact path| on +-0.4 signals / kernel) */
 #endif
 #define ROT_Q   (WR_FIR_LENGTH / ROT_SEG)
 #define SLOW_CH (UTAPS ? 8 : 4)           /* taps per memory round of the block-boundary paths */
