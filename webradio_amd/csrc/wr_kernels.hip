@@ -297,7 +297,7 @@ __device__ __forceinline__ void horner_close(v2f &y, v2f A, v2f cs)
                                             64 -> 1.2e-7 / 38.4 us (worst |IQ - bit-exact path| on +-0.4 signals / kernel) */
 #endif
 #define ROT_Q   (WR_FIR_LENGTH / ROT_SEG)
-#define SLOW_CH (UTAPS ? 8 : 4)           /* taps per memory round of the block-boundary paths */
+#define SLOW_CH 4                          /* taps per memory round of the block-boundary paths */
 
 /* SPLIT NCO: issue the two LDS gathers for left-aligned phase P.  LDS byte address =
  * table base | index << 8 | (lane & 31) << 3; the index byte of P is dropped straight
@@ -358,12 +358,13 @@ __device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, co
 #define DDC_WAVES         16u
 #endif
 #ifndef DDC_ROTATE_WGS_PER_CU
-#define DDC_ROTATE_WGS_PER_CU 1u
+#define DDC_ROTATE_WAVES      8u
+#define DDC_ROTATE_WGS_PER_CU 4u
 #endif
 #define DDC_LDS_BYTES     (DDC_TABLE_BYTES + DDC_WAVES * 2u * 512u)
 
 template <int NCO, bool UTAPS>
-__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && UTAPS ? DDC_ROTATE_WGS_PER_CU * DDC_WAVES / 4u : DDC_WAVES / 4u)))
+__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && UTAPS ? DDC_ROTATE_WGS_PER_CU * DDC_ROTATE_WAVES / 4u : DDC_WAVES / 4u)))
 k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist,
             float2 *__restrict__ hist_next, size_t nframes, size_t k1,
@@ -1118,12 +1119,45 @@ hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t c
 	return hipGetLastError();
 }
 
+/* launch geometry of k_tuner_ddc<NCO, UTAPS> (waves per workgroup, persistent workgroups per CU):
+ *   ROTATE, uniform taps : 8 x 4 -- 64 VGPRs, 20 KiB of LDS: 8 waves per SIMD hide the recurrence's
+ *                                  dependent FMAs better than 4 (measured 35.6 -> 34.7 us)
+ *   ROTATE, per-lane taps: 16 x 1 -- one lane group's taps (16 KiB) per workgroup
+ *   SPLIT                : 16 x 1 -- the replicated tables take 128 KiB
+ *   EXACT                : 16 x 2 -- small LDS footprint, two workgroups hide the gather latency */
+template <int NCO, bool UTAPS> struct DdcGeom {
+	static constexpr unsigned int waves = (NCO == WR_NCO_ROTATE && UTAPS) ? DDC_ROTATE_WAVES : DDC_WAVES;
+	static constexpr unsigned int wgs_per_cu = (NCO == WR_NCO_ROTATE && UTAPS) ? DDC_ROTATE_WGS_PER_CU
+	                                           : (NCO == WR_NCO_EXACT) ? 2u : 1u;
+};
+
 template <int NCO, bool UTAPS>
-static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaunch &L, const WrGroupDev &G,
-                             const float *table_dev, const float *hi_dev, const float *lo_dev)
+static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
+                             const float *table_dev, const float *hi_dev, const float *lo_dev, int num_cus)
 {
+	constexpr unsigned int W = DdcGeom<NCO, UTAPS>::waves;
+	const unsigned int ngroups = L.slots_used / 64;
+	/* launched even for a block too short to yield a channel-rate frame: workgroup 0 still
+	 * advances the NCO (downconverter.cxx:103 runs per input frame) and rolls the histories */
+	const size_t units = L.k1 * ngroups;
+	unsigned int wgs = (unsigned int)((units + W - 1) / W);
+	const unsigned int cap = (unsigned int)num_cus * DdcGeom<NCO, UTAPS>::wgs_per_cu;
+	if (wgs > cap)
+		wgs = cap;
+	if (NCO == WR_NCO_ROTATE && !UTAPS) {
+		/* per-lane taps live in LDS, one lane group per WORKGROUP: a whole number of
+		 * workgroups per group, at least one */
+		wgs = (wgs / ngroups) * ngroups;
+		if (wgs < ngroups)
+			wgs = ngroups;
+	} else {
+		/* every lane group needs at least one wave of its own (the kernel deals waves to groups) */
+		const unsigned int min_wgs = (ngroups + W - 1) / W;
+		if (wgs < min_wgs)
+			wgs = min_wgs;
+	}
 	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
-	                   : (DDC_WAVES * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
+	                   : (W * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
 	                     + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
 	static bool attr_done[WR_MAX_DEVICES];
 	if (lds > 64 * 1024) {
@@ -1131,10 +1165,10 @@ static hipError_t launch_ddc(hipStream_t st, unsigned int wgs, const WrTunerLaun
 		if (e != hipSuccess)
 			return e;
 	}
-	k_tuner_ddc<NCO, UTAPS><<<wgs, DDC_WAVES * 64u, lds, st>>>(
+	k_tuner_ddc<NCO, UTAPS><<<wgs, W * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
-		L.slots, L.slots_used / 64, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
+		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
 		(float2 *)G.chan_iq[L.cb], table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev);
@@ -1147,43 +1181,13 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 {
 	if (!L.slots_used)
 		return hipSuccess;
-	/* launched even for a block too short to yield a channel-rate frame: workgroup 0 still
-	 * advances the NCO (downconverter.cxx:103 runs per input frame) and rolls the histories */
-	const size_t units = L.k1 * (L.slots_used / 64);
-	unsigned int wgs = (unsigned int)((units + DDC_WAVES - 1) / DDC_WAVES);
-	/* every lane group needs at least one wave of its own (the kernel deals waves to groups) */
-	const unsigned int min_wgs = (L.slots_used / 64 + DDC_WAVES - 1) / DDC_WAVES;
-	if (wgs < min_wgs)
-		wgs = min_wgs;
-	if (L.nco_mode == WR_NCO_EXACT) {
-		/* small LDS footprint: two workgroups per CU hide the gather latency */
-		unsigned int cap = (unsigned int)num_cus * 2u;
-		if (wgs > cap)
-			wgs = cap;
-		return launch_ddc<WR_NCO_EXACT, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
-	}
-	if (L.nco_mode == WR_NCO_ROTATE) {
-		/* uniform taps: 64 VGPRs, two workgroups per CU; per-lane taps need 64 more registers */
-		unsigned int cap = (unsigned int)num_cus * (L.uniform_taps ? DDC_ROTATE_WGS_PER_CU : 1u);
-		if (wgs > cap)
-			wgs = cap;
-		if (L.uniform_taps)
-			return launch_ddc<WR_NCO_ROTATE, true>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
-		/* per-lane taps live in LDS, one lane group per WORKGROUP: a whole number of
-		 * workgroups per group, at least one */
-		const unsigned int ngroups = L.slots_used / 64;
-		wgs = (wgs / ngroups) * ngroups;
-		if (wgs < ngroups)
-			wgs = ngroups;
-		return launch_ddc<WR_NCO_ROTATE, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
-	}
-	/* the replicated tables take 128 KiB: one persistent workgroup per CU */
-	unsigned int cap = (unsigned int)num_cus;
-	if (wgs > cap)
-		wgs = cap;
-	if (L.uniform_taps)
-		return launch_ddc<WR_NCO_SPLIT, true>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
-	return launch_ddc<WR_NCO_SPLIT, false>(st, wgs, L, G, table_dev, hi_dev, lo_dev);
+	if (L.nco_mode == WR_NCO_EXACT)
+		return launch_ddc<WR_NCO_EXACT, false>(st, L, G, table_dev, hi_dev, lo_dev, num_cus);
+	if (L.nco_mode == WR_NCO_ROTATE)
+		return L.uniform_taps ? launch_ddc<WR_NCO_ROTATE, true>(st, L, G, table_dev, hi_dev, lo_dev, num_cus)
+		                      : launch_ddc<WR_NCO_ROTATE, false>(st, L, G, table_dev, hi_dev, lo_dev, num_cus);
+	return L.uniform_taps ? launch_ddc<WR_NCO_SPLIT, true>(st, L, G, table_dev, hi_dev, lo_dev, num_cus)
+	                      : launch_ddc<WR_NCO_SPLIT, false>(st, L, G, table_dev, hi_dev, lo_dev, num_cus);
 }
 
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
