@@ -81,9 +81,6 @@ struct Group {
 	int sp;                    /* state set (phase, LO history) the next block reads */
 	int cb;                    /* chan_iq buffer the next block writes */
 	int last_cb;               /* chan_iq buffer the last submit wrote */
-	hipEvent_t ev_ddc;         /* DDC of the last submit done (main stream) */
-	hipEvent_t ev_demod[2];    /* the demod that read chan_iq[i] is done (post stream) */
-	bool ev_demod_valid[2];
 	std::vector<int> owner;    /* slot -> chan or -1 */
 	bool dirty;                /* parameters must be uploaded before the next launch */
 	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
@@ -104,10 +101,6 @@ struct wr_tuner {
 	float *in_hist[2];         /* [63][2] ping-pong: last 63 IQ frames of the previous block */
 	int in_par;
 	bool submitted;
-	hipStream_t post_stream;   /* demod + audio of block b run here while block b+1's DDC runs */
-	bool overlap;
-	hipEvent_t ev_post;        /* everything of the last submit done */
-	bool ev_post_valid;
 	float audio_scale;
 	bool profiling;
 	unsigned int prof_stride;  /* bracket every prof_stride-th submit */
@@ -472,11 +465,6 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.prev_iq[1]);
 	(void)hipFree(g->dev.chan_iq[0]);
 	(void)hipFree(g->dev.chan_iq[1]);
-	if (g->ev_ddc)
-		(void)hipEventDestroy(g->ev_ddc);
-	for (int i = 0; i < 2; ++i)
-		if (g->ev_demod[i])
-			(void)hipEventDestroy(g->ev_demod[i]);
 	(void)hipFree(g->dev.dem[0]);
 	(void)hipFree(g->dev.dem[1]);
 	(void)hipFree(g->dev.audio);
@@ -491,9 +479,6 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	memset(&g->dev, 0, sizeof(g->dev));
 	g->parity = g->last_parity = 0;
 	g->sp = g->cb = g->last_cb = 0;
-	g->ev_ddc = nullptr;
-	g->ev_demod[0] = g->ev_demod[1] = nullptr;
-	g->ev_demod_valid[0] = g->ev_demod_valid[1] = false;
 	g->d1 = d1;
 	g->d2 = d2;
 	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
@@ -523,9 +508,6 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[1], (g->k1max ? g->k1max : 1) * S * 2);
-	if (!rc && hipEventCreateWithFlags(&g->ev_ddc, hipEventDisableTiming) != hipSuccess) rc = fail(WR_ERR_HIP, "hipEventCreate");
-	for (int i = 0; i < 2 && !rc; ++i)
-		if (hipEventCreateWithFlags(&g->ev_demod[i], hipEventDisableTiming) != hipSuccess) rc = fail(WR_ERR_HIP, "hipEventCreate");
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], (WR_HIST + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], (WR_HIST + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
@@ -560,16 +542,6 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->in_hist[0] = t->in_hist[1] = nullptr;
 	t->in_par = 0;
 	t->submitted = false;
-	t->post_stream = nullptr;
-	t->ev_post = nullptr;
-	t->ev_post_valid = false;
-	{
-		/* Opt-in experiment: run demod + audio of block b on a second stream beside the DDC of
-		 * block b+1.  Measured on MI355X / ROCm 7.2: the cross-stream event
-		 * hand-off costs ~20 us per block, as much as the overlap saves, so it is off. */
-		const char *on = getenv("WR_OVERLAP");
-		t->overlap = (on && *on && *on != '0');
-	}
 	t->audio_scale = 1.0f;
 	t->profiling = false;
 	t->prof_stride = 1;
@@ -577,11 +549,6 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->ev_used = 0;
 	t->prof_ms = 0.0;
 	t->prof_n = 0;
-	if (hipStreamCreateWithFlags(&t->post_stream, hipStreamNonBlocking) != hipSuccess ||
-	    hipEventCreateWithFlags(&t->ev_post, hipEventDisableTiming) != hipSuccess) {
-		wr_tuner_destroy(t);
-		return fail(WR_ERR_HIP, "wr_tuner_create: stream/event creation failed");
-	}
 	int rc = dev_alloc_zero(&t->in_hist[0], (size_t)WR_HIST * 2);
 	if (!rc)
 		rc = dev_alloc_zero(&t->in_hist[1], (size_t)WR_HIST * 2);
@@ -599,14 +566,8 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 		return WR_OK;
 	(void)hipSetDevice(t->dev->device);
 	(void)hipStreamSynchronize(t->dev->stream);
-	if (t->post_stream)
-		(void)hipStreamSynchronize(t->post_stream);
 	for (Group *g : t->groups)
 		group_free(g);
-	if (t->ev_post)
-		(void)hipEventDestroy(t->ev_post);
-	if (t->post_stream)
-		(void)hipStreamDestroy(t->post_stream);
 	for (hipEvent_t e : t->ev)
 		(void)hipEventDestroy(e);
 	for (wr_tuner::RingSlot &r : t->ring) {
@@ -621,7 +582,6 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 	return WR_OK;
 }
 
-static int tuner_join(wr_tuner *t);
 static int tuner_quiesce(wr_tuner *t);
 static int ring_push(wr_tuner *t);
 
@@ -902,20 +862,10 @@ extern "C" int wr_chan_slot(wr_tuner *t, int chan, int *slot)
 	return WR_OK;
 }
 
-/* make the main stream wait for the post-processing stream (results of the last submit) */
-static int tuner_join(wr_tuner *t)
-{
-	if (t->ev_post_valid)
-		HIP_TRY(hipStreamWaitEvent(t->dev->stream, t->ev_post, 0));
-	return WR_OK;
-}
-
-/* host is about to touch device arrays the post kernels read: drain both streams */
+/* host is about to touch device arrays the kernels of the last submit read: drain the stream */
 static int tuner_quiesce(wr_tuner *t)
 {
 	HIP_TRY(hipStreamSynchronize(t->dev->stream));
-	if (t->post_stream)
-		HIP_TRY(hipStreamSynchronize(t->post_stream));
 	return WR_OK;
 }
 
@@ -1125,7 +1075,6 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.nco_mode = t->nco_mode;
 		L.uniform_taps = g->uniform_taps ? 1 : 0;
 		L.audio_scale = t->audio_scale;
-		L.overlapped = t->overlap ? 1 : 0;
 		if (prof_now) {
 			int rc = prof_drain(t, 64);
 			if (rc)
@@ -1137,37 +1086,20 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			}
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
 		}
-		/* this block's DDC overwrites chan_iq[cb]: the demod that read it two blocks ago must
-		 * be done (a GPU-side wait; in steady state it completed long ago) */
-		hipStream_t ps = t->overlap ? t->post_stream : st;
-		if (t->overlap && g->ev_demod_valid[g->cb])
-			HIP_TRY(hipStreamWaitEvent(st, g->ev_demod[g->cb], 0));
 		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 		                      d->num_cus));
 		if (prof_now) {
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
 			t->ev_used += 2;
 		}
-		/* demod + audio of this block on the post stream, behind this block's DDC only:
-		 * the next block's DDC (main stream) does not wait for them */
-		if (t->overlap) {
-			HIP_TRY(hipEventRecord(g->ev_ddc, st));
-			HIP_TRY(hipStreamWaitEvent(ps, g->ev_ddc, 0));
-		}
-		/* demodulator output wanted (wr_tuner_keep_stages), an unusual audio decimation, or the
-		 * two-stream schedule: demod and audio filter as two kernels with the demod rows in HBM;
-		 * otherwise one fused pass */
-		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || t->overlap
-		                         || !wrk_tuner_post_supported(L.d2);
+		/* demodulator output wanted (wr_tuner_keep_stages) or an unusual audio decimation: demod
+		 * and audio filter as two kernels with the demod rows in HBM; otherwise one fused pass */
+		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
 		if (two_kernels) {
-			HIP_TRY(wrk_tuner_demod(ps, L, g->dev));
-			if (t->overlap) {
-				HIP_TRY(hipEventRecord(g->ev_demod[g->cb], ps));
-				g->ev_demod_valid[g->cb] = true;
-			}
-			HIP_TRY(wrk_tuner_audio(ps, L, g->dev));
+			HIP_TRY(wrk_tuner_demod(st, L, g->dev));
+			HIP_TRY(wrk_tuner_audio(st, L, g->dev));
 		} else {
-			HIP_TRY(wrk_tuner_post(ps, L, g->dev));
+			HIP_TRY(wrk_tuner_post(st, L, g->dev));
 		}
 		g->last_demod_kept = two_kernels;
 		g->last_parity = g->parity;
@@ -1180,10 +1112,6 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		}
 		g->last_k1 = L.k1;
 		g->last_k2 = L.k2;
-	}
-	if (t->overlap) {
-		HIP_TRY(hipEventRecord(t->ev_post, t->post_stream));
-		t->ev_post_valid = true;
 	}
 	if (!hist_written)
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
@@ -1216,11 +1144,6 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
-	{
-		int rc = tuner_join(t);         /* demod/audio of the last submit ran on the post stream */
-		if (rc)
-			return rc;
-	}
 	size_t n = 0;
 	switch (stage) {
 	case WR_STAGE_CHAN_IQ: n = g->last_k1 * 2; break;
@@ -1270,11 +1193,6 @@ extern "C" int wr_tuner_audio_dev(wr_tuner *t, const float **audio_dev, size_t *
 		}
 	if (!g)
 		return fail(WR_ERR_STATE, "tuner has no configured channel");
-	{
-		int rc = tuner_join(t);         /* order the caller's stream behind the audio kernel */
-		if (rc)
-			return rc;
-	}
 	*audio_dev = g->dev.audio;
 	*chan_stride = g->k2max;
 	*frames = g->last_k2;
@@ -1307,11 +1225,6 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
-	{
-		int rc = tuner_join(t);
-		if (rc)
-			return rc;
-	}
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
@@ -1355,7 +1268,7 @@ static int ring_push(wr_tuner *t)
 		HIP_TRY(hipHostMalloc((void **)&r.host, (want ? want : 1) * sizeof(float), hipHostMallocDefault));
 		r.cap = want;
 	}
-	hipStream_t st = t->overlap ? t->post_stream : t->dev->stream;
+	hipStream_t st = t->dev->stream;
 	if (need)
 		HIP_TRY(hipMemcpy2DAsync(r.host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 		                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));

@@ -63,7 +63,6 @@ struct WrTunerLaunch {
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
 	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
-	int          overlapped;    /* post-DDC kernels run beside the next block's DDC: use no LDS */
 	int          uniform_taps;  /* every 64-slot lane group carries one tap set (all its slots) */
 };
 

@@ -977,49 +977,6 @@ k_tuner_post(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int s
 	}
 }
 
-/* The same filter without LDS, for the overlapped schedule: while block b+1's DDC holds
- * 144 KiB of every CU's LDS, block b's audio filter can only share the CUs if it needs
- * none.  Thread = (slot lane, AUD_DQ consecutive output frames): taps in registers, the
- * (AUD_DQ-1)*D2 + 64 demod rows stream through once (each row read is one coalesced 256 B
- * segment per wave, served by L2), results leave as one 16-byte store per lane. */
-#define AUD_DQ 4u
-__global__ void __launch_bounds__(256)
-k_tuner_audio_direct(const float *__restrict__ dem, size_t k2, unsigned int d2, unsigned int slots,
-                     const float *__restrict__ taps2, const int *__restrict__ mode,
-                     float *__restrict__ audio, size_t k2max, float scale)
-{
-	const unsigned int lane = threadIdx.x & 63u;
-	const unsigned int w = threadIdx.x >> 6;
-	const unsigned int s = blockIdx.y * 64u + lane;
-	const size_t kq = ((size_t)blockIdx.x * 4u + w) * AUD_DQ;      /* first output frame of this thread */
-	if (kq >= k2 || mode[s] < 0)
-		return;
-	float h[WR_FIR_LENGTH];
-#pragma unroll
-	for (int j = 0; j < WR_FIR_LENGTH; ++j)
-		h[j] = taps2[(size_t)j * slots + s];
-	float acc[AUD_DQ];
-#pragma unroll
-	for (unsigned int q = 0; q < AUD_DQ; ++q) {
-		acc[q] = 0.0f;
-		if (kq + q < k2) {
-			const float *x = dem + ((kq + q) * d2) * slots + s;
-#pragma unroll 16
-			for (int j = 0; j < WR_FIR_LENGTH; ++j)
-				acc[q] = acc[q] + h[WR_FIR_LENGTH - 1 - j] * x[(size_t)j * slots];
-			if (scale != 1.0f)
-				acc[q] = acc[q] * scale;
-		}
-	}
-	float *o = audio + (size_t)s * k2max + kq;
-	if (kq + AUD_DQ <= k2 && ((k2max & 3u) == 0)) {
-		*reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-	} else {
-		for (unsigned int q = 0; q < AUD_DQ && kq + q < k2; ++q)
-			o[q] = acc[q];
-	}
-}
-
 /* strided row gather: dst[r*width + i] = src[r*row_stride + col_offset + i] */
 __global__ void k_gather_rows(const float *__restrict__ src, size_t rows, size_t row_stride,
                               size_t col_offset, unsigned int width, float *__restrict__ dst)
@@ -1239,13 +1196,6 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 {
 	if (!L.k2 || !L.slots_used)
 		return hipSuccess;
-	if (L.overlapped) {
-		/* shares the CUs with the next block's DDC: no LDS */
-		dim3 grid((unsigned int)((L.k2 + 4 * AUD_DQ - 1) / (4 * AUD_DQ)), L.slots_used / 64);
-		k_tuner_audio_direct<<<grid, 256, 0, st>>>(G.dem[L.parity], L.k2, L.d2, L.slots, G.taps2, G.mode,
-		                                           G.audio, L.k2max, L.audio_scale);
-		return hipGetLastError();
-	}
 	/* as many output frames per tile as the staged rows allow */
 	unsigned int tk = AUD_TMAX;
 	if (L.d2 > 1 && (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u < tk)
