@@ -310,8 +310,8 @@ __device__ __forceinline__ void gather_split(unsigned int P, unsigned int &ah, u
 	    : "+v"(ah) : "v"(P));
 	asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2"
 	    : "+v"(al) : "v"(P));
-	a = *(const lds_v2f *)ah;                          /* cis(2*pi*coarse/256) */
-	b = *(const lds_v2f *)al;                          /* cis(2*pi*fine/65536) */
+	a = *(const lds_v2f *)(uintptr_t)ah;                         /* cis(2*pi*coarse/256) */
+	b = *(const lds_v2f *)(uintptr_t)al;                         /* cis(2*pi*fine/65536) */
 }
 
 /*
