@@ -348,6 +348,67 @@ long wr_host_setter_stress(const float *iq, size_t nframes, unsigned int rate, u
 	return rc ? rc : calls.load();
 }
 
+/* A graph that is NOT the fused Receiver shape, built with the public DspBlock API the way a
+ * user of the reference would: tuner -> DownConverter -> LowPass x nstages -> Demodulator ->
+ * LowPass -> AudioStreamManager.  Several decimating stages in a row are what makes a narrow
+ * channel off a fast stream possible at all with 64-tap filters (one stage gives
+ * maxbin = 0, all-zero taps).  Runs block by block on the GPU with the intermediates handed
+ * over in device memory.  Returns the number of audio samples, or < 0. */
+long wr_host_run_multistage(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
+                            int if_hz, int mode, unsigned int nstages, const unsigned int *stage_rates,
+                            const unsigned int *stage_passbands, unsigned int audio_passband,
+                            unsigned int audio_rate, float *audio_out, size_t audio_cap)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	g_pos = 0;
+	g_rate = rate;
+	g_block = block_frames;
+	Tuner *tuner = makeTuner("multistage");
+	tuner->setSampleRate(rate);
+	tuner->setChannels(2);
+	tuner->setBlockSize(block_frames * 2);
+	DownConverter mixer("ms");
+	Demodulator demod("ms");
+	LowPass audio("ms-audio");
+	AudioStreamManager sink("ms");
+	std::vector<LowPass *> stages;
+	mixer.setIF(if_hz);
+	demod.setMode((Demodulator::Mode)mode);
+	tuner->connect(&mixer);
+	DspBlock *last = &mixer;
+	for (unsigned int n = 0; n < nstages; n++) {
+		LowPass *f = new LowPass("ms-stage");
+		f->setPassband(stage_passbands[n]);
+		f->setOutputSampleRate(stage_rates[n]);
+		last->connect(f);
+		last = f;
+		stages.push_back(f);
+	}
+	last->connect(&demod);
+	demod.connect(&audio);
+	audio.setPassband(audio_passband);
+	audio.setOutputSampleRate(audio_rate);
+	audio.connect(&sink);
+	sink.setCapacity(audio_cap);
+	long rc = -1;
+	if (tuner->start()) {
+		for (size_t b = 0; b < nframes / block_frames; b++)
+			tuner->run();
+		const vector<float> &a = sink.samples();
+		rc = (long)a.size();
+		if (a.size() <= audio_cap)
+			memcpy(audio_out, a.data(), a.size() * sizeof(float));
+		else
+			rc = -2;
+		tuner->stop();
+	}
+	delete tuner;
+	for (size_t n = 0; n < stages.size(); n++)
+		delete stages[n];
+	return rc;
+}
+
 int wr_host_registry_sizes(void)
 {
 	return (int)(Radio::frontEnds().size() * 1000 + Radio::receivers().size());

@@ -281,3 +281,71 @@ def test_setters_from_another_thread_while_running(tmp_path):
     r = np.load(out)
     assert int(r["calls"]) > 1000 and int(r["left"]) == 0
     assert r["audio"].shape == (12, block // 2000) and np.isfinite(r["audio"]).all()
+
+
+MS_RUNNER = r'''
+import ctypes as C, sys, numpy as np
+lib, npz, out = sys.argv[1], sys.argv[2], sys.argv[3]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz); iq = np.ascontiguousarray(d["iq"], np.float32); p = d["params"]
+rates = np.ascontiguousarray(d["rates"], np.uint32); pbs = np.ascontiguousarray(d["pbs"], np.uint32)
+fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint)
+L.wr_host_run_multistage.restype = C.c_long
+L.wr_host_run_multistage.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_uint, up, up, C.c_uint, C.c_uint,
+                                     fp, C.c_size_t]
+audio = np.zeros(1 << 16, np.float32)
+n = L.wr_host_run_multistage(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), int(p[2]), int(p[3]), rates.size,
+                             rates.ctypes.data_as(up), pbs.ctypes.data_as(up), int(p[4]), int(p[5]),
+                             audio.ctypes.data_as(fp), audio.size)
+np.savez(out, n=n, audio=audio[:max(n, 0)])
+'''
+
+
+def test_multistage_decimation_chain_on_device(tmp_path, oracle):
+    """SURVEY H4 / 8f-4: a 12.5 kHz-wide channel off a 20 Msps stream.  One 64-tap stage cannot do it
+    (maxbin = 64 * 12500 / 20e6 / 2 = 0: all-zero taps, the reference is silent); three decimating
+    LowPass stages in a row (20 M -> 1 M -> 100 k -> 25 k) can, using nothing but the DspBlock API.
+    Such a graph is not the fused Receiver shape: every block runs its own kernel, and the
+    intermediates are handed over in device memory.  Checked against the oracle's cascade of
+    the reference's own blocks, bit for bit (AM detector)."""
+    fs, block, f_if = 20_000_000, 400_000, 2_345_000
+    rates, pbs = [1_000_000, 100_000, 25_000], [700_000, 40_000, 12_500]     # maxbin 1, 1, 4
+    apb, arate, mode = 3_000, 12_500, 0
+    assert oracle.lowpass_maxbin(12_500, fs) == 0                    # the single-stage design is degenerate
+    n = 3 * block
+    t = np.arange(n) / fs
+    am = 1.0 + 0.5 * np.sin(2 * np.pi * 1_000 * t)                   # 1 kHz tone, AM on the carrier at f_if
+    rng = np.random.default_rng(3)
+    sig = 0.3 * am * np.exp(2j * np.pi * f_if * t) + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.float32)
+    iq[0::2], iq[1::2] = sig.real, sig.imag
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, iq=iq, params=np.array([fs, block, f_if, mode, apb, arate], np.int64), rates=np.array(rates), pbs=np.array(pbs))
+    subprocess.check_call([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
+                          timeout=300)
+    r = np.load(out)
+    got = r["audio"]
+    # the oracle's cascade: the reference's blocks chained the same way
+    table = oracle.sin_table()
+    firs, rate_in = [], fs
+    for ro, pb in zip(rates, pbs):
+        firs.append(oracle.Fir(2, rate_in // ro, oracle.lowpass_design(pb, rate_in)))
+        rate_in = ro
+    fa = oracle.Fir(1, rate_in // arate, oracle.lowpass_design(apb, rate_in))
+    phase, prev, want = 0, (0.0, 0.0), []
+    for b in range(3):
+        x, phase = oracle.mix(table, phase, oracle.phase_step(f_if, fs), iq[2 * b * block: 2 * (b + 1) * block])
+        for f in firs:
+            x = f.process(x)
+        d, prev = oracle.demod(mode, prev, x)
+        want.append(fa.process(d))
+    want = np.concatenate(want)
+    assert int(r["n"]) == want.size == 3 * block // (fs // arate)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and it really receives: the 1 kHz tone dominates the audio once the filters have settled
+    tail = got[got.size // 3:] - got[got.size // 3:].mean()
+    spec = np.abs(np.fft.rfft(tail * np.hanning(tail.size)))
+    spec[:3] = 0.0                                                    # what is left of the carrier's DC term
+    assert abs(np.argmax(spec) * arate / tail.size - 1_000) < 2 * arate / tail.size

@@ -70,13 +70,30 @@ bool Demodulator::process(const vector<sample_t> &inBuffer, vector<sample_t> &ou
 	const unsigned int nframes = currentInputFrames();
 	wr_dev *dev = wrhost::deviceFor(this);
 	const size_t inBytes = (size_t)nframes * 2 * sizeof(float), outBytes = (size_t)nframes * sizeof(float);
-	if (!dev || !_in->reserve(dev, inBytes) || !_out->reserve(dev, outBytes))
+	if (!dev || !_out->reserve(dev, outBytes ? outBytes : sizeof(float)))
 		return false;
-	if (wr_dev_upload(dev, _in->ptr, inBuffer.data(), inBytes) != WR_OK ||
-	    wr_demod(dev, (int)_mode, (const float *)_in->ptr, nframes, _prev, (float *)_out->ptr) != WR_OK ||
-	    wr_dev_download(dev, outBuffer.data(), _out->ptr, outBytes) != WR_OK) {
+	const float *din = (const float *)upstreamDeviceOutput();
+	if (!din) {
+		if (!_in->reserve(dev, inBytes ? inBytes : sizeof(float)) ||
+		    wr_dev_upload(dev, _in->ptr, inBuffer.data(), inBytes) != WR_OK) {
+			LOG_ERROR("Demodulator: %s\n", wr_last_error());
+			return false;
+		}
+		din = (const float *)_in->ptr;
+	}
+	if (wr_demod(dev, (int)_mode, din, nframes, _prev, (float *)_out->ptr) != WR_OK) {
 		LOG_ERROR("Demodulator: %s\n", wr_last_error());
 		return false;
+	}
+	publishDeviceOutput(_out->ptr);
+	const bool onHost = hostOutputNeeded();
+	elideOutput(!onHost);
+	if (onHost) {
+		outBuffer.resize(nframes);
+		if (wr_dev_download(dev, outBuffer.data(), _out->ptr, outBytes) != WR_OK) {
+			LOG_ERROR("Demodulator: %s\n", wr_last_error());
+			return false;
+		}
 	}
 	return true;
 }

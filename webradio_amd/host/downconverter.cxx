@@ -72,15 +72,41 @@ bool DownConverter::process(const vector<sample_t> &inBuffer, vector<sample_t> &
 		 * these calls per source block */
 		return _channel->batch->submitOnce(inBuffer, nframes);
 	}
+	/* stand-alone (not the fused Receiver shape): one kernel for this block.  The input is, in
+	 * order of preference, the producer's output where it already lies in device memory, the
+	 * device copy of the tuner block every GPU consumer of the source shares, or an upload;
+	 * the output stays on the device and only reaches the host if a consumer needs it there. */
 	wr_dev *dev = wrhost::deviceFor(this);
 	const size_t bytes = (size_t)nframes * 2 * sizeof(float);
-	if (!dev || !_in->reserve(dev, bytes) || !_out->reserve(dev, bytes))
+	if (!dev || !_out->reserve(dev, bytes))
 		return false;
-	if (wr_dev_upload(dev, _in->ptr, inBuffer.data(), bytes) != WR_OK ||
-	    wr_mix(dev, (const float *)_in->ptr, (float *)_out->ptr, nframes, &_phase, _phaseStep) != WR_OK ||
-	    wr_dev_download(dev, outBuffer.data(), _out->ptr, bytes) != WR_OK) {
+	wr_dev *sdev = NULL;
+	const float *din = (const float *)upstreamDeviceOutput();
+	if (!din) {
+		din = wrhost::stagedBlock(this, inBuffer, &sdev);
+		if (din && sdev != dev)
+			din = NULL;
+	}
+	if (!din) {
+		if (!_in->reserve(dev, bytes) || wr_dev_upload(dev, _in->ptr, inBuffer.data(), bytes) != WR_OK) {
+			LOG_ERROR("DownConverter: %s\n", wr_last_error());
+			return false;
+		}
+		din = (const float *)_in->ptr;
+	}
+	if (wr_mix(dev, din, (float *)_out->ptr, nframes, &_phase, _phaseStep) != WR_OK) {
 		LOG_ERROR("DownConverter: %s\n", wr_last_error());
 		return false;
+	}
+	publishDeviceOutput(_out->ptr);
+	const bool onHost = hostOutputNeeded();
+	elideOutput(!onHost);               /* from the next block on the runtime does not size it either */
+	if (onHost) {
+		outBuffer.resize((size_t)nframes * 2);
+		if (wr_dev_download(dev, outBuffer.data(), _out->ptr, bytes) != WR_OK) {
+			LOG_ERROR("DownConverter: %s\n", wr_last_error());
+			return false;
+		}
 	}
 	return true;
 }

@@ -37,6 +37,7 @@ private:
 	bool init();
 	void deinit();
 	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer);
+	bool acceptsDeviceInput() const { return _channel == NULL; }   /* stand-alone: reads the producer's device output */
 
 	LowPass*		_unusedFilter;
 	int				_ifHz;

@@ -35,7 +35,7 @@ DspBlock::DspBlock(const string &name, const string &type)
 	  _name(name), _type(type),
 	  _inRate(DEFAULT_SAMPLE_RATE), _inChannels(DEFAULT_CHANNELS),
 	  _decim(1), _interp(1), _nsTotal(0), _framesIn(0), _framesOut(0),
-	  _running(false), _elide(false), _curInFrames(0), _curOutFrames(0), _producer(NULL)
+	  _running(false), _elide(false), _curInFrames(0), _curOutFrames(0), _producer(NULL), _devOut(NULL)
 {
 }
 
@@ -165,6 +165,7 @@ bool DspBlock::runFrames(const vector<sample_t> &inBuffer, unsigned int inframes
 		_out.resize(want);
 	}
 
+	_devOut = NULL;
 	const uint64_t t0 = cpuNanoseconds();
 	if (!process(inBuffer, _out)) {
 		LOG_ERROR("Pipeline failed at block %s:%s\n", type().c_str(), name().c_str());
@@ -178,6 +179,15 @@ bool DspBlock::runFrames(const vector<sample_t> &inBuffer, unsigned int inframes
 		if (!_consumers[n]->runFrames(_out, outframes))
 			return false;
 	return true;
+}
+
+/* does anybody read this block's output on the host? */
+bool DspBlock::hostOutputNeeded() const
+{
+	for (size_t n = 0; n < _consumers.size(); n++)
+		if (!_consumers[n]->acceptsDeviceInput())
+			return true;
+	return false;
 }
 
 void DspBlock::setSampleRate(unsigned int rate)

@@ -83,6 +83,14 @@ protected:
 	 * data from the tuner batch on the GPU) asks the runtime not to materialise it. */
 	void elideOutput(bool on) { _elide = on; }
 	bool outputElided() const { return _elide; }
+	/* Device hand-over between blocks that run block by block on the GPU (a chain that is not
+	 * the fused Receiver shape, e.g. several LowPass stages in a row): a block that leaves its
+	 * output in device memory publishes the pointer, a consumer that can read device memory
+	 * says so, and when every consumer can, the host copy of that output is never made. */
+	virtual bool acceptsDeviceInput() const { return false; }
+	void publishDeviceOutput(const void *devptr) { _devOut = devptr; }
+	const void *upstreamDeviceOutput() const { return _producer ? _producer->_devOut : NULL; }
+	bool hostOutputNeeded() const;
 	/* frames of the block currently being pushed through this block */
 	unsigned int currentInputFrames() const { return _curInFrames; }
 	unsigned int currentOutputFrames() const { return _curOutFrames; }
@@ -109,6 +117,7 @@ private:
 	unsigned int		_curInFrames;
 	unsigned int		_curOutFrames;
 	DspBlock*			_producer;
+	const void*			_devOut;		/* this block's output of the current block, on the device */
 	vector<sample_t>	_out;
 	vector<DspBlock*>	_consumers;
 };

@@ -109,17 +109,36 @@ bool LowPass::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuf
 	}
 	const unsigned int ch = inputChannels();
 	const unsigned int nframes = currentInputFrames();
+	const unsigned int outframes = currentOutputFrames();
 	wr_dev *dev = wrhost::deviceFor(this);
 	const size_t inBytes = (size_t)nframes * ch * sizeof(float);
-	const size_t outBytes = outBuffer.size() * sizeof(float);
-	if (!dev || !_in->reserve(dev, inBytes) || !_out->reserve(dev, outBytes) || !_history->ptr)
+	const size_t outBytes = (size_t)outframes * outputChannels() * sizeof(float);
+	if (!dev || !_out->reserve(dev, outBytes ? outBytes : sizeof(float)) || !_history->ptr)
 		return false;
-	if (wr_dev_upload(dev, _in->ptr, inBuffer.data(), inBytes) != WR_OK ||
-	    wr_fir_decimate_n(dev, (const float *)_in->ptr, nframes, ch, decimation(), _firLength, _coeff.data(),
-	                    (float *)_history->ptr, (float *)_out->ptr) != WR_OK ||
-	    wr_dev_download(dev, outBuffer.data(), _out->ptr, outBytes) != WR_OK) {
+	/* input: the producer's device output if there is one, else an upload (see DownConverter) */
+	const float *din = (const float *)upstreamDeviceOutput();
+	if (!din) {
+		if (!_in->reserve(dev, inBytes ? inBytes : sizeof(float)) ||
+		    wr_dev_upload(dev, _in->ptr, inBuffer.data(), inBytes) != WR_OK) {
+			LOG_ERROR("LowPass: %s\n", wr_last_error());
+			return false;
+		}
+		din = (const float *)_in->ptr;
+	}
+	if (wr_fir_decimate_n(dev, din, nframes, ch, decimation(), _firLength, _coeff.data(),
+	                      (float *)_history->ptr, (float *)_out->ptr) != WR_OK) {
 		LOG_ERROR("LowPass: %s\n", wr_last_error());
 		return false;
+	}
+	publishDeviceOutput(_out->ptr);
+	const bool onHost = hostOutputNeeded();
+	elideOutput(!onHost);
+	if (onHost) {
+		outBuffer.resize((size_t)outframes * outputChannels());
+		if (wr_dev_download(dev, outBuffer.data(), _out->ptr, outBytes) != WR_OK) {
+			LOG_ERROR("LowPass: %s\n", wr_last_error());
+			return false;
+		}
 	}
 	return true;
 }
