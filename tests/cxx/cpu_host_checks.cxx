@@ -51,3 +51,80 @@ extern "C" long wr_filetuner_play(const char *path, unsigned int block_frames, u
 	memcpy(out, c.got.data(), n * sizeof(float));
 	return (long)c.got.size();
 }
+
+/* ---- device hand-over bookkeeping of DspBlock (no GPU involved: pointers are just tokens) ---- */
+namespace {
+struct Src : public DspSource {
+	Src() : DspSource("s", "Src") {}
+protected:
+	bool init() { return true; }
+	void deinit() {}
+	bool process(const vector<sample_t> &, vector<sample_t> &out) {
+		for (size_t n = 0; n < out.size(); n++)
+			out[n] = (float)n;
+		return true;
+	}
+};
+/* pretends to compute on a device: publishes a token, fills the host vector only if asked to */
+struct DevStage : public DspBlock {
+	DevStage(const char *n, bool takesDevice) : DspBlock(n, "DevStage"), takes(takesDevice), hostFills(0),
+	                                            sawUpstream(NULL), sawHostFrames(0) {}
+	bool takes;
+	int token;
+	int hostFills;
+	const void *sawUpstream;
+	size_t sawHostFrames;
+protected:
+	bool init() { _outputSampleRate = inputSampleRate(); _outputChannels = inputChannels(); return true; }
+	void deinit() {}
+	bool acceptsDeviceInput() const { return takes; }
+	bool process(const vector<sample_t> &in, vector<sample_t> &out) {
+		sawUpstream = upstreamDeviceOutput();
+		sawHostFrames = in.size() / 2;
+		publishDeviceOutput(&token);
+		const bool onHost = hostOutputNeeded();
+		elideOutput(!onHost);
+		if (onHost) {
+			out.assign((size_t)currentOutputFrames() * 2, 1.0f);
+			hostFills++;
+		}
+		return true;
+	}
+};
+}
+
+/* returns a bit mask of failed expectations (0 = all good) */
+extern "C" int wr_handover_checks(void)
+{
+	int bad = 0;
+	Src src;
+	src.setSampleRate(48000);
+	src.setChannels(2);
+	src.setBlockSize(64);
+	DevStage a("a", true), b("b", true), hostsink("h", false);
+	src.connect(&a);
+	a.connect(&b);
+	if (!src.start())
+		return -1;
+	src.run();
+	src.run();
+	/* a is fed by the source: no device input, full host block; its only consumer takes device
+	 * input, so a never fills its host output, and b sees a's token and an EMPTY host vector
+	 * that still stands for 32 frames (b has no consumer: nobody needs its output on the host) */
+	if (a.sawUpstream != NULL || a.sawHostFrames != 32) bad |= 1;
+	if (a.hostFills != 0) bad |= 2;
+	if (b.sawUpstream != (const void *)&a.token || b.sawHostFrames != 0) bad |= 4;
+	if (b.hostFills != 0) bad |= 8;
+	/* a host consumer joins b while running (hot-connect, quirk Q9): from then on b fills its host output */
+	b.connect(&hostsink);
+	src.run();
+	if (b.hostFills != 1 || hostsink.sawHostFrames != 32) bad |= 16;
+	if (hostsink.sawUpstream != (const void *)&b.token) bad |= 32;       /* published all the same */
+	/* and a second, host-only consumer of a makes a fill its output too, while b keeps reading the token */
+	DevStage tap("t", false);
+	a.connect(&tap);
+	src.run();
+	if (a.hostFills != 1 || tap.sawHostFrames != 32 || b.sawUpstream != (const void *)&a.token) bad |= 64;
+	src.stop();
+	return bad;
+}

@@ -60,3 +60,12 @@ def test_loop_and_raw_bytes(checks, oracle, tmp_path):
 def test_missing_file(checks, tmp_path):
     n, ok, out, raw = _play(checks, tmp_path / "nope.bin", 10, 1, 0)
     assert n == -1                                           # init() fails -> start() false
+
+
+def test_device_handover_bookkeeping():
+    """DspBlock::publishDeviceOutput / upstreamDeviceOutput / acceptsDeviceInput / hostOutputNeeded
+    (the hand-over between stand-alone GPU blocks), exercised with stub blocks: no GPU needed."""
+    import ctypes as C
+    lib = os.path.join(CXXT, "libwr_cpu_host_checks.so")
+    L = C.CDLL(lib)
+    assert L.wr_handover_checks() == 0
