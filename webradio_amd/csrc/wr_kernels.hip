@@ -943,9 +943,38 @@ k_tuner_post(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int s
 		for (int j = 0; j < WR_FIR_LENGTH; ++j)
 			h[j] = taps2[(size_t)j * slots + s];
 	}
-#pragma unroll 4
-	for (unsigned int r = row; r < NEED; r += NROW)
-		stage[r * 64u + lane] = (m >= 0) ? post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, r0 + r) : 0.0f;
+	{
+		/* a run of consecutive rows per thread: each channel frame is loaded once and stays in a
+		 * register as the next row's predecessor */
+		constexpr unsigned int PER = (NEED + NROW - 1u) / NROW;
+		const unsigned int beg = row * PER;
+		const unsigned int end = (beg + PER < NEED) ? beg + PER : NEED;
+		float2 zp = make_float2(0.0f, 0.0f);
+		if (m >= 0 && beg < end) {
+			const size_t rr = r0 + beg;
+			if (rr == WR_HIST)
+				zp = prev_iq[s];
+			else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
+				zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
+		}
+#pragma unroll 6
+		for (unsigned int r = beg; r < end; ++r) {
+			const size_t rr = r0 + r;
+			float v = 0.0f;
+			if (m >= 0) {
+				if (rr < WR_HIST) {
+					v = dem_hist[rr * slots + s];
+					if (rr + 1u == WR_HIST)
+						zp = prev_iq[s];                    /* the next row is the block's first frame */
+				} else if (rr - WR_HIST < k1) {
+					const float2 z = chan_iq[(rr - WR_HIST) * slots + s];
+					v = demod_one(m, z.x, z.y, zp.x, zp.y);
+					zp = z;
+				}
+			}
+			stage[r * 64u + lane] = v;
+		}
+	}
 	__syncthreads();
 	if (row < POST_TK / POST_B) {
 		float acc[POST_B];
