@@ -887,7 +887,9 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
  *                 the last 63 demod outputs (audio filter history) and the last channel
  *                 frame (Demodulator::prev_i/q), into the other ping-pong set.
  */
+#ifndef POST_TK
 #define POST_TK 16u
+#endif
 #define POST_B 4u
 #define POST_THREADS 512u
 __device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
