@@ -205,6 +205,17 @@ int wr_tuner_submit(wr_tuner *tuner, const float *iq, size_t nframes, int where)
  * the bytes cross PCIe and leave HBM.  Results are identical to converting first. */
 int wr_tuner_submit_u8(wr_tuner *tuner, const uint8_t *iq_u8, size_t nframes, int where);
 
+/* The demodulator + audio filter of a block (its "post stage") need not run inside the submit
+ * that brought the block: where the kernel variant allows (WR_NCO_ROTATE, one channel filter per
+ * lane group, audio decimation 1..6, demodulator output not kept) it is launched together with
+ * the NEXT block's down-conversion, in the same kernel, so that a continuous stream costs one
+ * launch per block.  Every call that reads results (wr_chan_fetch, wr_tuner_fetch_audio_all,
+ * wr_tuner_audio_dev, wr_chan_get_state) or changes channel parameters launches a pending post
+ * stage first, so nothing is ever observed out of order; wr_tuner_flush does only that (e.g. at
+ * the end of a stream consumed through the audio ring).  WR_DEFER_POST=0 in the environment
+ * turns the deferral off. */
+int wr_tuner_flush(wr_tuner *tuner);
+
 /* results of the last submit.  Frames per channel: CHAN_IQ nframes/d1 (x2 floats),
  * DEMOD nframes/d1, AUDIO nframes/d1/d2 -- the truncating arithmetic of
  * dspblock.cxx:177-178.  Synchronises the stream. */
@@ -221,9 +232,10 @@ int wr_chan_slot(wr_tuner *tuner, int chan, int *slot);
 int wr_tuner_fetch_audio_all(wr_tuner *tuner, float *out_host, size_t out_capacity,
                              size_t *chan_stride, size_t *frames, unsigned int *slots_used);
 /* ---- audio sink boundary: a ring of pinned host buffers ----
- * With a ring of `depth` >= 1 slots, every wr_tuner_submit* queues ONE asynchronous
- * device-to-host copy of all channels' audio into the next free slot, behind the block's
- * kernels on the tuner's stream, and returns without waiting: the consumer side (the 256
+ * With a ring of `depth` >= 1 slots, ONE asynchronous device-to-host copy of all channels' audio
+ * is queued into the next free slot right behind the kernel that produces it (with a deferred
+ * post stage, see wr_tuner_flush: behind the next submit's launch, or behind the flush), and
+ * nothing waits: the consumer side (the 256
  * AudioStreamManager sinks of a tuner, web/audiostream.cxx:65-73, or a recorder) takes the
  * blocks in order with acquire/release, typically from another thread or one block later,
  * so that the copy and the consumers overlap the next block's kernels.  Like the reference's

@@ -78,12 +78,21 @@ struct Group {
 	int parity;                /* index of the current ping-pong buffers (prev_iq, dem) */
 	int last_parity;           /* parity the last submit wrote its demod rows with */
 	bool last_demod_kept = false; /* the last submit left its demod rows in HBM */
+	/* The post stage (demodulator + audio filter) of the last block, not launched yet: it goes
+	 * out with the NEXT block's DDC launch (extra workgroups of the same kernel, see
+	 * k_tuner_ddc) or, when somebody needs the results first, on its own (tuner_flush). */
+	bool post_pending = false;
+	WrPostArgs post_args;
+	unsigned long long pend_seq = 0;   /* ring bookkeeping of that block */
+	size_t pend_k2 = 0;
+	unsigned int pend_slots = 0;
 	int sp;                    /* state set (phase, LO history) the next block reads */
 	int cb;                    /* chan_iq buffer the next block writes */
 	int last_cb;               /* chan_iq buffer the last submit wrote */
 	std::vector<int> owner;    /* slot -> chan or -1 */
 	bool dirty;                /* parameters must be uploaded before the next launch */
 	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
+	bool uniform_taps2 = false; /* ... and one audio-filter tap set */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -121,7 +130,9 @@ struct wr_tuner {
 	std::vector<RingSlot> ring;
 	unsigned int ring_head = 0, ring_count = 0;    /* next slot to fill, slots queued */
 	bool ring_held = false;                        /* oldest slot handed out, not yet released */
-	unsigned long long ring_seq = 0, ring_overruns = 0;
+	unsigned long long ring_overruns = 0;
+	unsigned long long submit_seq = 0;             /* blocks submitted so far */
+	bool defer_post = true;                        /* see Group::post_pending; WR_DEFER_POST=0 turns it off */
 	std::mutex ring_lock;                          /* producer (submit) vs consumer thread */
 };
 
@@ -543,6 +554,10 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	t->in_par = 0;
 	t->submitted = false;
 	t->audio_scale = 1.0f;
+	{
+		const char *e = getenv("WR_DEFER_POST");
+		t->defer_post = !(e && *e == '0');
+	}
 	t->profiling = false;
 	t->prof_stride = 1;
 	t->prof_tick = 0;
@@ -583,7 +598,8 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 }
 
 static int tuner_quiesce(wr_tuner *t);
-static int ring_push(wr_tuner *t);
+static int tuner_flush(wr_tuner *t);
+static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used);
 
 static Chan *chan_get(wr_tuner *t, int chan)
 {
@@ -862,9 +878,28 @@ extern "C" int wr_chan_slot(wr_tuner *t, int chan, int *slot)
 	return WR_OK;
 }
 
-/* host is about to touch device arrays the kernels of the last submit read: drain the stream */
+/* launch whatever post stage is still pending (results of the last submit wanted now) */
+static int tuner_flush(wr_tuner *t)
+{
+	for (Group *g : t->groups) {
+		if (!g->post_pending)
+			continue;
+		HIP_TRY(wrk_tuner_post_args(t->dev->stream, g->post_args));
+		g->post_pending = false;
+		int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots);
+		if (rc)
+			return rc;
+	}
+	return WR_OK;
+}
+
+/* host is about to touch device arrays the kernels of the last submit read or write: get the
+ * pending post stage out, then drain the stream */
 static int tuner_quiesce(wr_tuner *t)
 {
+	int rc = tuner_flush(t);
+	if (rc)
+		return rc;
 	HIP_TRY(hipStreamSynchronize(t->dev->stream));
 	return WR_OK;
 }
@@ -918,6 +953,27 @@ static int group_upload(wr_tuner *t, Group *g)
 						taps1[(size_t)j * S + s] = t->chans[rep].taps[0][j];
 	}
 	g->uniform_taps = uniform;
+	/* the same for the audio filter (radio.cxx:80-81): uniform taps can be scalar operands of
+	 * the post stage when it runs inside the DDC kernel */
+	bool uniform2 = true;
+	for (size_t base = 0; base < S && uniform2; base += WR_LANES) {
+		int rep = -1;
+		for (size_t s = base; s < base + WR_LANES; ++s) {
+			int ci = g->owner[s];
+			if (ci < 0)
+				continue;
+			if (rep < 0)
+				rep = ci;
+			else if (memcmp(t->chans[ci].taps[1], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH))
+				uniform2 = false;
+		}
+		if (rep >= 0 && uniform2)
+			for (size_t s = base; s < base + WR_LANES; ++s)
+				if (g->owner[s] < 0)
+					for (int j = 0; j < WR_FIR_LENGTH; ++j)
+						taps2[(size_t)j * S + s] = t->chans[rep].taps[1][j];
+	}
+	g->uniform_taps2 = uniform2;
 	/* pageable sources: hipMemcpyAsync stages them before returning */
 	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
@@ -1045,6 +1101,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 	const uint8_t *cur_u8 = u8 ? (const uint8_t *)src : nullptr;
 
 	bool hist_written = false;
+	const unsigned long long seq = t->submit_seq++;
 	const bool prof_now = t->profiling && (t->prof_tick++ % t->prof_stride) == 0;
 	for (Group *g : t->groups) {
 		if (g->active <= 0) {
@@ -1086,20 +1143,45 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			}
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
 		}
+		/* The previous block's post stage rides along with this block's DDC where the kernel
+		 * variant can take it (wrk_tuner_ddc says); otherwise it goes out on its own first. */
+		bool rode = false;
 		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
-		                      d->num_cus));
+		                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
 		if (prof_now) {
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
 			t->ev_used += 2;
 		}
+		if (g->post_pending) {
+			if (!rode)
+				HIP_TRY(wrk_tuner_post_args(st, g->post_args));
+			g->post_pending = false;
+			int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots);
+			if (rc)
+				return rc;
+		}
 		/* demodulator output wanted (wr_tuner_keep_stages) or an unusual audio decimation: demod
-		 * and audio filter as two kernels with the demod rows in HBM; otherwise one fused pass */
+		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
+		 * fused pass -- deferred to the next launch where that launch can carry it. */
 		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
+		const bool defer = !two_kernels && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE && g->uniform_taps
+		                   && g->uniform_taps2;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, L, g->dev));
 			HIP_TRY(wrk_tuner_audio(st, L, g->dev));
+		} else if (defer) {
+			g->post_pending = true;
+			g->post_args = wrk_post_args(L, g->dev);
+			g->pend_seq = seq;
+			g->pend_k2 = L.k2;
+			g->pend_slots = L.slots_used;
 		} else {
 			HIP_TRY(wrk_tuner_post(st, L, g->dev));
+		}
+		if (!defer) {
+			int rc = ring_push(t, g, seq, L.k2, L.slots_used);
+			if (rc)
+				return rc;
 		}
 		g->last_demod_kept = two_kernels;
 		g->last_parity = g->parity;
@@ -1124,12 +1206,16 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		c.phaseL += (unsigned int)nframes * c.stepL;
 	}
 	t->submitted = true;
-	if (!t->ring.empty()) {
-		int rc = ring_push(t);
-		if (rc)
-			return rc;
-	}
 	return WR_OK;
+}
+
+extern "C" int wr_tuner_flush(wr_tuner *t)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	return tuner_flush(t);
 }
 
 extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, size_t out_capacity,
@@ -1144,6 +1230,11 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	{
+		int rc = tuner_flush(t);        /* the block's demod/audio may still be waiting for the next launch */
+		if (rc)
+			return rc;
+	}
 	size_t n = 0;
 	switch (stage) {
 	case WR_STAGE_CHAN_IQ: n = g->last_k1 * 2; break;
@@ -1193,6 +1284,13 @@ extern "C" int wr_tuner_audio_dev(wr_tuner *t, const float **audio_dev, size_t *
 		}
 	if (!g)
 		return fail(WR_ERR_STATE, "tuner has no configured channel");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	{
+		int rc = tuner_flush(t);        /* the caller is about to read the last block's audio */
+		if (rc)
+			return rc;
+	}
 	*audio_dev = g->dev.audio;
 	*chan_stride = g->k2max;
 	*frames = g->last_k2;
@@ -1225,6 +1323,11 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	{
+		int rc = tuner_flush(t);
+		if (rc)
+			return rc;
+	}
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
@@ -1245,21 +1348,20 @@ static Group *single_group(wr_tuner *t)
 	return g;
 }
 
-/* queue the copy of the block just submitted (called at the end of tuner_submit) */
-static int ring_push(wr_tuner *t)
+/* queue the copy of one block's audio, right behind the kernel that produces it */
+static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used)
 {
+	if (t->ring.empty())
+		return WR_OK;
 	std::lock_guard<std::mutex> lk(t->ring_lock);
-	const unsigned long long seq = t->ring_seq++;
-	Group *g = single_group(t);
-	if (!g)
+	if (single_group(t) != g)
 		return WR_OK;                           /* no or several rate groups: not queued (see the header) */
 	if (t->ring_count == t->ring.size()) {
 		++t->ring_overruns;                     /* io/rtlsdrtuner.cxx:100-117: the new block is dropped */
 		return WR_OK;
 	}
 	wr_tuner::RingSlot &r = t->ring[t->ring_head];
-	const unsigned int used = group_slots_used(g);
-	const size_t need = (size_t)used * g->last_k2;
+	const size_t need = (size_t)used * k2;
 	if (need > r.cap) {
 		(void)hipHostFree(r.host);
 		r.host = nullptr;
@@ -1270,10 +1372,10 @@ static int ring_push(wr_tuner *t)
 	}
 	hipStream_t st = t->dev->stream;
 	if (need)
-		HIP_TRY(hipMemcpy2DAsync(r.host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
-		                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpy2DAsync(r.host, k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
+		                         k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(r.done, st));
-	r.stride = r.frames = g->last_k2;
+	r.stride = r.frames = k2;
 	r.slots = used;
 	r.seq = seq;
 	t->ring_head = (t->ring_head + 1) % (unsigned int)t->ring.size();
@@ -1307,7 +1409,7 @@ extern "C" int wr_tuner_audio_ring(wr_tuner *t, unsigned int depth)
 	for (wr_tuner::RingSlot &r : t->ring)
 		HIP_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
 	t->ring_head = t->ring_count = 0;
-	t->ring_seq = t->ring_overruns = 0;
+	t->ring_overruns = 0;
 	return WR_OK;
 }
 

@@ -78,12 +78,35 @@ hipError_t wrk_demod(hipStream_t st, int mode, const float *in, size_t nframes, 
                      float prev_q, float *out);
 hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t count);
 
+/* what one launch of the post stage (demodulator + audio filter of ONE block) works on */
+struct WrPostArgs {
+	const float *chan_iq;        /* [k1][slots][2] the block's channel IQ */
+	unsigned int k1, slots;
+	const int   *mode;
+	const float *prev_iq;        /* [slots][2] frame before the block's first */
+	float       *prev_next;
+	const float *dem_hist;       /* [63][slots] audio filter history */
+	float       *dem_hist_next;
+	size_t       k2;
+	unsigned int ntiles;         /* tiles of POST_TK audio frames per lane group */
+	const float *taps2;
+	float       *audio;
+	size_t       k2max;
+	float        scale;
+	unsigned int d2;
+	unsigned int groups;         /* lane groups in use */
+};
+/* `post` (optional): the post stage of the PREVIOUS block, run by extra workgroups of the same
+ * launch beside this block's DDC (only taken up by the ROTATE / uniform-taps kernel; *post_taken
+ * says whether it was) */
 hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
-                         int num_cus);
+                         int num_cus, const WrPostArgs *post = nullptr, bool *post_taken = nullptr);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A);
 bool wrk_tuner_post_supported(unsigned int d2);
 hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
                           const float *hist, float *hist_next);

@@ -351,6 +351,177 @@ __device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, co
 	return cur[n];
 }
 
+/*
+ * k_tuner_post<D2>: Demodulator::process and the audio LowPass::process in one pass
+ * (dsp/demodulator.cxx:77-115 feeding dsp/lowpass.cxx:131-162), for the common small audio
+ * decimations and when nobody asked for the demodulator's own output (wr_tuner_keep_stages).
+ * The demod rows of a tile are computed from the channel IQ rows straight into LDS: the
+ * 4 B/frame/channel demod array makes no round trip through HBM and one launch goes away.
+ * Rows a tile shares with its neighbour (the FIR overlap) are demodulated by both.
+ *
+ *   blockIdx.x <  ntiles : POST_TK audio frames x 64 slots.
+ *        stage  : all 8 waves; thread (row, lane) takes rows row, row+8, ... of the tile.  Row rr
+ *                 of [history | current] is dem_hist[rr] for rr < 63, else the demodulated
+ *                 channel frame rr - 63 (its predecessor re-read from L1/L2, or prev_iq).
+ *        filter : POST_TK / POST_B waves; thread (lane, group of POST_B consecutive frames):
+ *                 the lane's 64 taps in registers, each staged row read from LDS ONCE and
+ *                 applied to every frame of the group that uses it.  D2 is a template
+ *                 parameter so that which tap meets which row is resolved at compile time.
+ *                 Per frame the products are added oldest-first, unfused, as lowpass.cxx does.
+ *   blockIdx.x == ntiles : what the block leaves behind per lane group, as k_tuner_demod does:
+ *                 the last 63 demod outputs (audio filter history) and the last channel
+ *                 frame (Demodulator::prev_i/q), into the other ping-pong set.
+ */
+#ifndef POST_TK
+#define POST_TK 16u
+#endif
+#define POST_B 4u
+#define POST_THREADS 512u
+__device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
+                                          unsigned int s, int m, const float2 *__restrict__ prev_iq,
+                                          const float *__restrict__ dem_hist, size_t rr)
+{
+	if (rr < WR_HIST)
+		return dem_hist[rr * slots + s];
+	const size_t kk = rr - WR_HIST;
+	if (kk >= k1)
+		return 0.0f;                                    /* beyond the block: never read by lowpass.cxx */
+	const float2 z = chan_iq[kk * slots + s];
+	const float2 zp = kk ? chan_iq[(kk - 1u) * slots + s] : prev_iq[s];
+	return demod_one(m, z.x, z.y, zp.x, zp.y);
+}
+
+/* One workgroup's share of the post stage: tile `bx` < ntiles of lane group `g`, or (bx == ntiles)
+ * the group's end-of-block state.  HREGS: the filter's taps live in registers, one set per lane
+ * (the stand-alone kernel); otherwise each tap is read from memory once per thread, when its
+ * turn comes -- 64 fewer VGPRs, for the workgroups that run this inside k_tuner_ddc beside the
+ * next block's DDC.  `stage` and `tile` are LDS: [NEED][64] and
+ * [POST_TK][65] floats. */
+template <unsigned int D2, bool HREGS>
+__device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, unsigned int g,
+                                          float *stage, float *tile)
+{
+	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
+	constexpr unsigned int NROW = POST_THREADS / 64u;
+	const float2 *__restrict__ chan_iq = (const float2 *)A.chan_iq;
+	const float2 *__restrict__ prev_iq = (const float2 *)A.prev_iq;
+	const float *__restrict__ dem_hist = A.dem_hist;
+	const float *__restrict__ taps2 = A.taps2;
+	const unsigned int k1 = A.k1, slots = A.slots;
+	const unsigned int lane = threadIdx.x & 63u;        /* slot within the group */
+	const unsigned int row = threadIdx.x >> 6;
+	const unsigned int s = g * 64u + lane;
+	const int m = A.mode[s];                            /* < 0: idle slot */
+
+	if (bx == A.ntiles) {
+		if (m < 0)
+			return;
+		const size_t first = k1;                        /* the last 63 rows of [history | current] */
+#pragma unroll
+		for (unsigned int r = row; r < WR_HIST; r += NROW)   /* unrolled: one memory round, not eight */
+			A.dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r);
+		if (row == 0)
+			((float2 *)A.prev_next)[s] = k1 ? chan_iq[(size_t)(k1 - 1u) * slots + s] : prev_iq[s];
+		return;
+	}
+
+	const size_t kbase = (size_t)bx * POST_TK;
+	const size_t r0 = kbase * D2;
+	/* the filter waves fetch their taps first: the latency hides behind the stage phase */
+	float h[HREGS ? WR_FIR_LENGTH : 1];
+	if (HREGS && row < POST_TK / POST_B) {
+#pragma unroll
+		for (int j = 0; j < (HREGS ? WR_FIR_LENGTH : 1); ++j)
+			h[j] = taps2[(size_t)j * slots + s];
+	}
+	{
+		/* a run of consecutive rows per thread: each channel frame is loaded once and stays in a
+		 * register as the next row's predecessor */
+		constexpr unsigned int PER = (NEED + NROW - 1u) / NROW;
+		const unsigned int beg = row * PER;
+		const unsigned int end = (beg + PER < NEED) ? beg + PER : NEED;
+		float2 zp = make_float2(0.0f, 0.0f);
+		if (m >= 0 && beg < end) {
+			const size_t rr = r0 + beg;
+			if (rr == WR_HIST)
+				zp = prev_iq[s];
+			else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
+				zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
+		}
+#pragma unroll 6
+		for (unsigned int r = beg; r < end; ++r) {
+			const size_t rr = r0 + r;
+			float v = 0.0f;
+			if (m >= 0) {
+				if (rr < WR_HIST) {
+					v = dem_hist[rr * slots + s];
+					if (rr + 1u == WR_HIST)
+						zp = prev_iq[s];                    /* the next row is the block's first frame */
+				} else if (rr - WR_HIST < k1) {
+					const float2 z = chan_iq[(rr - WR_HIST) * slots + s];
+					v = demod_one(m, z.x, z.y, zp.x, zp.y);
+					zp = z;
+				}
+			}
+			stage[r * 64u + lane] = v;
+		}
+	}
+	__syncthreads();
+	if (row < POST_TK / POST_B) {
+		float acc[POST_B];
+#pragma unroll
+		for (unsigned int o = 0; o < POST_B; ++o)
+			acc[o] = 0.0f;
+		const float *x = stage + (row * POST_B * D2) * 64u + lane;
+		if (HREGS) {
+			/* rows outermost: each staged row is read from LDS once and meets the tap of every
+			 * frame of the group that uses it (which tap: resolved at compile time) */
+#pragma unroll
+			for (unsigned int r = 0; r < (POST_B - 1u) * D2 + WR_FIR_LENGTH; ++r) {
+				const float xv = x[r * 64u];
+#pragma unroll
+				for (unsigned int o = 0; o < POST_B; ++o) {
+					if (r >= o * D2 && r - o * D2 < WR_FIR_LENGTH)
+						acc[o] = acc[o] + h[HREGS ? WR_FIR_LENGTH - 1u - (r - o * D2) : 0] * xv;
+				}
+			}
+		} else {
+			/* taps outermost, newest tap last (so that every frame still adds its products
+			 * oldest row first): one memory read per tap, shared by the frames of the group; the
+			 * rows come from LDS once per frame */
+#pragma unroll 16
+			for (int j = WR_FIR_LENGTH - 1; j >= 0; --j) {
+				const float hj = taps2[(size_t)j * slots + s];
+#pragma unroll
+				for (unsigned int o = 0; o < POST_B; ++o)
+					acc[o] = acc[o] + hj * x[(o * D2 + (WR_FIR_LENGTH - 1u - (unsigned int)j)) * 64u];
+			}
+		}
+#pragma unroll
+		for (unsigned int o = 0; o < POST_B; ++o)
+			tile[(row * POST_B + o) * 65u + lane] = acc[o];
+	}
+	__syncthreads();
+	/* transposed write: POST_TK consecutive frames of one slot per POST_TK threads */
+	for (unsigned int e = threadIdx.x; e < 64u * POST_TK; e += POST_THREADS) {
+		const unsigned int sl = e / POST_TK, kk = e - sl * POST_TK;
+		const unsigned int so = g * 64u + sl;
+		const size_t k = kbase + kk;
+		if (k < A.k2 && A.mode[so] >= 0)
+			A.audio[(size_t)so * A.k2max + k] = (A.scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * A.scale;
+	}
+}
+
+template <unsigned int D2>
+__global__ void __launch_bounds__(POST_THREADS)
+k_tuner_post(WrPostArgs A)
+{
+	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
+	__shared__ float stage[NEED * 64u];
+	__shared__ float tile[POST_TK * 65u];
+	post_role<D2, true>(A, blockIdx.x, blockIdx.y, stage, tile);
+}
+
 /* LDS plan of k_tuner_ddc: [0, 128 KiB) the two replicated NCO tables (SPLIT only),
  * then one private 2 x 512 B sample window per wave (double buffered across units). */
 #define DDC_TABLE_BYTES   (2u * WR_SPLIT_N * 32u * 8u)
@@ -363,7 +534,11 @@ __device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, co
 #endif
 #define DDC_LDS_BYTES     (DDC_TABLE_BYTES + DDC_WAVES * 2u * 512u)
 
-template <int NCO, bool UTAPS>
+/* PD2 > 0: workgroups n_ddc.. of the grid run the post stage (audio decimation PD2) of the
+ * PREVIOUS block -- see post_role and wr_capi.hip: the two have nothing to do with each other
+ * except that they share the CUs, the post stage's latency-bound phases filling in between the
+ * DDC's arithmetic.  Their dependency is the kernel boundary before this launch. */
+template <int NCO, bool UTAPS, unsigned int PD2>
 __global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && UTAPS ? DDC_ROTATE_WGS_PER_CU * DDC_ROTATE_WAVES / 4u : DDC_WAVES / 4u)))
 k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist,
@@ -375,9 +550,17 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
             const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
-            const float2 *__restrict__ lo_cs)
+            const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post)
 {
 	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
+	if (PD2 != 0u && blockIdx.x >= n_ddc) {
+		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
+		const unsigned int idx = blockIdx.x - n_ddc;
+		float *stage = (float *)lds;
+		post_role<(PD2 ? PD2 : 1u), false>(post, idx % (post.ntiles + 1u), idx / (post.ntiles + 1u), stage,
+		                                    stage + NEED * 64u);
+		return;
+	}
 	const unsigned int lane = threadIdx.x & 63u;
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned int waves_per_wg = blockDim.x >> 6;
@@ -427,7 +610,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	{
 		/* spread over the whole grid: 63 x slots LO evaluations are a few per workgroup */
 		const unsigned int nlo = (unsigned int)nframes;
-		const unsigned int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+		const unsigned int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = n_ddc * blockDim.x;
 		for (unsigned int s = gtid; s < slots; s += gsz) {
 			const bool act = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
 			phase_next[s] = act ? phase[s] + nlo * step[s] : phase[s];
@@ -475,12 +658,12 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 * units it came every few units.  Waves with the same k (neighbours in a workgroup) read
 	 * the same window at about the same time: one HBM read, the rest L1/L2 hits. */
 	const unsigned int k1u = (unsigned int)k1;
-	const unsigned int nwaves = gridDim.x * waves_per_wg;
+	const unsigned int nwaves = n_ddc * waves_per_wg;
 	const unsigned int wid = blockIdx.x * waves_per_wg + wave;
 	/* ROTATE with per-lane taps keeps the taps of ONE lane group in LDS (16 KiB) instead of 64
 	 * registers per lane: there a whole workgroup keeps to one group */
 	constexpr bool LTAPS = (NCO == WR_NCO_ROTATE) && !UTAPS;
-	const unsigned int wpg = LTAPS ? (gridDim.x / groups) * waves_per_wg : nwaves / groups;   /* >= 1: see the launcher */
+	const unsigned int wpg = LTAPS ? (n_ddc / groups) * waves_per_wg : nwaves / groups;   /* >= 1: see the launcher */
 	const unsigned int g = LTAPS ? blockIdx.x % groups : wid % groups;
 	unsigned int k = LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
 	if (k >= wpg)
@@ -866,148 +1049,6 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 	}
 }
 
-/*
- * k_tuner_post<D2>: Demodulator::process and the audio LowPass::process in one pass
- * (dsp/demodulator.cxx:77-115 feeding dsp/lowpass.cxx:131-162), for the common small audio
- * decimations and when nobody asked for the demodulator's own output (wr_tuner_keep_stages).
- * The demod rows of a tile are computed from the channel IQ rows straight into LDS: the
- * 4 B/frame/channel demod array makes no round trip through HBM and one launch goes away.
- * Rows a tile shares with its neighbour (the FIR overlap) are demodulated by both.
- *
- *   blockIdx.x <  ntiles : POST_TK audio frames x 64 slots.
- *        stage  : all 8 waves; thread (row, lane) takes rows row, row+8, ... of the tile.  Row rr
- *                 of [history | current] is dem_hist[rr] for rr < 63, else the demodulated
- *                 channel frame rr - 63 (its predecessor re-read from L1/L2, or prev_iq).
- *        filter : POST_TK / POST_B waves; thread (lane, group of POST_B consecutive frames):
- *                 the lane's 64 taps in registers, each staged row read from LDS ONCE and
- *                 applied to every frame of the group that uses it.  D2 is a template
- *                 parameter so that which tap meets which row is resolved at compile time.
- *                 Per frame the products are added oldest-first, unfused, as lowpass.cxx does.
- *   blockIdx.x == ntiles : what the block leaves behind per lane group, as k_tuner_demod does:
- *                 the last 63 demod outputs (audio filter history) and the last channel
- *                 frame (Demodulator::prev_i/q), into the other ping-pong set.
- */
-#ifndef POST_TK
-#define POST_TK 16u
-#endif
-#define POST_B 4u
-#define POST_THREADS 512u
-__device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
-                                          unsigned int s, int m, const float2 *__restrict__ prev_iq,
-                                          const float *__restrict__ dem_hist, size_t rr)
-{
-	if (rr < WR_HIST)
-		return dem_hist[rr * slots + s];
-	const size_t kk = rr - WR_HIST;
-	if (kk >= k1)
-		return 0.0f;                                    /* beyond the block: never read by lowpass.cxx */
-	const float2 z = chan_iq[kk * slots + s];
-	const float2 zp = kk ? chan_iq[(kk - 1u) * slots + s] : prev_iq[s];
-	return demod_one(m, z.x, z.y, zp.x, zp.y);
-}
-
-template <unsigned int D2>
-__global__ void __launch_bounds__(POST_THREADS)
-k_tuner_post(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
-             const int *__restrict__ mode, const float2 *__restrict__ prev_iq, float2 *__restrict__ prev_next,
-             const float *__restrict__ dem_hist, float *__restrict__ dem_hist_next,
-             size_t k2, unsigned int ntiles, const float *__restrict__ taps2, float *__restrict__ audio,
-             size_t k2max, float scale)
-{
-	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
-	constexpr unsigned int NROW = POST_THREADS / 64u;
-	__shared__ float stage[NEED * 64u];
-	__shared__ float tile[POST_TK * 65u];
-	const unsigned int lane = threadIdx.x & 63u;        /* slot within the group */
-	const unsigned int row = threadIdx.x >> 6;
-	const unsigned int g = blockIdx.y;
-	const unsigned int s = g * 64u + lane;
-	const int m = mode[s];                              /* < 0: idle slot */
-
-	if (blockIdx.x == ntiles) {
-		if (m < 0)
-			return;
-		const size_t first = k1;                        /* the last 63 rows of [history | current] */
-#pragma unroll
-		for (unsigned int r = row; r < WR_HIST; r += NROW)   /* unrolled: one memory round, not eight */
-			dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r);
-		if (row == 0)
-			prev_next[s] = k1 ? chan_iq[(size_t)(k1 - 1u) * slots + s] : prev_iq[s];
-		return;
-	}
-
-	const size_t kbase = (size_t)blockIdx.x * POST_TK;
-	const size_t r0 = kbase * D2;
-	/* the filter waves fetch their taps first: the latency hides behind the stage phase */
-	float h[WR_FIR_LENGTH];
-	if (row < POST_TK / POST_B) {
-#pragma unroll
-		for (int j = 0; j < WR_FIR_LENGTH; ++j)
-			h[j] = taps2[(size_t)j * slots + s];
-	}
-	{
-		/* a run of consecutive rows per thread: each channel frame is loaded once and stays in a
-		 * register as the next row's predecessor */
-		constexpr unsigned int PER = (NEED + NROW - 1u) / NROW;
-		const unsigned int beg = row * PER;
-		const unsigned int end = (beg + PER < NEED) ? beg + PER : NEED;
-		float2 zp = make_float2(0.0f, 0.0f);
-		if (m >= 0 && beg < end) {
-			const size_t rr = r0 + beg;
-			if (rr == WR_HIST)
-				zp = prev_iq[s];
-			else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
-				zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
-		}
-#pragma unroll 6
-		for (unsigned int r = beg; r < end; ++r) {
-			const size_t rr = r0 + r;
-			float v = 0.0f;
-			if (m >= 0) {
-				if (rr < WR_HIST) {
-					v = dem_hist[rr * slots + s];
-					if (rr + 1u == WR_HIST)
-						zp = prev_iq[s];                    /* the next row is the block's first frame */
-				} else if (rr - WR_HIST < k1) {
-					const float2 z = chan_iq[(rr - WR_HIST) * slots + s];
-					v = demod_one(m, z.x, z.y, zp.x, zp.y);
-					zp = z;
-				}
-			}
-			stage[r * 64u + lane] = v;
-		}
-	}
-	__syncthreads();
-	if (row < POST_TK / POST_B) {
-		float acc[POST_B];
-#pragma unroll
-		for (unsigned int o = 0; o < POST_B; ++o)
-			acc[o] = 0.0f;
-		const float *x = stage + (row * POST_B * D2) * 64u + lane;
-#pragma unroll
-		for (unsigned int r = 0; r < (POST_B - 1u) * D2 + WR_FIR_LENGTH; ++r) {
-			const float xv = x[r * 64u];
-#pragma unroll
-			for (unsigned int o = 0; o < POST_B; ++o) {
-				if (r >= o * D2 && r - o * D2 < WR_FIR_LENGTH)
-					acc[o] = acc[o] + h[WR_FIR_LENGTH - 1u - (r - o * D2)] * xv;
-			}
-		}
-#pragma unroll
-		for (unsigned int o = 0; o < POST_B; ++o)
-			tile[(row * POST_B + o) * 65u + lane] = acc[o];
-	}
-	__syncthreads();
-	/* transposed write: POST_TK consecutive frames of one slot per POST_TK threads */
-	for (unsigned int e = threadIdx.x; e < 64u * POST_TK; e += POST_THREADS) {
-		const unsigned int sl = e / POST_TK, kk = e - sl * POST_TK;
-		const unsigned int so = g * 64u + sl;
-		const size_t k = kbase + kk;
-		if (k < k2 && mode[so] >= 0)
-			audio[(size_t)so * k2max + k] = (scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * scale;
-	}
-}
-
 /* strided row gather: dst[r*width + i] = src[r*row_stride + col_offset + i] */
 __global__ void k_gather_rows(const float *__restrict__ src, size_t rows, size_t row_stride,
                               size_t col_offset, unsigned int width, float *__restrict__ dst)
@@ -1119,17 +1160,42 @@ template <int NCO, bool UTAPS> struct DdcGeom {
 	                                           : (NCO == WR_NCO_EXACT) ? 2u : 1u;
 };
 
-template <int NCO, bool UTAPS>
+template <int NCO, bool UTAPS, unsigned int PD2>
 static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
-                             const float *table_dev, const float *hi_dev, const float *lo_dev, int num_cus)
+                             const float *table_dev, const float *hi_dev, const float *lo_dev, int num_cus,
+                             const WrPostArgs *post)
 {
 	constexpr unsigned int W = DdcGeom<NCO, UTAPS>::waves;
 	const unsigned int ngroups = L.slots_used / 64;
+	size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
+	             : (W * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
+	               + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
+	unsigned int wgs_per_cu = DdcGeom<NCO, UTAPS>::wgs_per_cu;
+	unsigned int post_wgs = 0;
+	if (PD2 != 0u) {
+		/* the post workgroups' stage + tile set the LDS size of every workgroup of the launch;
+		 * POST_RESERVE workgroup slots per CU are left to them (they come and go, the DDC ones
+		 * persist).  Measured at C2, kernel duration: 1 slot 41.3 us (the 508 post workgroups
+		 * take two rounds through 256 slots and finish last), 2 slots 39.6, 3 slots 51 (the DDC
+		 * starves); DDC + post as two launches: 34.8 + 15.3 + gap. */
+		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
+		const size_t post_lds = ((size_t)NEED * 64u + POST_TK * 65u) * sizeof(float);
+		if (post_lds > lds)
+			lds = post_lds;
+		unsigned int fit = (unsigned int)((160u * 1024u) / lds);
+		if (fit < wgs_per_cu)
+			wgs_per_cu = fit;
+#ifndef POST_RESERVE
+#define POST_RESERVE 2u
+#endif
+		wgs_per_cu = (wgs_per_cu > POST_RESERVE) ? wgs_per_cu - POST_RESERVE : 1u;
+		post_wgs = (post->ntiles + 1u) * post->groups;
+	}
 	/* launched even for a block too short to yield a channel-rate frame: workgroup 0 still
 	 * advances the NCO (downconverter.cxx:103 runs per input frame) and rolls the histories */
 	const size_t units = L.k1 * ngroups;
 	unsigned int wgs = (unsigned int)((units + W - 1) / W);
-	const unsigned int cap = (unsigned int)num_cus * DdcGeom<NCO, UTAPS>::wgs_per_cu;
+	const unsigned int cap = (unsigned int)num_cus * wgs_per_cu;
 	if (wgs > cap)
 		wgs = cap;
 	if (NCO == WR_NCO_ROTATE && !UTAPS) {
@@ -1144,38 +1210,52 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		if (wgs < min_wgs)
 			wgs = min_wgs;
 	}
-	const size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
-	                   : (W * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
-	                     + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
 	static bool attr_done[WR_MAX_DEVICES];
 	if (lds > 64 * 1024) {
-		hipError_t e = allow_lds((const void *)k_tuner_ddc<NCO, UTAPS>, lds, attr_done);
+		hipError_t e = allow_lds((const void *)k_tuner_ddc<NCO, UTAPS, PD2>, lds, attr_done);
 		if (e != hipSuccess)
 			return e;
 	}
-	k_tuner_ddc<NCO, UTAPS><<<wgs, W * 64u, lds, st>>>(
+	const WrPostArgs pa = post ? *post : WrPostArgs();
+	k_tuner_ddc<NCO, UTAPS, PD2><<<wgs + post_wgs, W * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
 		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
 		(float2 *)G.chan_iq[L.cb], table_dev,
-		(const float2 *)hi_dev, (const float2 *)lo_dev);
+		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa);
 	return hipGetLastError();
 }
 
 hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
-                         int num_cus)
+                         int num_cus, const WrPostArgs *post, bool *post_taken)
 {
+	if (post_taken)
+		*post_taken = false;
 	if (!L.slots_used)
 		return hipSuccess;
 	if (L.nco_mode == WR_NCO_EXACT)
-		return launch_ddc<WR_NCO_EXACT, false>(st, L, G, table_dev, hi_dev, lo_dev, num_cus);
-	if (L.nco_mode == WR_NCO_ROTATE)
-		return L.uniform_taps ? launch_ddc<WR_NCO_ROTATE, true>(st, L, G, table_dev, hi_dev, lo_dev, num_cus)
-		                      : launch_ddc<WR_NCO_ROTATE, false>(st, L, G, table_dev, hi_dev, lo_dev, num_cus);
-	return L.uniform_taps ? launch_ddc<WR_NCO_SPLIT, true>(st, L, G, table_dev, hi_dev, lo_dev, num_cus)
-	                      : launch_ddc<WR_NCO_SPLIT, false>(st, L, G, table_dev, hi_dev, lo_dev, num_cus);
+		return launch_ddc<WR_NCO_EXACT, false, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
+	if (L.nco_mode == WR_NCO_ROTATE) {
+		if (!L.uniform_taps)
+			return launch_ddc<WR_NCO_ROTATE, false, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
+		if (post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
+			if (post_taken)
+				*post_taken = true;
+			switch (post->d2) {
+			case 1: return launch_ddc<WR_NCO_ROTATE, true, 1>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
+			case 2: return launch_ddc<WR_NCO_ROTATE, true, 2>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
+			case 3: return launch_ddc<WR_NCO_ROTATE, true, 3>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
+			case 4: return launch_ddc<WR_NCO_ROTATE, true, 4>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
+			case 5: return launch_ddc<WR_NCO_ROTATE, true, 5>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
+			default: return launch_ddc<WR_NCO_ROTATE, true, 6>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
+			}
+		}
+		return launch_ddc<WR_NCO_ROTATE, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
+	}
+	return L.uniform_taps ? launch_ddc<WR_NCO_SPLIT, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr)
+	                      : launch_ddc<WR_NCO_SPLIT, false, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
 }
 
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
@@ -1190,15 +1270,34 @@ hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	return hipGetLastError();
 }
 
-template <unsigned int D2>
-static hipError_t launch_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
+WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G)
 {
 	const int p = L.parity;
-	const unsigned int ntiles = (unsigned int)((L.k2 + POST_TK - 1) / POST_TK);
-	dim3 grid(ntiles + 1u, L.slots_used / 64);
-	k_tuner_post<D2><<<grid, POST_THREADS, 0, st>>>(
-		(const float2 *)G.chan_iq[L.cb], (unsigned int)L.k1, L.slots, G.mode, (const float2 *)G.prev_iq[p],
-		(float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1], L.k2, ntiles, G.taps2, G.audio, L.k2max, L.audio_scale);
+	WrPostArgs A;
+	A.chan_iq = G.chan_iq[L.cb];
+	A.k1 = (unsigned int)L.k1;
+	A.slots = L.slots;
+	A.mode = G.mode;
+	A.prev_iq = G.prev_iq[p];
+	A.prev_next = G.prev_iq[p ^ 1];
+	A.dem_hist = G.dem[p];
+	A.dem_hist_next = G.dem[p ^ 1];
+	A.k2 = L.k2;
+	A.ntiles = (unsigned int)((L.k2 + POST_TK - 1) / POST_TK);
+	A.taps2 = G.taps2;
+	A.audio = G.audio;
+	A.k2max = L.k2max;
+	A.scale = L.audio_scale;
+	A.d2 = L.d2;
+	A.groups = L.slots_used / 64;
+	return A;
+}
+
+template <unsigned int D2>
+static hipError_t launch_post(hipStream_t st, const WrPostArgs &A)
+{
+	dim3 grid(A.ntiles + 1u, A.groups);
+	k_tuner_post<D2><<<grid, POST_THREADS, 0, st>>>(A);
 	return hipGetLastError();
 }
 
@@ -1208,19 +1307,26 @@ bool wrk_tuner_post_supported(unsigned int d2)
 	return d2 >= 1 && d2 <= 6;
 }
 
+hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A)
+{
+	if (!A.k1 || !A.groups)
+		return hipSuccess;
+	switch (A.d2) {
+	case 1: return launch_post<1>(st, A);
+	case 2: return launch_post<2>(st, A);
+	case 3: return launch_post<3>(st, A);
+	case 4: return launch_post<4>(st, A);
+	case 5: return launch_post<5>(st, A);
+	case 6: return launch_post<6>(st, A);
+	default: return hipErrorInvalidValue;
+	}
+}
+
 hipError_t wrk_tuner_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
 {
 	if (!L.k1 || !L.slots_used)
 		return hipSuccess;
-	switch (L.d2) {
-	case 1: return launch_post<1>(st, L, G);
-	case 2: return launch_post<2>(st, L, G);
-	case 3: return launch_post<3>(st, L, G);
-	case 4: return launch_post<4>(st, L, G);
-	case 5: return launch_post<5>(st, L, G);
-	case 6: return launch_post<6>(st, L, G);
-	default: return hipErrorInvalidValue;
-	}
+	return wrk_tuner_post_args(st, wrk_post_args(L, G));
 }
 
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)

@@ -124,6 +124,10 @@ class Tuner:
             mask |= 1 << st
         check(self.lib.wr_tuner_keep_stages(self.h, mask))
 
+    def flush(self):
+        """Launch a post stage (demod + audio filter) that is still waiting for the next submit."""
+        check(self.lib.wr_tuner_flush(self.h))
+
     def audio_ring(self, depth):
         """Pinned host ring for the audio of every submit (0 = off)."""
         check(self.lib.wr_tuner_audio_ring(self.h, depth))

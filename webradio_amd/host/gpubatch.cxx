@@ -364,6 +364,8 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
+	/* the graph hands this block's audio on within this very run(): no waiting for the next launch */
+	wr_tuner_flush(_tuner);
 	/* one transfer brings back the audio of every channel: through the tuner's pinned ring
 	 * (queued behind the kernels by the submit itself), read in place until the next block */
 	size_t stride = 0, frames = 0;
