@@ -118,3 +118,65 @@ def test_ring_consumer_thread(dev):
     for b in range(nb):
         assert np.array_equal(got[b], want[b]), b
     t.destroy()
+
+
+def test_deferred_post_stage_keeps_block_order(dev, oracle):
+    """The demod + audio filter of block b run inside the launch of block b+1 (wr_tuner_flush in the
+    header).  Nothing may be observed out of order: mode / IF / audio passband changes made
+    between two submits (no fetch in between, so a post stage IS pending) apply to the right
+    block, a keep-stages request switches paths mid-stream, a flush in the middle is harmless.
+    Every block's audio, taken from the ring afterwards, against the oracle."""
+    nb = 10
+    blocks = _blocks(nb)
+    rxs = [oracle.Receiver(FS, f, 128_000, 5_000, [oracle.FM, oracle.AM][c % 2], 160, 1_000) for c, f in enumerate(IFS)]
+    t = _tuner(dev)
+    t.audio_ring(nb)
+    want = []
+    for b, iq in enumerate(blocks):
+        if b == 2:                                    # detector change while block 1's post stage is pending
+            rxs[3].set_mode(oracle.USB); t.set_mode(3, capi.WR_USB)
+        if b == 4:
+            rxs[5].set_if(4321); t.set_if(5, 4321)
+        if b == 5:
+            t.flush(); t.flush()
+        if b == 6:
+            t.keep_stages(capi.WR_STAGE_DEMOD)       # two-kernel path from here on ...
+        if b == 8:
+            t.keep_stages()                           # ... and back
+        t.submit_host(iq)
+        want.append(np.stack([rx.run(iq)[0] for rx in rxs]))
+    t.flush()
+    assert t.ring_stats() == (nb, 0)
+    for b in range(nb):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b
+        for c in range(len(IFS)):
+            if rxs[c].s.mode == oracle.FM or (c == 3 and b < 2):
+                continue                               # FM: device atan2 (checked elsewhere within tolerance)
+            assert np.abs(audio[c] - want[b][c]).max() <= 4e-6, (b, c)
+    t.destroy()
+
+
+def test_deferral_off_gives_the_same_bits(dev):
+    import os
+    blocks = _blocks(4)
+    outs = []
+    for env in ("1", "0"):
+        os.environ["WR_DEFER_POST"] = env
+        try:
+            t = _tuner(dev)
+        finally:
+            del os.environ["WR_DEFER_POST"]
+        t.audio_ring(4)
+        for iq in blocks:
+            t.submit_host(iq)
+        t.flush()
+        got = []
+        for _ in range(4):
+            a, _ = t.ring_acquire()
+            got.append(a.copy())
+            t.ring_release()
+        outs.append(np.stack(got))
+        t.destroy()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
