@@ -2,7 +2,7 @@
 # kernel timeline of the last quick_time steps: start/end (us, relative) and queue id per kernel
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $GRAFT_REPO_ROOT/tools/quick_time.py 256 split > /tmp/tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $GRAFT_REPO_ROOT/tools/quick_time.py 256 rotate > /tmp/tl.log 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = []
