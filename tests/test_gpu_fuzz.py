@@ -141,3 +141,56 @@ def test_random_standalone_blocks(dev, oracle, seed):
             assert np.abs(g - w).max() <= FM_ATOL
         else:
             assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "8"))))
+def test_random_streams_through_the_ring(dev, oracle, seed):
+    """The same kind of random configuration, consumed the way a streaming sink would: no fetch
+    between submits, every block's audio taken from the pinned ring afterwards.  With one
+    channel filter and one audio filter per lane group (what radio.cxx sets up) the demod + audio
+    filter of a block then run inside the NEXT block's launch (wr_tuner_flush in the header)."""
+    rng = np.random.default_rng(5000 + seed)
+    fs, crate, arate = RATES[seed % len(RATES)]
+    d1, d2 = fs // crate, crate // arate
+    nchan = int(rng.choice([1, 3, 64, 65, 130]))
+    base = d1 * d2
+    block = int(rng.choice([base * 2, base * 9, base * 5 + int(rng.integers(0, base)), 3 * 4096]))
+    if block > 60_000:
+        block = base * 3 + 1
+    cpb, apb = int(rng.choice([fs // 16, fs // 8, fs // 3])), int(rng.choice([crate // 8, crate // 4]))
+    ifs = [int(v) for v in rng.integers(-fs // 2 + 1, fs // 2, nchan)]
+    modes = [int(rng.integers(0, 4)) for _ in range(nchan)]
+    t = Tuner(dev, fs, nchan, block)
+    rxs, chans = [], []
+    for c in range(nchan):
+        rxs.append(oracle.Receiver(fs, ifs[c], cpb, crate, modes[c], apb, arate))
+        chans.append(t.add_receiver(ifs[c], cpb, crate, modes[c], apb, arate))
+    gain = max(1.0, float(np.abs(oracle.lowpass_design(apb, crate)).sum()))
+    nb = 6
+    t.audio_ring(nb)
+    carriers = ifs[:: max(1, nchan // 3)][:3]
+    want, pos = [], 0
+    was_fm = [m == capi.WR_FM for m in modes]
+    for b in range(nb):
+        if b == 3:
+            c = int(rng.integers(nchan))
+            ifs[c] = int(rng.integers(-fs // 2 + 1, fs // 2))
+            modes[c] = int(rng.integers(0, 4))
+            was_fm[c] = was_fm[c] or modes[c] == capi.WR_FM
+            rxs[c].set_if(ifs[c]); rxs[c].set_mode(modes[c])
+            t.set_if(chans[c], ifs[c]); t.set_mode(chans[c], modes[c])
+        iq = synth.fm_stream(block, fs, carriers, start_frame=pos, amp=0.5 / len(carriers), fm_base=fs / 70_000.0,
+                             fm_step=fs / 300_000.0, beta=2.0, seed=seed)
+        pos += block
+        t.submit_host(iq)
+        want.append([rx.run(iq)[0] for rx in rxs])
+    t.flush()
+    assert t.ring_stats() == (nb, 0)
+    for b in range(nb):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b and audio.shape[1] == want[b][0].size
+        for c in range(nchan):
+            if not was_fm[c] and want[b][c].size:
+                assert np.abs(audio[c] - want[b][c]).max() <= 2e-6 * gain, (seed, b, c)
+    t.destroy()
