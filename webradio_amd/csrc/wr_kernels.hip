@@ -6,17 +6,18 @@
  *      stands alone in a graph; arithmetic is the reference's, operation for
  *      operation (compiled with -ffp-contract=off so nothing is fused behind our
  *      back), hence bit-identical to the CPU path.
- *   2. the fused per-tuner path (k_tuner_ddc -> k_tuner_demod -> k_tuner_audio):
- *      every receiver chain attached to one tuner in one launch sequence.  The
- *      full-rate mixer output, which the reference materialises per receiver
- *      (8 B x fs x channels), never exists: only the 64 input frames that reach
- *      a tap of each decimated output are mixed (lowpass.cxx:150-158 touches
- *      nothing else when decimation >= 64).
+ *   2. the fused per-tuner path: k_tuner_ddc (NCO mix + channel filter of every receiver
+ *      chain attached to one tuner) and the post stage (demodulator + audio filter:
+ *      k_tuner_post, or post_role inside the NEXT block's k_tuner_ddc launch; k_tuner_demod +
+ *      k_tuner_audio when the demodulator output itself is wanted).  The full-rate mixer
+ *      output, which the reference materialises per receiver (8 B x fs x channels), never
+ *      exists: only the 64 input frames that reach a tap of each decimated output are
+ *      mixed (lowpass.cxx:150-158 touches nothing else when decimation >= 64).
  *
  * Wavefronts are 64 wide.  In the fused kernels a LANE IS A RECEIVER CHANNEL: the
  * 64 lanes of a wave hold 64 channels of the same tuner, so the tuner samples are
- * wave-uniform (they arrive through the scalar cache into SGPRs, never through
- * VGPR loads) and per-channel state (phase, taps, accumulators) lives in VGPRs.
+ * wave-uniform (one coalesced load per output frame, handed round through a per-wave LDS
+ * window) and per-channel state (phase, taps, accumulators) lives in VGPRs.
  *
  * Reference paths are relative to webradio's src/.
  */
