@@ -180,3 +180,48 @@ def test_deferral_off_gives_the_same_bits(dev):
         outs.append(np.stack(got))
         t.destroy()
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_receivers_come_and_go_while_a_post_stage_is_pending(dev, oracle):
+    """Receivers added and removed between two submits with nothing fetched in between
+    (radio.cxx:151-163 does this from the REST thread): the pending post stage of the block
+    before is launched before the channel tables change, a new receiver starts from empty
+    filters, the others are undisturbed."""
+    blocks = _blocks(6)
+    t = Tuner(dev, FS, 200, N)
+    rx, ch = {}, {}
+    def add(key, f, mode_o, mode_c):
+        rx[key] = oracle.Receiver(FS, f, 128_000, 5_000, mode_o, 160, 1_000)
+        ch[key] = t.add_receiver(f, 128_000, 5_000, mode_c, 160, 1_000)
+    for c in range(66):                              # two lane groups from the start
+        add(c, IFS[c % len(IFS)] + 17 * c, oracle.AM, capi.WR_AM)
+    t.audio_ring(6)
+    want = []
+    for b, iq in enumerate(blocks):
+        if b == 2:
+            add("late", 7777, oracle.USB, capi.WR_USB)
+        if b == 3:
+            t.remove_receiver(ch.pop(5)); rx.pop(5)
+        if b == 4:
+            for c in range(100, 170):                 # a third lane group appears
+                add(c, -50_000 + 700 * c, oracle.LSB, capi.WR_LSB)
+        t.submit_host(iq)
+        want.append({k: r.run(iq)[0] for k, r in rx.items()})
+        slots = {k: t.lib and _slot(t, v) for k, v in ch.items()}
+        want[-1]["_slots"] = slots
+    t.flush()
+    for b in range(6):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b
+        slots = want[b].pop("_slots")
+        for k, w in want[b].items():
+            assert np.abs(audio[slots[k]] - w).max() <= 4e-6, (b, k)       # default NCO mode: within tolerance
+    t.destroy()
+
+
+def _slot(t, chan):
+    import ctypes as C
+    s = C.c_int()
+    capi.check(t.lib.wr_chan_slot(t.h, chan, C.byref(s)))
+    return s.value
