@@ -272,6 +272,9 @@ def test_c2_full_size_properties(dev, oracle, nco):
         t.destroy()
     worst = max(float(np.abs(a[0] - b[0]).max()) for a, b in zip(outs[capi.WR_NCO_EXACT], outs[nco]))
     assert worst <= IQ_ATOL
+    if nco == capi.WR_NCO_ROTATE:
+        # what DESIGN.md quotes for the default mode (correctly rounded turns, one anchor per frame)
+        assert worst <= 2.5e-7, worst
     for a, b in list(zip(outs[capi.WR_NCO_EXACT], outs[nco]))[::4]:      # carrier channels
         assert np.abs(a[1] - b[1]).max() <= AUDIO_ATOL
     # oracle on a prefix for three channels
