@@ -150,7 +150,9 @@ def test_random_streams_through_the_ring(dev, oracle, seed):
     channel filter and one audio filter per lane group (what radio.cxx sets up) the demod + audio
     filter of a block then run inside the NEXT block's launch (wr_tuner_flush in the header)."""
     rng = np.random.default_rng(5000 + seed)
-    fs, crate, arate = RATES[seed % len(RATES)]
+    # every audio decimation the riding post stage is instantiated for (1..6), and one it is not (8)
+    rates = RATES + [(2_000_000, 5_000, 2_500), (2_000_000, 5_000, 1_250), (1_200_000, 6_000, 1_000)]
+    fs, crate, arate = rates[seed % len(rates)]
     d1, d2 = fs // crate, crate // arate
     nchan = int(rng.choice([1, 3, 64, 65, 130]))
     base = d1 * d2
