@@ -143,7 +143,7 @@ def test_random_standalone_blocks(dev, oracle, seed):
             assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "9"))))
 def test_random_streams_through_the_ring(dev, oracle, seed):
     """The same kind of random configuration, consumed the way a streaming sink would: no fetch
     between submits, every block's audio taken from the pinned ring afterwards.  With one
