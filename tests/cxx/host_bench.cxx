@@ -116,6 +116,21 @@ int main(int argc, char **argv)
 	       "\"msps_tuner_input\": %.1f, \"audio_samples_per_receiver\": %lu, \"audio_abs_sum\": %.3f}\n",
 	       nrx, blocks, frames, dt / blocks * 1e3, (double)frames * blocks / dt / 1e6,
 	       total / (unsigned long)rx.size(), sum);
+	if (getenv("WR_HOST_BENCH_PROFILE")) {
+		/* DspBlock's own profiler (process-CPU ns inside process(), dspblock.h:69-75), summed per block type */
+		uint64_t mix = 0, f1 = 0, dem = 0, f2 = 0, snk = 0;
+		for (size_t n = 0; n < rx.size(); n++) {
+			mix += rx[n]->downconverter()->totalNanoseconds();
+			f1 += rx[n]->channelFilter()->totalNanoseconds();
+			dem += rx[n]->demodulator()->totalNanoseconds();
+			f2 += rx[n]->audioFilter()->totalNanoseconds();
+			snk += rx[n]->stream()->totalNanoseconds();
+		}
+		const double per = 1e-3 / (blocks + 2);
+		fprintf(stderr, "process() CPU us per block, all receivers: mixer %.1f  chan filter %.1f  demod %.1f  audio filter %.1f  "
+		        "sink %.1f  tuner %.1f  spectrum %.1f\n", mix * per, f1 * per, dem * per, f2 * per, snk * per,
+		        fe->tuner()->totalNanoseconds() * per, fe->spectrum()->totalNanoseconds() * per);
+	}
 	fe->tuner()->stop();
 	for (size_t n = 0; n < rx.size(); n++)
 		delete rx[n];

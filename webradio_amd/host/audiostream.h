@@ -26,7 +26,7 @@ public:
 		: SampleSink(name, "AudioStreamManager"), _keep(1u << 20), _total(0) {}
 	virtual ~AudioStreamManager() {}
 
-	/* audio received since start (at most the last `capacity` samples are retained) */
+	/* audio received since start (the last `capacity` samples are retained, at times up to twice as many) */
 	const vector<float>& samples() const { return _samples; }
 	unsigned long totalSamples() const { return _total; }
 	void setCapacity(size_t samples) { _keep = samples; }
@@ -38,7 +38,9 @@ protected:
 	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer) {
 		_total += inBuffer.size();
 		_samples.insert(_samples.end(), inBuffer.begin(), inBuffer.end());
-		if (_samples.size() > _keep)
+		/* trim in large steps: dropping the front of a vector moves everything behind it, and
+		 * doing that for every block of a long stream would cost more than the DSP */
+		if (_samples.size() > 2 * _keep)
 			_samples.erase(_samples.begin(), _samples.begin() + (_samples.size() - _keep));
 		return true;
 	}

@@ -166,12 +166,18 @@ bool DspBlock::runFrames(const vector<sample_t> &inBuffer, unsigned int inframes
 	}
 
 	_devOut = NULL;
-	const uint64_t t0 = cpuNanoseconds();
+	/* The process-CPU clock is a system call (two per block and receiver, 2 560 per tuner
+	 * block with 256 receivers: half a millisecond).  A block whose output nobody looks at on
+	 * the host does its work elsewhere (the tuner batch, or a kernel it only enqueues): its
+	 * process() is a few instructions, and is booked as zero. */
+	const bool timed = !_elide;
+	const uint64_t t0 = timed ? cpuNanoseconds() : 0;
 	if (!process(inBuffer, _out)) {
 		LOG_ERROR("Pipeline failed at block %s:%s\n", type().c_str(), name().c_str());
 		return false;
 	}
-	_nsTotal += cpuNanoseconds() - t0;
+	if (timed)
+		_nsTotal += cpuNanoseconds() - t0;
 	_framesIn += inframes;
 	_framesOut += outframes;
 
