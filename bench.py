@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_SAMPLE = 8.0 + 4.0 * 256 / (400 * 5)      # 8.512 B per input sample
+VALU_PER_TAP = {"rotate": 7, "split": 11}                 # VALU instructions per channel-tap
 HBM_PEAK_GBPS = 8000.0                                    # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -142,6 +143,9 @@ def main():
         total_samples = float(n) * args.steps * world
         value = total_samples / elapsed / 1e6
         achieved = (n * ALGO_BYTES_PER_SAMPLE / 1e9) / (ddc_ms / 1e3) if ddc_ms > 0 else 0.0
+        # lane groups x channel-rate frames x 64 taps x VALU instructions per tap
+        tap_instr = ((args.channels + 63) // 64) * (n // (cfg["input_rate"] // cfg["chan_rate"])) * 64 \
+            * VALU_PER_TAP.get(args.nco, 0)
         # HBM bytes of the dominant kernel from the PMC passes of tools/profile_round.sh (they
         # cannot be collected from inside this process); null when the committed figure is
         # not for this configuration
@@ -190,6 +194,14 @@ def main():
                 "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SAMPLE,
                 "note": "the path is fp32-VALU bound at 256 channels (DESIGN.md): "
                         "HBM fraction is reported as the contract asks, not as the binding roof",
+                # the binding resource, for context: VALU wave-instructions the DDC taps need (7 per
+                # channel-tap in the ROTATE mode, 64 lanes per wave) against the rate the same
+                # instruction mix reaches in isolation (profiles/r01_ubench_rot.txt, 32 waves per CU)
+                "valu": {
+                    "tap_wave_instr_per_launch": tap_instr,
+                    "isolated_rate_wave_instr_per_s": 0.988e12,
+                    "frac": round(tap_instr / 0.988e12 / (ddc_ms / 1e3), 4) if ddc_ms > 0 else None,
+                },
             },
         }
         if world == 1 and not args.no_cpu_baseline:
