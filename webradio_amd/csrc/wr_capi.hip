@@ -1199,7 +1199,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
 	t->in_par ^= 1;
 
-	/* host mirrors of what k_tuner_advance did */
+	/* host mirror of the phase advance k_tuner_ddc wrote into the other state set */
 	for (Chan &c : t->chans) {
 		if (!c.in_use || c.group < 0)
 			continue;

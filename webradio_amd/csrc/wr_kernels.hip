@@ -320,9 +320,8 @@ __device__ __forceinline__ void gather_split(unsigned int P, unsigned int &ah, u
  * of a tuner (dsp/downconverter.cxx:91-114 feeding dsp/lowpass.cxx:131-162).
  *
  *   work unit  = (k, g): channel-rate output frame k for the 64 channel slots of
- *                lane group g.  One wave per unit; units are dealt round-robin to
- *                the waves of a persistent grid (one 1024-thread workgroup per CU
- *                in SPLIT mode, because the LDS tables take 128 KiB).
+ *                lane group g.  One wave per unit; a wave of the persistent grid keeps one
+ *                lane group and walks k with a fixed stride (launch geometry: DdcGeom).
  *   per unit   : 64 taps.  Tap j touches input frame n = k*D1 - 63 + j, whose
  *                sample is wave-uniform.  Each lane advances its own left-aligned
  *                32-bit phase P (= reference phase << 1, so the 31-bit wrap of
