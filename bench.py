@@ -41,7 +41,7 @@ def parse():
                          "more than the 256 MB Infinity Cache holds, so every step reads its block from HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=2)
-    ap.add_argument("--profile-stride", type=int, default=4,
+    ap.add_argument("--profile-stride", type=int, default=8,
                     help="bracket every n-th step's dominant kernel with HIP events (an event pair costs ~4 us)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
