@@ -32,8 +32,8 @@ HBM_PEAK_GBPS = 8000.0                                    # MI355X_MICROARCH.md:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--nco", choices=["rotate", "split", "exact"], default="rotate")
     ap.add_argument("--resident-blocks", type=int, default=12,

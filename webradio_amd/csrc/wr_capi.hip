@@ -1132,6 +1132,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.nco_mode = t->nco_mode;
 		L.uniform_taps = g->uniform_taps ? 1 : 0;
 		L.audio_scale = t->audio_scale;
+		L.ev_start = L.ev_stop = nullptr;
 		if (prof_now) {
 			int rc = prof_drain(t, 64);
 			if (rc)
@@ -1141,17 +1142,16 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 				HIP_TRY(hipEventCreate(&e));
 				t->ev.push_back(e);
 			}
-			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
+			L.ev_start = t->ev[t->ev_used];     /* stamped by the launch itself (wrk_tuner_ddc) */
+			L.ev_stop = t->ev[t->ev_used + 1];
 		}
 		/* The previous block's post stage rides along with this block's DDC where the kernel
 		 * variant can take it (wrk_tuner_ddc says); otherwise it goes out on its own first. */
 		bool rode = false;
 		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 		                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
-		if (prof_now) {
-			HIP_TRY(hipEventRecord(t->ev[t->ev_used + 1], st));
+		if (prof_now)
 			t->ev_used += 2;
-		}
 		if (g->post_pending) {
 			if (!rode)
 				HIP_TRY(wrk_tuner_post_args(st, g->post_args));

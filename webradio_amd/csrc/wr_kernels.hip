@@ -23,6 +23,8 @@
  */
 #include "wr_internal.h"
 
+#include <hip/hip_ext.h>
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2f lds_v2f;
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1217,6 +1219,19 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 			return e;
 	}
 	const WrPostArgs pa = post ? *post : WrPostArgs();
+	if (L.ev_start && L.ev_stop) {
+		/* profiling: the launch stamps the two events with the dispatch's own start and end, as
+		 * rocprof sees them -- events recorded around it would add their own barrier packets */
+		hipExtLaunchKernelGGL((k_tuner_ddc<NCO, UTAPS, PD2>), dim3(wgs + post_wgs), dim3(W * 64u), (uint32_t)lds, st,
+		                      (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
+		                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next,
+		                      L.nframes, L.k1, L.d1, L.slots, ngroups, (const unsigned int *)G.phase[L.sp],
+		                      (const unsigned int *)G.step, (const float2 *)G.hist_cs[L.sp], (const int *)G.flags,
+		                      G.phase[L.sp ^ 1], (float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp],
+		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
+		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa);
+		return hipGetLastError();
+	}
 	k_tuner_ddc<NCO, UTAPS, PD2><<<wgs + post_wgs, W * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
