@@ -485,3 +485,31 @@ def test_long_stream_of_short_blocks(dev, oracle):
             assert np.abs(ga - wa).max() <= 4e-6, c
         assert t.state(chans[c])[0] == rxs[c].s.phase
     t.destroy()
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
+@pytest.mark.parametrize("rates", [(48_000, 48_000, 48_000), (48_000, 24_000, 24_000), (96_000, 48_000, 8_000),
+                                   (192_000, 64_000, 64_000)])
+def test_channel_decimations_one_two_three(dev, oracle, nco, rates):
+    """D1 = 1, 2, 3: every output frame's window reaches into the previous one's, and for the
+    first 63 / 32 / 21 frames of a block into the previous block."""
+    fs, crate, arate = rates
+    t = Tuner(dev, fs, 3, 5000, nco)
+    rxs, chs = [], []
+    for c, f in enumerate((1000, -7000, 0)):
+        m = [oracle.AM, oracle.USB, oracle.LSB][c]
+        rxs.append(oracle.Receiver(fs, f, fs // 4, crate, m, crate // 4, arate))
+        chs.append(t.add_receiver(f, fs // 4, crate, m, crate // 4, arate))
+    n = 5000 - 5000 % (fs // arate)
+    for b in range(3):
+        iq = synth.fm_stream(n, fs, [1000, -7000], start_frame=b * n, amp=0.3)
+        t.submit_host(iq)
+        for rx, ch in zip(rxs, chs):
+            wa = rx.run(iq)[0]
+            ga = t.fetch(ch, capi.WR_STAGE_AUDIO, wa.size + 4)
+            assert ga.size == wa.size
+            if nco == capi.WR_NCO_EXACT:
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32))
+            else:
+                assert np.abs(ga - wa).max() <= 4e-6
+    t.destroy()
