@@ -54,6 +54,37 @@ __global__ void __launch_bounds__(1024) k_rot(float *out, unsigned fs, float c0,
 	out[blockIdx.x * blockDim.x + threadIdx.x] = ar + ai + rc + rs + (float)F + (float)g;
 }
 
+// two independent taps per iteration (two output frames of the same channel in flight in one wave)
+__global__ void __launch_bounds__(1024) k_rot2(float *out, unsigned fs, float c0, float s0, float c1, float s1, float u)
+{
+	unsigned F = threadIdx.x * 2654435761u, G = F * 7u + 3u;
+	float ar = threadIdx.x, ai = 1.0f, br = 2.0f, bi = threadIdx.x, rc, rs, qc, qs;
+	for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+		for (int k = 0; k < UNR; ++k) {
+			float tr, ti, vr, vi;
+			asm volatile("v_add_co_u32 %0, vcc, %0, %14\n"
+			             "v_cndmask_b32 %2, %15, %17, vcc\n"
+			             "v_cndmask_b32 %3, %16, %18, vcc\n"
+			             "v_add_co_u32 %1, vcc, %1, %14\n"
+			             "v_cndmask_b32 %4, %15, %17, vcc\n"
+			             "v_cndmask_b32 %5, %16, %18, vcc\n"
+			             "v_fma_f32 %10, -%7, %3, %19\n"
+			             "v_fma_f32 %12, -%9, %5, %19\n"
+			             "v_fma_f32 %11, %6, %3, %19\n"
+			             "v_fma_f32 %13, %8, %5, %19\n"
+			             "v_fma_f32 %6, %6, %2, %10\n"
+			             "v_fma_f32 %8, %8, %4, %12\n"
+			             "v_fma_f32 %7, %7, %2, %11\n"
+			             "v_fma_f32 %9, %9, %4, %13\n"
+			             : "+v"(F), "+v"(G), "=&v"(rc), "=&v"(rs), "=&v"(qc), "=&v"(qs), "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi),
+			               "=&v"(tr), "=&v"(ti), "=&v"(vr), "=&v"(vi)
+			             : "v"(fs), "v"(c0), "v"(s0), "v"(c1), "v"(s1), "v"(u) : "vcc");
+		}
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = ar + ai + br + bi + (float)F + (float)G;
+}
+
 template <typename F>
 static double timeit(F f, int reps = 5)
 {
@@ -90,6 +121,12 @@ int main()
 		t[2] = timeit([&] { k_rot<2><<<wg, 1024>>>(out, 12345u, 0.9f, 0.1f, 0.8f, 0.2f, 0.5f); });
 		t[3] = timeit([&] { k_rot<3><<<wg, 1024>>>(out, 12345u, 0.9f, 0.1f, 0.8f, 0.2f, 0.5f); });
 		t[4] = timeit([&] { k_rot<4><<<wg, 1024>>>(out, 12345u, 0.9f, 0.1f, 0.8f, 0.2f, 0.5f); });
+		{
+			double t2 = timeit([&] { k_rot2<<<wg, 1024>>>(out, 12345u, 0.9f, 0.1f, 0.8f, 0.2f, 0.5f); });
+			const double taps2 = (double)wg * 16 * ITERS * UNR * 2;
+			printf("%d WG/CU  %-34s: %.3f ms  %.3f G wave-taps/s  %.3f T wave-inst/s\n", wgs_per_cu,
+			       "two interleaved taps per wave", t2 * 1e3, taps2 / t2 / 1e9, taps2 * 7 / t2 / 1e12);
+		}
 		for (int m = 0; m < 5; ++m) {
 			const double taps = (double)wg * 16 * ITERS * UNR;     // wave-taps
 			printf("%d WG/CU  %-34s: %.3f ms  %.3f G wave-taps/s  %.3f T wave-inst/s  (%.2f inst/clk/CU @2.4GHz)\n",
