@@ -6,10 +6,10 @@
 round=${1:-r01}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-cd $R && python bench.py --steps 30 --warmup 5 > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err
+cd $R && python bench.py > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$round
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$round -o $round -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /tmp/prof_$round.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$round -o $round -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > /tmp/prof_$round.log 2>&1
 python3 - "$round" <<'PY'
 import csv, sys, os
 r = sys.argv[1]; R = os.environ['GRAFT_REPO_ROOT']
