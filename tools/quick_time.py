@@ -21,7 +21,9 @@ for name in which:
         t.keep_stages(capi.WR_STAGE_DEMOD)
     mixed = os.environ.get("QT_MIXED") == "1"     # per-lane taps: a different passband per channel
     for i, f in enumerate(ifs):
-        t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0), c2["chan_rate"], capi.WR_FM,
+        odd = os.environ.get("QT_ONE_ODD") == "1" and i == 70       # one receiver with its own passband
+        t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0) + (3_000_000 if odd else 0),
+                       c2["chan_rate"], capi.WR_FM,
                        c2["audio_passband"], c2["audio_rate"])
     for _ in range(4):
         t.submit_device(x, n)

@@ -92,7 +92,7 @@ struct Group {
 	std::vector<int> owner;    /* slot -> chan or -1 */
 	bool dirty;                /* parameters must be uploaded before the next launch */
 	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
-	bool uniform_taps2 = false; /* ... and one audio-filter tap set */
+	unsigned long long uniform_mask = 0; /* bit i: lane group i does (the others take the per-lane-taps kernel) */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -935,8 +935,10 @@ static int group_upload(wr_tuner *t, Group *g)
 	 * kernel folds the taps into the shared sample window; idle slots of such a group
 	 * are given the group's taps so that any slot can serve as its representative. */
 	bool uniform = true;
-	for (size_t base = 0; base < S && uniform; base += WR_LANES) {
+	unsigned long long umask = 0;
+	for (size_t base = 0; base < S; base += WR_LANES) {
 		int rep = -1;
+		bool uni = true;
 		for (size_t s = base; s < base + WR_LANES; ++s) {
 			int ci = g->owner[s];
 			if (ci < 0)
@@ -944,36 +946,20 @@ static int group_upload(wr_tuner *t, Group *g)
 			if (rep < 0)
 				rep = ci;
 			else if (memcmp(t->chans[ci].taps[0], t->chans[rep].taps[0], sizeof(float) * WR_FIR_LENGTH))
-				uniform = false;
+				uni = false;
 		}
-		if (rep >= 0 && uniform)
+		if (rep >= 0 && uni)
 			for (size_t s = base; s < base + WR_LANES; ++s)
 				if (g->owner[s] < 0)
 					for (int j = 0; j < WR_FIR_LENGTH; ++j)
 						taps1[(size_t)j * S + s] = t->chans[rep].taps[0][j];
+		if (rep >= 0 && !uni)
+			uniform = false;
+		if (uni && base / WR_LANES < 64)
+			umask |= 1ull << (base / WR_LANES);
 	}
 	g->uniform_taps = uniform;
-	/* the same for the audio filter (radio.cxx:80-81): uniform taps can be scalar operands of
-	 * the post stage when it runs inside the DDC kernel */
-	bool uniform2 = true;
-	for (size_t base = 0; base < S && uniform2; base += WR_LANES) {
-		int rep = -1;
-		for (size_t s = base; s < base + WR_LANES; ++s) {
-			int ci = g->owner[s];
-			if (ci < 0)
-				continue;
-			if (rep < 0)
-				rep = ci;
-			else if (memcmp(t->chans[ci].taps[1], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH))
-				uniform2 = false;
-		}
-		if (rep >= 0 && uniform2)
-			for (size_t s = base; s < base + WR_LANES; ++s)
-				if (g->owner[s] < 0)
-					for (int j = 0; j < WR_FIR_LENGTH; ++j)
-						taps2[(size_t)j * S + s] = t->chans[rep].taps[1][j];
-	}
-	g->uniform_taps2 = uniform2;
+	g->uniform_mask = umask;           /* a lane group that is not uniform takes the per-lane-taps kernel, alone */
 	/* pageable sources: hipMemcpyAsync stages them before returning */
 	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
@@ -1131,6 +1117,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.k2max = g->k2max;
 		L.nco_mode = t->nco_mode;
 		L.uniform_taps = g->uniform_taps ? 1 : 0;
+		L.uniform_mask = g->uniform_mask;
 		L.audio_scale = t->audio_scale;
 		L.ev_start = L.ev_stop = nullptr;
 		if (prof_now) {
@@ -1164,8 +1151,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
 		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
-		const bool defer = !two_kernels && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE && g->uniform_taps
-		                   && g->uniform_taps2;
+		const bool defer = !two_kernels && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE
+		                   && (g->uniform_taps || (g->uniform_mask & ((L.slots_used / 64 >= 64) ? ~0ull : ((1ull << (L.slots_used / 64)) - 1ull))) != 0);
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, L, g->dev));
 			HIP_TRY(wrk_tuner_audio(st, L, g->dev));

@@ -63,8 +63,9 @@ struct WrTunerLaunch {
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
 	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
-	int          uniform_taps;
-	void        *ev_start, *ev_stop;   /* hipEvent_t pair the DDC launch itself stamps (profiling), or NULL */  /* every 64-slot lane group carries one tap set (all its slots) */
+	int          uniform_taps;  /* every 64-slot lane group carries one tap set (all its slots) */
+	unsigned long long uniform_mask;   /* bit g: lane group g does (up to 64 groups; beyond that only uniform_taps) */
+	void        *ev_start, *ev_stop;   /* hipEvent_t pair the DDC launch itself stamps (profiling), or NULL */
 };
 
 /* ---- kernel launchers (wr_kernels.hip); all return hipError_t ---- */

@@ -552,7 +552,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
             const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
-            const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post)
+            const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post,
+            unsigned long long gmap0, unsigned long long gmap1, int whole)
 {
 	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
 	if (PD2 != 0u && blockIdx.x >= n_ddc) {
@@ -595,7 +596,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	/* the tuner's next input history = last 63 frames of [hist | cur] (lowpass.cxx:138-142
 	 * keeps them per LowPass; here once per tuner).  It goes to the OTHER history buffer,
 	 * so no reader of `hist` in this launch is disturbed. */
-	if (blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
+	/* (`whole`: this launch covers every lane group of the rate group, or is the first of the
+	 * two launches that between them do -- it then also rolls the state of ALL channels) */
+	if (whole && blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
 		const size_t f = nframes + lane;            /* frame index in [hist | cur] */
 		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
 	}
@@ -609,7 +612,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 *     can be re-mixed bit-identically next block whatever happens to the phase step in
 	 *     between (setIF) and however short the blocks are.  A zero LO row = an empty
 	 *     history (a fresh LowPass::block). */
-	{
+	if (whole) {
 		/* spread over the whole grid: 63 x slots LO evaluations are a few per workgroup */
 		const unsigned int nlo = (unsigned int)nframes;
 		const unsigned int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = n_ddc * blockDim.x;
@@ -666,7 +669,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 * registers per lane: there a whole workgroup keeps to one group */
 	constexpr bool LTAPS = (NCO == WR_NCO_ROTATE) && !UTAPS;
 	const unsigned int wpg = LTAPS ? (n_ddc / groups) * waves_per_wg : nwaves / groups;   /* >= 1: see the launcher */
-	const unsigned int g = LTAPS ? blockIdx.x % groups : wid % groups;
+	/* `groups` lane groups take part in this launch; which ones: 16 one-byte entries */
+	const unsigned int gl = LTAPS ? blockIdx.x % groups : wid % groups;
+	const unsigned int g = (unsigned int)(((gl < 8u ? gmap0 : gmap1) >> ((gl & 7u) * 8u)) & 255u);
 	unsigned int k = LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
 	if (k >= wpg)
 		k = k1u;                                         /* the few waves left over stay idle */
@@ -1162,13 +1167,24 @@ template <int NCO, bool UTAPS> struct DdcGeom {
 	                                           : (NCO == WR_NCO_EXACT) ? 2u : 1u;
 };
 
+/* `gsel`: bit g set = lane group g takes part in this launch (0 = all of them); `whole`: the launch
+ * also rolls the per-channel state of every group (exactly one launch per block does) */
 template <int NCO, bool UTAPS, unsigned int PD2>
 static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                              const float *table_dev, const float *hi_dev, const float *lo_dev, int num_cus,
-                             const WrPostArgs *post)
+                             const WrPostArgs *post, unsigned long long gsel = 0, bool whole = true)
 {
 	constexpr unsigned int W = DdcGeom<NCO, UTAPS>::waves;
-	const unsigned int ngroups = L.slots_used / 64;
+	const unsigned int allgroups = L.slots_used / 64;
+	unsigned long long gmap[2] = {0, 0};
+	unsigned int ngroups = 0;
+	for (unsigned int g = 0; g < allgroups && ngroups < 16u; ++g)
+		if (!gsel || ((gsel >> g) & 1ull)) {
+			gmap[ngroups >> 3] |= (unsigned long long)g << ((ngroups & 7u) * 8u);
+			++ngroups;
+		}
+	if (!ngroups)
+		return hipSuccess;
 	size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
 	             : (W * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
 	               + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
@@ -1229,7 +1245,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		                      (const unsigned int *)G.step, (const float2 *)G.hist_cs[L.sp], (const int *)G.flags,
 		                      G.phase[L.sp ^ 1], (float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp],
 		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
-		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa);
+		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
 		return hipGetLastError();
 	}
 	k_tuner_ddc<NCO, UTAPS, PD2><<<wgs + post_wgs, W * 64u, lds, st>>>(
@@ -1238,8 +1254,53 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
 		(float2 *)G.chan_iq[L.cb], table_dev,
-		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa);
+		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
 	return hipGetLastError();
+}
+
+template <int NCO>
+static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, const float *table_dev,
+                                  const float *hi_dev, const float *lo_dev, int num_cus, const WrPostArgs *post,
+                                  bool *post_taken)
+{
+	/* Lane groups whose 64 channels share one channel filter take the uniform-taps kernel, the
+	 * others the per-lane-taps one: one odd receiver costs its own lane group, not the tuner.
+	 * (More than 16 lane groups in use, i.e. more than 1024 channels: one launch, as a whole.) */
+	const unsigned int allgroups = L.slots_used / 64;
+	const unsigned long long all = (allgroups >= 64u) ? ~0ull : ((1ull << allgroups) - 1ull);
+	unsigned long long uni = L.uniform_taps ? all : (L.uniform_mask & all);
+	if (allgroups > 16u)
+		uni = L.uniform_taps ? all : 0ull;
+	const unsigned long long odd = all & ~uni;
+	bool whole = true;
+	if (uni) {
+		hipError_t e;
+		const unsigned long long sel = (uni == all) ? 0ull : uni;
+		if (NCO == WR_NCO_ROTATE && post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
+			if (post_taken)
+				*post_taken = true;
+			switch (post->d2) {
+			case 1: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 1u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
+			case 2: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 2u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
+			case 3: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 3u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
+			case 4: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 4u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
+			case 5: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 5u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
+			default: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 6u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
+			}
+		} else {
+			e = launch_ddc<NCO, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, sel, true);
+		}
+		if (e != hipSuccess)
+			return e;
+		whole = false;
+	}
+	if (odd || !uni) {
+		WrTunerLaunch L2 = L;
+		L2.ev_start = L2.ev_stop = nullptr;                 /* the profiling events went to the first launch */
+		return launch_ddc<NCO, false, 0>(st, uni ? L2 : L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr,
+		                                 (odd == all) ? 0ull : odd, whole);
+	}
+	return hipSuccess;
 }
 
 hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
@@ -1252,25 +1313,9 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 		return hipSuccess;
 	if (L.nco_mode == WR_NCO_EXACT)
 		return launch_ddc<WR_NCO_EXACT, false, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
-	if (L.nco_mode == WR_NCO_ROTATE) {
-		if (!L.uniform_taps)
-			return launch_ddc<WR_NCO_ROTATE, false, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
-		if (post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
-			if (post_taken)
-				*post_taken = true;
-			switch (post->d2) {
-			case 1: return launch_ddc<WR_NCO_ROTATE, true, 1>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
-			case 2: return launch_ddc<WR_NCO_ROTATE, true, 2>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
-			case 3: return launch_ddc<WR_NCO_ROTATE, true, 3>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
-			case 4: return launch_ddc<WR_NCO_ROTATE, true, 4>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
-			case 5: return launch_ddc<WR_NCO_ROTATE, true, 5>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
-			default: return launch_ddc<WR_NCO_ROTATE, true, 6>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post);
-			}
-		}
-		return launch_ddc<WR_NCO_ROTATE, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
-	}
-	return L.uniform_taps ? launch_ddc<WR_NCO_SPLIT, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr)
-	                      : launch_ddc<WR_NCO_SPLIT, false, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr);
+	if (L.nco_mode == WR_NCO_ROTATE)
+		return launch_ddc_fast<WR_NCO_ROTATE>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, post_taken);
+	return launch_ddc_fast<WR_NCO_SPLIT>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, nullptr);
 }
 
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G)
