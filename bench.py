@@ -206,12 +206,30 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ifs, args.cpu_blocks)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
 
     tuner.destroy()
     dev.close()
+    # RCCL writes its version banner to stdout through C stdio when NCCL_DEBUG=VERSION is set (it is on
+    # the GPU boxes).  Every rank pushes that out, the ranks meet, and only then does rank 0 print:
+    # the JSON line is the LAST line the job writes.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
