@@ -513,3 +513,37 @@ def test_channel_decimations_one_two_three(dev, oracle, nco, rates):
             else:
                 assert np.abs(ga - wa).max() <= 4e-6
     t.destroy()
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_SPLIT, capi.WR_NCO_ROTATE])
+def test_one_odd_receiver_costs_its_own_lane_group(dev, oracle, nco):
+    """130 receivers, one of them with a different channel filter: lane groups 0 and 1 stay on the
+    uniform-taps kernel (with the post stage riding along), group 2 -- which holds the odd one --
+    takes the per-lane-taps kernel in a launch of its own.  Then the odd one is retuned to the
+    common filter (one launch again) and a receiver of group 0 goes odd instead."""
+    cfg = _mini_c2(130)
+    fs = cfg["fs"]
+    t = Tuner(dev, fs, 130, 40_000, nco)
+    rxs, chans = [], []
+    for c, f in enumerate(cfg["ifs"]):
+        pb = 200_000 if c == 129 else cfg["chan_pb"]
+        rxs.append(oracle.Receiver(fs, f, pb, cfg["chan_rate"], oracle.USB, cfg["audio_pb"], cfg["audio_rate"]))
+        chans.append(t.add_receiver(f, pb, cfg["chan_rate"], capi.WR_USB, cfg["audio_pb"], cfg["audio_rate"]))
+    t.audio_ring(8)
+    want = []
+    for b in range(6):
+        if b == 3:                                    # setPassband while running recomputes the taps (lowpass.cxx:55-61)
+            for c, pb in ((129, cfg["chan_pb"]), (7, 300_000)):
+                rxs[c].s.chan_fir.coeff[:64] = list(oracle.lowpass_design(pb, fs))
+                t.set_filter(chans[c], 0, pb, cfg["chan_rate"])
+        iq = synth.fm_stream(40_000, fs, cfg["ifs"][::16], start_frame=b * 40_000, amp=0.1)
+        t.submit_host(iq)
+        want.append([rx.run(iq)[0] for rx in rxs])
+    t.flush()
+    for b in range(6):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b
+        for c in range(130):
+            assert np.abs(audio[c] - want[b][c]).max() <= 4e-6, (b, c)
+    t.destroy()
