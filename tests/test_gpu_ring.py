@@ -161,6 +161,11 @@ def test_deferred_post_stage_keeps_block_order(dev, oracle):
 def test_deferral_off_gives_the_same_bits(dev):
     import os
     blocks = _blocks(4)
+    # ragged stream: blocks too short for a channel-rate frame (k1 = 0: no post stage at all), too
+    # short for an audio frame (k2 = 0: only the end-of-block state), and ordinary ones
+    long = np.concatenate(_blocks(3))
+    cuts = [0, 40_000, 40_100, 40_500, 42_500, 42_501, 82_501, 83_301, 120_000]
+    blocks = blocks + [long[2 * a: 2 * b] for a, b in zip(cuts[:-1], cuts[1:])]
     outs = []
     for env in ("1", "0"):
         os.environ["WR_DEFER_POST"] = env
@@ -168,18 +173,22 @@ def test_deferral_off_gives_the_same_bits(dev):
             t = _tuner(dev)
         finally:
             del os.environ["WR_DEFER_POST"]
-        t.audio_ring(4)
+        t.audio_ring(len(blocks))
         for iq in blocks:
             t.submit_host(iq)
         t.flush()
         got = []
-        for _ in range(4):
-            a, _ = t.ring_acquire()
+        for b in range(len(blocks)):
+            a, seq = t.ring_acquire()
+            assert seq == b
             got.append(a.copy())
             t.ring_release()
-        outs.append(np.stack(got))
+        outs.append(got)
         t.destroy()
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert [g.shape for g in outs[0]] == [g.shape for g in outs[1]]
+    assert sum(g.shape[1] for g in outs[0]) > 0
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_receivers_come_and_go_while_a_post_stage_is_pending(dev, oracle):
