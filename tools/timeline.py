@@ -1,0 +1,43 @@
+"""Per-wave timeline of k_tuner_ddc at C2 (development aid): needs a library built with
+-DDDC_TIMELINE (tools/mkvariant.sh tl -DDDC_TIMELINE) in place of the product library."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from webradio_amd import capi, synth
+from webradio_amd.device import Device, Tuner
+
+c2 = synth.C2
+fs, n = c2["input_rate"], c2["block_frames"]
+ifs = synth.c2_ifs(256)
+dev = Device(0, torch.cuda.current_stream().cuda_stream)
+x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
+t = Tuner(dev, fs, 256, n, capi.WR_NCO_ROTATE)
+for f in ifs:
+    t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
+for _ in range(6):
+    t.submit_device(x, n)
+torch.cuda.synchronize()
+lib = C.CDLL(capi.LIB_PATH)
+SL, NW = 12, 16384
+buf = np.zeros(NW * SL, dtype=np.uint64)
+rc = lib.wr_debug_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+tl = buf.reshape(NW, SL).astype(np.int64)
+used = tl[:, 0] > 0
+tl = tl[used]
+t0 = tl[:, 0].min()
+print("rc", rc, "waves stamped", tl.shape[0])
+def stat(name, v):
+    v = np.sort(v)
+    print("%-34s min %8d  p10 %8d  median %8d  p90 %8d  max %8d" % (name, v[0], v[len(v) // 10], v[len(v) // 2], v[len(v) * 9 // 10], v[-1]))
+stat("wave start - first start", tl[:, 0] - t0)
+stat("prologue (tables, state roll)", tl[:, 1] - tl[:, 0])
+stat("state load issue", tl[:, 2] - tl[:, 1])
+for u in range(8):
+    a = tl[:, 3 + u]; b = tl[:, 2 + u]
+    ok = (a > 0) & (b > 0)
+    if ok.sum():
+        stat("unit %d (%d waves)" % (u, ok.sum()), (a - b)[ok])
+stat("wave end - first start", tl[:, 11] - t0)
+stat("wave life", tl[:, 11] - tl[:, 0])
+print("kernel span (ticks): %d" % (tl[:, 11].max() - t0))
+t.destroy()

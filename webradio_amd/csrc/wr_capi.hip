@@ -46,6 +46,7 @@ struct wr_dev {
 	int num_cus;
 	float *table;              /* [65536] reference sine table */
 	float *table_turn;         /* [65536] correctly rounded sin(2 pi i / 65536): WR_NCO_ROTATE's turns */
+	float *turn_host;          /* the same table on the host (per-slot turns are looked up at upload time) */
 	float *hi_cs, *lo_cs;      /* [256][2] split NCO tables */
 	float *scratch;            /* growable scratch */
 	size_t scratch_floats;
@@ -288,6 +289,12 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	wrd_sin_table_rounded(turn.data());
 	wrd_split_tables(hi.data(), lo.data());
 	int rc = WR_OK;
+	d->turn_host = (float *)malloc(WR_TABLE_SIZE * sizeof(float));
+	if (!d->turn_host) {
+		delete d;
+		return fail(WR_ERR_NOMEM, "out of memory");
+	}
+	memcpy(d->turn_host, turn.data(), WR_TABLE_SIZE * sizeof(float));
 	do {
 		if ((e = hipMalloc((void **)&d->table, WR_TABLE_SIZE * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMalloc((void **)&d->table_turn, WR_TABLE_SIZE * sizeof(float))) != hipSuccess) break;
@@ -320,6 +327,7 @@ extern "C" int wr_dev_close(wr_dev *d)
 	(void)hipFree(d->lo_cs);
 	(void)hipFree(d->coeff);
 	(void)hipFree(d->scratch);
+	free(d->turn_host);
 	if (d->own_stream)
 		(void)hipStreamDestroy(d->stream);
 	delete d;
@@ -472,6 +480,8 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.mode);
 	(void)hipFree(g->dev.taps1);
 	(void)hipFree(g->dev.taps2);
+	(void)hipFree(g->dev.rot);
+	(void)hipFree(g->dev.taps1u);
 	(void)hipFree(g->dev.prev_iq[0]);
 	(void)hipFree(g->dev.prev_iq[1]);
 	(void)hipFree(g->dev.chan_iq[0]);
@@ -515,6 +525,8 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
+	if (!rc) rc = dev_alloc_zero(&g->dev.rot, S * 4);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
@@ -960,12 +972,28 @@ static int group_upload(wr_tuner *t, Group *g)
 	}
 	g->uniform_taps = uniform;
 	g->uniform_mask = umask;           /* a lane group that is not uniform takes the per-lane-taps kernel, alone */
+	/* per-slot turns of the ROTATE NCO and the window-ordered taps of each lane group (see WrGroupDev) */
+	std::vector<float> rot(S * 4, 0.0f), taps1u(S, 0.0f);
+	{
+		const float *turn = t->dev->turn_host;
+		for (size_t s = 0; s < S; ++s) {
+			const unsigned int Sx = step[s] >> 16;
+			rot[4 * s + 0] = turn[(Sx + 16384u) & 0xFFFFu];
+			rot[4 * s + 1] = turn[Sx & 0xFFFFu];
+			rot[4 * s + 2] = turn[(Sx + 16385u) & 0xFFFFu];
+			rot[4 * s + 3] = turn[(Sx + 1u) & 0xFFFFu];
+			const size_t base = s - s % WR_LANES, j = s % WR_LANES;
+			taps1u[s] = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * S + base];
+		}
+	}
 	/* pageable sources: hipMemcpyAsync stages them before returning */
 	HIP_TRY(hipMemcpyAsync(g->dev.step, step.data(), S * sizeof(unsigned int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.mode, mode.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1, taps1.data(), taps1.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.taps1u, taps1u.data(), taps1u.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	for (size_t s = 0; s < S; ++s) {
 		int ci = g->owner[s];
 		if (ci < 0)

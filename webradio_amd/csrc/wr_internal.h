@@ -40,6 +40,13 @@ struct WrGroupDev {
 	int          *mode;         /* wr_mode, or -1 for an idle slot (what the post-DDC kernels test) */
 	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */
 	float        *taps2;        /* [64][slots] audio-filter taps */
+	/* what a DDC wave needs before its first tap, laid out so that it is ONE coalesced load each (a
+	 * wave that gathers them -- 64 tap rows, four table entries per lane -- queues 320 cache-line
+	 * requests behind the other 31 waves of its CU, and every wave of the launch does so at once) */
+	float        *rot;          /* WR_NCO_ROTATE: [slots][4] the two turns of the slot's step:
+	                               cis(2 pi S / 65536), cis(2 pi (S+1) / 65536), S = step >> 16 */
+	float        *taps1u;       /* [slots] lane group g's channel filter when all its slots share one:
+	                               taps1u[g*64 + j] = coeff[63 - j], the tap of window sample j */
 	float        *prev_iq[2];   /* [slots][2] Demodulator::prev_i/prev_q, ping-pong by block parity */
 	float        *chan_iq[2];   /* [k1max][slots][2] channel-filter output, time major; double buffered so
 	                               that block b+1's DDC can run while block b is being demodulated */

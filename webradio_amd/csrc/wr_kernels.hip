@@ -32,6 +32,19 @@ typedef __attribute__((address_space(3))) v4f lds_v4f;
 
 #define PHASE_FLAG_ACTIVE   1
 
+#ifdef DDC_TIMELINE
+/* development aid (tools/mkvariant.sh ... -DDDC_TIMELINE): per-wave s_memtime stamps of k_tuner_ddc */
+#define TL_SLOTS 12
+__device__ unsigned long long g_ddc_tl[16384 * TL_SLOTS];
+extern "C" int wr_debug_timeline(unsigned long long *out, size_t n)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_tl), n * sizeof(unsigned long long));
+}
+#define TL(slot) do { if (lane == 0 && wid < 16384u && (slot) < TL_SLOTS) g_ddc_tl[wid * TL_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TL(slot) do { } while (0)
+#endif
+
 /* ------------------------------------------------------------------------- */
 /* tier 1: one kernel per reference block                                     */
 /* ------------------------------------------------------------------------- */
@@ -295,6 +308,26 @@ __device__ __forceinline__ void horner_close(v2f &y, v2f A, v2f cs)
 	y.y = yi;
 }
 
+/* s_setprio with a run-time (wave-uniform) level.  The SIMD's issue arbiter goes by priority, then
+ * AGE: at equal priority the older waves of a SIMD take every VALU slot their tap loops can use and
+ * the youngest wave does not even get its prologue issued until they stall (measured with
+ * s_memtime stamps, C2: its state loads took 10 us, and it then ran its units alone on the SIMD at a
+ * third of the issue rate after the others had finished -- a 40 % tail).  So a wave's priority
+ * falls as it gets through its units: whoever is behind goes first. */
+__device__ __forceinline__ void wave_prio(unsigned int level)
+{
+#ifndef DDC_NO_PRIO
+	if (level >= 3u)
+		__builtin_amdgcn_s_setprio(3);
+	else if (level == 2u)
+		__builtin_amdgcn_s_setprio(2);
+	else if (level == 1u)
+		__builtin_amdgcn_s_setprio(1);
+	else
+		__builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 #ifndef ROT_SEG
 #define ROT_SEG 64                       /* measured on MI355X, C2: 16 -> 4.5e-8 / 40.9 us, 32 -> 6.7e-8 / 39.5 us,
                                             64 -> 1.2e-7 / 38.4 us (worst |IQ - bit-exact path| on +-0.4 signals / kernel) */
@@ -550,13 +583,16 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist_cs, const int *__restrict__ flags,
             unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next,
             const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
-            const float *__restrict__ taps1, float2 *__restrict__ chan_iq,
+            const float *__restrict__ taps1, const float4 *__restrict__ rot, const float *__restrict__ taps1u,
+            float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post,
             unsigned long long gmap0, unsigned long long gmap1, int whole)
 {
 	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
 	if (PD2 != 0u && blockIdx.x >= n_ddc) {
+		/* latency-bound tenants: a chain of loads, barriers and short bursts of arithmetic */
+		wave_prio(3u);
 		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
 		const unsigned int idx = blockIdx.x - n_ddc;
 		float *stage = (float *)lds;
@@ -567,6 +603,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	const unsigned int lane = threadIdx.x & 63u;
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned int waves_per_wg = blockDim.x >> 6;
+	const unsigned int wid = blockIdx.x * waves_per_wg + wave;
+	TL(0);                                                   /* wave starts */
+	wave_prio(3u);                                           /* the prologue's loads go out at once */
 
 	if (NCO == WR_NCO_SPLIT) {
 		for (unsigned int e = threadIdx.x; e < WR_SPLIT_N * 32u; e += blockDim.x) {
@@ -603,59 +642,6 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
 	}
 
-	/* End-of-block state of every channel, written to the OTHER state set so that no reader
-	 * of this launch is disturbed and the next block's launch depends on nothing but this one:
-	 *   - DownConverter::phase advances by nframes steps (downconverter.cxx:103);
-	 *   - the channel filter's history.  The reference keeps the last 63 MIXED frames per
-	 *     receiver (lowpass.cxx:138-142).  Here the raw frames are kept once per tuner and,
-	 *     per channel, the LO value (cos, sin) each of them was mixed with -- so the frames
-	 *     can be re-mixed bit-identically next block whatever happens to the phase step in
-	 *     between (setIF) and however short the blocks are.  A zero LO row = an empty
-	 *     history (a fresh LowPass::block). */
-	if (whole) {
-		/* spread over the whole grid: 63 x slots LO evaluations are a few per workgroup */
-		const unsigned int nlo = (unsigned int)nframes;
-		const unsigned int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = n_ddc * blockDim.x;
-		for (unsigned int s = gtid; s < slots; s += gsz) {
-			const bool act = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
-			phase_next[s] = act ? phase[s] + nlo * step[s] : phase[s];
-		}
-		for (unsigned int e = gtid; e < WR_HIST * slots; e += gsz) {
-			const unsigned int r = e / slots, s = e - r * slots;
-			const size_t f = nframes + r;                 /* frame index in [hist | cur] */
-			v2f cs = {0.0f, 0.0f};
-			if (NCO == WR_NCO_ROTATE) {
-				/* ROTATE also keeps the LO values themselves: the segment anchors */
-				v2f lo = {0.0f, 0.0f};
-				if (flags[s] & PHASE_FLAG_ACTIVE) {
-					if (f < WR_HIST) {
-						const float2 o = hist_lo[f * slots + s];
-						lo = (v2f){o.x, o.y};
-					} else {
-						lo = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
-					}
-				}
-				hist_lo_next[e] = make_float2(lo.x, lo.y);
-			}
-			if (flags[s] & PHASE_FLAG_ACTIVE) {
-				if (f < WR_HIST) {
-					const float2 o = hist_cs[f * slots + s];
-					cs = (v2f){o.x, o.y};
-				} else if (NCO == WR_NCO_ROTATE) {
-					/* ROTATE keeps turns, not LO values: row r = the turn into frame r - 62 of the
-					 * next block, i.e. into frame f - 62 >= 1 of this one.  (Row 62 is the turn
-					 * into the next block's first frame: made with THIS block's step, as the
-					 * reference adds phase_step right after using a frame.)  A zero row = nothing
-					 * before that frame counts, which is also how a fresh channel starts. */
-					cs = rot_into(phase[s], step[s], (unsigned int)(f - (WR_HIST - 1)), table);
-				} else {
-					cs = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
-				}
-			}
-			hist_cs_next[e] = make_float2(cs.x, cs.y);
-		}
-	}
-
 	/* Units (g, k) are dealt so that a wave keeps ONE lane group for its whole life: wave w of
 	 * the grid takes g = w mod groups and walks k = w / groups, + waves_per_group, ...  Its
 	 * per-channel state (phase, step, taps, turns) is loaded once, before the loop -- a
@@ -664,7 +650,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 * the same window at about the same time: one HBM read, the rest L1/L2 hits. */
 	const unsigned int k1u = (unsigned int)k1;
 	const unsigned int nwaves = n_ddc * waves_per_wg;
-	const unsigned int wid = blockIdx.x * waves_per_wg + wave;
+	TL(1);                                                   /* tables in LDS, state rolled */
 	/* ROTATE with per-lane taps keeps the taps of ONE lane group in LDS (16 KiB) instead of 64
 	 * registers per lane: there a whole workgroup keeps to one group */
 	constexpr bool LTAPS = (NCO == WR_NCO_ROTATE) && !UTAPS;
@@ -701,32 +687,40 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	/* the window of the NEXT unit is fetched while this one is computed: its global-load
 	 * latency would otherwise sit in front of every unit */
 	float2 xnext = make_float2(0.0f, 0.0f);
-	if (k < k1u)
-		xnext = window_sample(k);
 	const unsigned int s = g * 64u + lane;
 	if (k < k1u) {
 		{
+			/* one coalesced load each (WrGroupDev::rot, taps1u), all independent of one another */
+			p0 = phase[s];
+			st = step[s];
+			fl = flags[s];
+			if (NCO == WR_NCO_ROTATE) {
+				const float4 r = rot[s];
+				rot0 = (v2f){r.x, r.y};
+				rot1 = (v2f){r.z, r.w};
+			}
 			if (UTAPS) {
 				/* every slot of the group carries the same taps (host guarantee) */
-				hlane = taps1[(size_t)(WR_FIR_LENGTH - 1 - lane) * slots + g * 64u];
+				hlane = taps1u[s];
 			} else {
 #pragma unroll
 				for (int j = 0; j < ((UTAPS || LTAPS) ? 1 : WR_FIR_LENGTH); ++j)
 					h[j] = taps1[(size_t)j * slots + s];
 			}
-			p0 = phase[s];
-			st = step[s];
-			fl = flags[s];
-			if (NCO == WR_NCO_ROTATE) {
-				const unsigned int S = st >> 16;
-				rot0 = (v2f){table[(S + 16384u) & 0xFFFFu], table[S]};
-				rot1 = (v2f){table[(S + 16385u) & 0xFFFFu], table[(S + 1u) & 0xFFFFu]};
-			}
 		}
+		xnext = window_sample(k);
 	}
 
+	TL(2);                                                   /* per-channel state loaded (issued) */
+	unsigned int tl_unit = 0;
+	/* units this wave will do, and how far through them it is, in quarters (see wave_prio) */
+	const unsigned int my_units = (k < k1u) ? (k1u - k + wpg - 1u) / wpg : 0u;
 	for (; k < k1u; buf ^= 1u) {
 		const unsigned int kn = k + wpg;              /* the unit after this one */
+		{
+			const unsigned int q = (4u * tl_unit) / (my_units ? my_units : 1u);   /* 0..3 */
+			wave_prio(q >= 3u ? 0u : 2u - q + 0u);
+		}
 
 		/* ---- the window: sample j of this output frame goes to lane j, then to LDS.
 		 * Every lane needs every sample; a tap reads its sample back with a broadcast
@@ -823,7 +817,11 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			v2f A = {0.0f, 0.0f}, Aq[ROT_Q];
 #pragma unroll
 			for (int jp = 0; jp < WR_FIR_LENGTH / 2; ++jp) {
+#ifdef ABL_LDS_HALF                                  /* ablation: half the window reads (wrong results) */
+				const v4f x2 = w4[jp & ~1];
+#else
 				const v4f x2 = w4[jp];
+#endif
 #pragma unroll
 				for (int jj = 0; jj < 2; ++jj) {
 					const int j = 2 * jp + jj;
@@ -949,7 +947,68 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		if (fl & PHASE_FLAG_ACTIVE)
 			chan_iq[(size_t)k * slots + s] = make_float2(acc.x, acc.y);
 		k = kn;
+		TL(3u + tl_unit);                                    /* unit done (store issued) */
+		++tl_unit;
 	}
+	wave_prio(0u);
+	/* End-of-block state of every channel, written to the OTHER state set so that no reader
+	 * of this launch is disturbed and the next block's launch depends on nothing but this one:
+	 *   - DownConverter::phase advances by nframes steps (downconverter.cxx:103);
+	 *   - the channel filter's history.  The reference keeps the last 63 MIXED frames per
+	 *     receiver (lowpass.cxx:138-142).  Here the raw frames are kept once per tuner and,
+	 *     per channel, the LO value (cos, sin) each of them was mixed with -- so the frames
+	 *     can be re-mixed bit-identically next block whatever happens to the phase step in
+	 *     between (setIF) and however short the blocks are.  A zero LO row = an empty
+	 *     history (a fresh LowPass::block).
+	 * Done by the LAST workgroups of the grid, after their units: they are the ones that get
+	 * one unit fewer when the units do not divide evenly, and nothing in this launch waits for it
+	 * (at the head of the kernel its dependent loads sat in front of the first unit). */
+	const unsigned int roll_wgs = (WR_FIR_LENGTH * slots + blockDim.x - 1u) / blockDim.x;
+	const unsigned int roll_first = n_ddc > roll_wgs ? n_ddc - roll_wgs : 0u;
+	if (whole && blockIdx.x >= roll_first) {
+		const unsigned int nlo = (unsigned int)nframes;
+		const unsigned int gtid = (blockIdx.x - roll_first) * blockDim.x + threadIdx.x, gsz = (n_ddc - roll_first) * blockDim.x;
+		for (unsigned int s = gtid; s < slots; s += gsz) {
+			const bool act = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
+			phase_next[s] = act ? phase[s] + nlo * step[s] : phase[s];
+		}
+		for (unsigned int e = gtid; e < WR_HIST * slots; e += gsz) {
+			const unsigned int r = e / slots, s = e - r * slots;
+			const size_t f = nframes + r;                 /* frame index in [hist | cur] */
+			v2f cs = {0.0f, 0.0f};
+			if (NCO == WR_NCO_ROTATE) {
+				/* ROTATE also keeps the LO values themselves: the segment anchors */
+				v2f lo = {0.0f, 0.0f};
+				if (flags[s] & PHASE_FLAG_ACTIVE) {
+					if (f < WR_HIST) {
+						const float2 o = hist_lo[f * slots + s];
+						lo = (v2f){o.x, o.y};
+					} else {
+						lo = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
+					}
+				}
+				hist_lo_next[e] = make_float2(lo.x, lo.y);
+			}
+			if (flags[s] & PHASE_FLAG_ACTIVE) {
+				if (f < WR_HIST) {
+					const float2 o = hist_cs[f * slots + s];
+					cs = (v2f){o.x, o.y};
+				} else if (NCO == WR_NCO_ROTATE) {
+					/* ROTATE keeps turns, not LO values: row r = the turn into frame r - 62 of the
+					 * next block, i.e. into frame f - 62 >= 1 of this one.  (Row 62 is the turn
+					 * into the next block's first frame: made with THIS block's step, as the
+					 * reference adds phase_step right after using a frame.)  A zero row = nothing
+					 * before that frame counts, which is also how a fresh channel starts. */
+					cs = rot_into(phase[s], step[s], (unsigned int)(f - (WR_HIST - 1)), table);
+				} else {
+					cs = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
+				}
+			}
+			hist_cs_next[e] = make_float2(cs.x, cs.y);
+		}
+	}
+
+	TL(11);
 }
 
 /* Demodulator::process for every channel (dsp/demodulator.cxx:77-115): thread (k, s);
@@ -1193,9 +1252,9 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	if (PD2 != 0u) {
 		/* the post workgroups' stage + tile set the LDS size of every workgroup of the launch;
 		 * POST_RESERVE workgroup slots per CU are left to them (they come and go, the DDC ones
-		 * persist).  Measured at C2, kernel duration: 1 slot 41.3 us (the 508 post workgroups
-		 * take two rounds through 256 slots and finish last), 2 slots 39.6, 3 slots 51 (the DDC
-		 * starves); DDC + post as two launches: 34.8 + 15.3 + gap. */
+		 * persist).  Measured at C2, kernel duration (r02: per-slot turns, priorities by progress,
+		 * post workgroups at priority 3): 1 slot 38.2 us, 2 slots 39.7, 3 slots 49.8 (the DDC
+		 * starves); DDC + post as two launches: 31.3 + 15.2 + gap. */
 		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
 		const size_t post_lds = ((size_t)NEED * 64u + POST_TK * 65u) * sizeof(float);
 		if (post_lds > lds)
@@ -1204,7 +1263,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		if (fit < wgs_per_cu)
 			wgs_per_cu = fit;
 #ifndef POST_RESERVE
-#define POST_RESERVE 2u
+#define POST_RESERVE 1u
 #endif
 		wgs_per_cu = (wgs_per_cu > POST_RESERVE) ? wgs_per_cu - POST_RESERVE : 1u;
 		post_wgs = (post->ntiles + 1u) * post->groups;
@@ -1244,7 +1303,8 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		                      L.nframes, L.k1, L.d1, L.slots, ngroups, (const unsigned int *)G.phase[L.sp],
 		                      (const unsigned int *)G.step, (const float2 *)G.hist_cs[L.sp], (const int *)G.flags,
 		                      G.phase[L.sp ^ 1], (float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp],
-		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (float2 *)G.chan_iq[L.cb], table_dev,
+		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (const float4 *)G.rot, (const float *)G.taps1u,
+		                      (float2 *)G.chan_iq[L.cb], table_dev,
 		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
 		return hipGetLastError();
 	}
@@ -1253,7 +1313,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		L.k1, L.d1,
 		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
-		(float2 *)G.chan_iq[L.cb], table_dev,
+		(const float4 *)G.rot, G.taps1u, (float2 *)G.chan_iq[L.cb], table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
 	return hipGetLastError();
 }
