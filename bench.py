@@ -12,8 +12,10 @@
 
 Prints ONE JSON line on rank 0 (see the contract in the task description) carrying
 `roofline` (dominant kernel, HIP-event timed inside the timed region) and, at N = 1,
-`cpu_baseline` (the oracle -- a scalar port of the reference CPU path -- timed on one
-host core over a bounded sample of the same workload).
+`cpu_baseline` (the oracle -- a scalar port of the reference CPU path -- timed on ALL host
+cores, one pipeline thread per core with its own subset of the receivers, and on one core,
+over a bounded sample of the same workload) and `secondary.c3` (BASELINE config 3: the
+SpectrumSink waterfall, 65536-point FFT at 50 % overlap, off the same resident stream).
 """
 import argparse
 import json
@@ -27,6 +29,10 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_SAMPLE = 8.0 + 4.0 * 256 / (400 * 5)      # 8.512 B per input sample
 VALU_PER_TAP = {"rotate": 7, "split": 11}                 # VALU instructions per channel-tap
 HBM_PEAK_GBPS = 8000.0                                    # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak FP32 (vector)
+ALGO_FLOP_PER_SAMPLE = 445.0                              # flop per tuner input sample, 256 channels
+C3_FFT, C3_HOP = 65536, 32768                             # BASELINE config 3
+C3_BYTES_PER_FRAME = 12 * C3_FFT                          # 8 B in + 4 B dB out per bin
 
 
 def parse():
@@ -40,7 +46,9 @@ def parse():
                     help="consecutive blocks of the stream kept in HBM and cycled through (12 x 32 MB is "
                          "more than the 256 MB Infinity Cache holds, so every step reads its block from HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-blocks", type=int, default=2)
+    ap.add_argument("--cpu-blocks", type=int, default=0,
+                    help="blocks of the all-cores CPU baseline (0: as many as take about 10-20 s)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 (SpectrumSink) measurement")
     ap.add_argument("--profile-stride", type=int, default=8,
                     help="bracket every n-th step's dominant kernel with HIP events (an event pair costs ~4 us)")
     ap.add_argument("--backend", default="nccl",
@@ -50,21 +58,72 @@ def parse():
 
 def cpu_baseline(cfg, ifs, blocks):
     """The oracle's Receiver chains (a faithful scalar port of the reference CPU path:
-    full-rate mixer, block copy, 64-tap FIRs, atan2f), one core, all channels over
-    `blocks` blocks of the same synthetic stream."""
+    full-rate mixer, block copy, 64-tap FIRs, atan2f) over the same synthetic stream:
+    T pipeline threads, T = all host cores, each with its own subset of the receivers of
+    the one tuner buffer (the reference pipeline itself is single-threaded, radio.cxx:56-59),
+    and the one-thread figure (one block)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wr_oracle as oracle
     from webradio_amd import synth
     n = cfg["block_frames"]
     iq = synth.fm_stream(n, cfg["input_rate"], ifs[::4], seed=12345)
-    secs = oracle.bench_receivers(cfg["input_rate"], ifs, cfg["chan_passband"], cfg["chan_rate"], oracle.FM,
-                                  cfg["audio_passband"], cfg["audio_rate"], iq, blocks)
+    args = (cfg["input_rate"], ifs, cfg["chan_passband"], cfg["chan_rate"], oracle.FM,
+            cfg["audio_passband"], cfg["audio_rate"], iq)
+    cores = max(1, min(len(os.sched_getaffinity(0)), len(ifs)))
+    one = oracle.bench_receivers(*args, 1)
+    if blocks <= 0:
+        # one block on T threads takes about one / T seconds if the cores scale; aim at ~12 s
+        blocks = int(max(2, min(64, round(12.0 / max(one / cores, 1e-3)))))
+    secs = oracle.bench_receivers_mt(*args, blocks, cores)
     return {
         "value": round(n * blocks / secs / 1e6, 4),
         "unit": "complex Msamples/s (tuner input, all %d channels)" % len(ifs),
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": "%d channels x %d block(s) of %d frames, %.1f s on one host core" % (len(ifs), blocks, n, secs),
+        "sample": "%d channels x %d block(s) of %d frames on %d threads (disjoint channel subsets), %.1f s" % (
+            len(ifs), blocks, n, cores, secs),
+        "one_core": {"value": round(n / one / 1e6, 4), "cores": 1,
+                     "sample": "%d channels x 1 block of %d frames, %.1f s" % (len(ifs), n, one)},
+    }
+
+
+def c3_secondary(torch, dev, blocks, n, steps):
+    """BASELINE config 3: SpectrumSink (io/spectrumsink.cxx:88-142) as a waterfall -- 65536-point
+    Hamming-windowed FFT every 32768 frames, dB with fft-shift -- over the same resident stream:
+    consecutive 4 M-frame blocks (more than the Infinity Cache holds), one row buffer per block.
+    Timed with events on the stream the kernels run on."""
+    from webradio_amd.device import Spectrum
+    rows = (n - C3_FFT) // C3_HOP + 1
+    spec = Spectrum(dev, C3_FFT, C3_HOP)
+    nb = len(blocks)
+    outs = [torch.empty(rows * C3_FFT, dtype=torch.float32, device="cuda") for _ in range(nb)]
+    for b in range(min(2, nb)):
+        spec.batch_db(blocks[b], rows, outs[b])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        spec.batch_db(blocks[i % nb], rows, outs[i % nb])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    db = outs[(steps - 1) % nb][:C3_FFT]
+    assert bool(torch.isfinite(db).all())
+    spec.destroy()
+    achieved = rows * C3_BYTES_PER_FRAME / (ms / 1e3) / 1e9
+    return {
+        "workload": "C3: SpectrumSink waterfall, %d-point FFT, hop %d (50 %% overlap), %d frames per 4 000 000-frame "
+                    "block, %d resident blocks cycled" % (C3_FFT, C3_HOP, rows, nb),
+        "metric": "FFT frames/s",
+        "value": round(rows / (ms / 1e3), 1),
+        "msps_new_samples": round(rows * C3_HOP / (ms / 1e3) / 1e6, 1),
+        "ms_per_block": round(ms, 5),
+        "steps": steps,
+        "roofline": {"bound": "hbm", "kernel": "k_fft64k (window + 65536-point FFT + dB, fft-shift)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                     "algorithmic_bytes_per_frame": C3_BYTES_PER_FRAME,
+                     "traffic": None},
     }
 
 
@@ -139,6 +198,13 @@ def main():
     a = tuner.fetch(0, capi.WR_STAGE_AUDIO, n)
     assert a.size == n // 400 // 5 and bool((a == a).all()) and float(abs(a).max()) > 0.0
 
+    # BASELINE config 3 off the same resident stream, outside the timed region of the headline
+    c3 = None
+    if world == 1 and not args.no_secondary:
+        tuner.flush()
+        torch.cuda.synchronize()
+        c3 = c3_secondary(torch, dev, blocks, n, max(nb, min(args.steps, 60)))
+
     if rank == 0:
         total_samples = float(n) * args.steps * world
         value = total_samples / elapsed / 1e6
@@ -199,11 +265,17 @@ def main():
                 # instruction mix reaches in isolation (profiles/r01_ubench_rot.txt, 32 waves per CU)
                 "valu": {
                     "tap_wave_instr_per_launch": tap_instr,
-                    "isolated_rate_wave_instr_per_s": 0.988e12,
-                    "frac": round(tap_instr / 0.988e12 / (ddc_ms / 1e3), 4) if ddc_ms > 0 else None,
+                    "isolated_rate_wave_instr_per_s": 0.954e12,
+                    "frac": round(tap_instr / 0.954e12 / (ddc_ms / 1e3), 4) if ddc_ms > 0 else None,
+                    # SURVEY 8d's algorithmic flop count against the fp32 vector peak
+                    "fp32_tflops": round(n * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12, 2) if ddc_ms > 0 else None,
+                    "fp32_frac_of_vector_peak": round(n * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12
+                                                      / FP32_VECTOR_PEAK_TFLOPS, 4) if ddc_ms > 0 else None,
                 },
             },
         }
+        if world == 1 and c3 is not None:
+            out["secondary"] = {"c3": c3}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ifs, args.cpu_blocks)
     else:

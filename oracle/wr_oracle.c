@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -508,6 +509,84 @@ double wro_bench_receivers(unsigned int input_rate, const int *if_hz, unsigned i
 	free(rx);
 	free(table);
 	free(scratch);
+	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* The same with T pipeline threads, each owning a disjoint subset of the receivers of the one
+ * tuner buffer (the reference pipeline is single-threaded, radio.cxx:56-59; its
+ * receiver graphs are independent objects, so T of them run side by side).  Wall clock around
+ * all threads; the graphs are built before the clock starts. */
+struct wro_mt_job {
+	wro_receiver *rx;
+	unsigned int first, count;
+	const float *table;
+	const float *iq;
+	size_t nframes;
+	unsigned int nblocks;
+	float *scratch;
+};
+
+static void *wro_mt_worker(void *arg)
+{
+	struct wro_mt_job *j = (struct wro_mt_job *)arg;
+	for (unsigned int b = 0; b < j->nblocks; b++)
+		for (unsigned int c = 0; c < j->count; c++)
+			wro_receiver_run(&j->rx[j->first + c], j->table, j->iq, j->nframes, j->scratch, NULL, NULL);
+	return NULL;
+}
+
+double wro_bench_receivers_mt(unsigned int input_rate, const int *if_hz, unsigned int nrx,
+                              unsigned int chan_passband, unsigned int chan_rate, int mode,
+                              unsigned int audio_passband, unsigned int audio_rate,
+                              const float *iq, size_t nframes, unsigned int nblocks,
+                              unsigned int nthreads)
+{
+	if (nthreads < 1)
+		nthreads = 1;
+	if (nthreads > nrx)
+		nthreads = nrx;
+	float *table = (float *)malloc(sizeof(float) * WRO_TABLE_SIZE);
+	wro_receiver *rx = (wro_receiver *)calloc(nrx, sizeof(wro_receiver));
+	struct wro_mt_job *jobs = (struct wro_mt_job *)calloc(nthreads, sizeof(struct wro_mt_job));
+	pthread_t *th = (pthread_t *)calloc(nthreads, sizeof(pthread_t));
+	struct timespec t0, t1;
+
+	wro_sin_table(table);
+	for (unsigned int c = 0; c < nrx; c++)
+		if (!wro_receiver_init(&rx[c], input_rate, if_hz[c], chan_passband, chan_rate,
+		                       mode, audio_passband, audio_rate)) {
+			free(table);
+			free(rx);
+			free(jobs);
+			free(th);
+			return -1.0;
+		}
+	const size_t k2 = nframes / rx[0].d1 / rx[0].d2;
+	for (unsigned int t = 0; t < nthreads; t++) {
+		jobs[t].rx = rx;
+		jobs[t].first = (unsigned int)((unsigned long long)nrx * t / nthreads);
+		jobs[t].count = (unsigned int)((unsigned long long)nrx * (t + 1) / nthreads) - jobs[t].first;
+		jobs[t].table = table;
+		jobs[t].iq = iq;
+		jobs[t].nframes = nframes;
+		jobs[t].nblocks = nblocks;
+		jobs[t].scratch = (float *)malloc(sizeof(float) * (k2 ? k2 : 1));
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (unsigned int t = 0; t < nthreads; t++)
+		pthread_create(&th[t], NULL, wro_mt_worker, &jobs[t]);
+	for (unsigned int t = 0; t < nthreads; t++)
+		pthread_join(th[t], NULL);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+
+	for (unsigned int t = 0; t < nthreads; t++)
+		free(jobs[t].scratch);
+	for (unsigned int c = 0; c < nrx; c++)
+		wro_receiver_free(&rx[c]);
+	free(rx);
+	free(table);
+	free(jobs);
+	free(th);
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 

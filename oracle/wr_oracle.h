@@ -140,6 +140,14 @@ double   wro_bench_receivers(unsigned int input_rate, const int *if_hz, unsigned
                              const float *iq, size_t nframes, unsigned int nblocks,
                              float *audio_last /* [nrx * nframes/d1/d2] or NULL */);
 
+/* The same on `nthreads` pipeline threads, each owning a disjoint subset of the receivers
+ * (the all-cores CPU baseline; audio is discarded). */
+double   wro_bench_receivers_mt(unsigned int input_rate, const int *if_hz, unsigned int nrx,
+                                unsigned int chan_passband, unsigned int chan_rate, int mode,
+                                unsigned int audio_passband, unsigned int audio_rate,
+                                const float *iq, size_t nframes, unsigned int nblocks,
+                                unsigned int nthreads);
+
 /* RTL-SDR u8 -> float rule (io/rtlsdrtuner.cxx:106) */
 void     wro_u8_to_float(const uint8_t *in, float *out, size_t n);
 

@@ -63,6 +63,7 @@ def lib():
         L.wro_fir_process.restype = C.c_size_t
         L.wro_receiver_run.restype = C.c_size_t
         L.wro_bench_receivers.restype = C.c_double
+        L.wro_bench_receivers_mt.restype = C.c_double
         _lib = L
     return _lib
 
@@ -271,6 +272,17 @@ def bench_receivers(input_rate, ifs, chan_passband, chan_rate, mode, audio_passb
                                      C.c_uint(ifs.size), C.c_uint(chan_passband), C.c_uint(chan_rate),
                                      C.c_int(mode), C.c_uint(audio_passband), C.c_uint(audio_rate),
                                      _p(iq), C.c_size_t(iq.size // 2), C.c_uint(nblocks), None)
+
+
+def bench_receivers_mt(input_rate, ifs, chan_passband, chan_rate, mode, audio_passband, audio_rate,
+                       iq, nblocks, nthreads):
+    """bench_receivers on `nthreads` threads, each with its own subset of the receivers."""
+    iq = _f32(iq)
+    ifs = np.ascontiguousarray(ifs, dtype=np.int32)
+    return lib().wro_bench_receivers_mt(C.c_uint(input_rate), ifs.ctypes.data_as(C.POINTER(C.c_int)),
+                                        C.c_uint(ifs.size), C.c_uint(chan_passband), C.c_uint(chan_rate),
+                                        C.c_int(mode), C.c_uint(audio_passband), C.c_uint(audio_rate),
+                                        _p(iq), C.c_size_t(iq.size // 2), C.c_uint(nblocks), C.c_uint(nthreads))
 
 
 def u8_to_float(b):

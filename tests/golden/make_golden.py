@@ -7,7 +7,7 @@
                         oracle/ref_harness.cxx), all four modes, 8 blocks of 512 frames.
   dspblock_traces.json  scheduling traces of the REAL reference DspBlock runtime
                         (dsp/dspblock.cxx) for the scenarios of oracle/ref_harness.cxx.
-  chain_oracle.npz      regression vectors of the ORACLE for the functions whose
+  oracle_selfcheck_c1.npz  regression vectors of the ORACLE for the functions whose
                         reference sources cannot be built here (<fftw3.h> missing):
                         C1-style single receiver, 4 blocks.  These pin the oracle to
                         itself over time, NOT to the reference ("parity unpinned").
@@ -56,7 +56,7 @@ def main():
         a, c, _ = rx.run(iqf[2 * n * b: 2 * n * (b + 1)])
         audio.append(a)
         chan.append(c)
-    np.savez_compressed(os.path.join(HERE, "chain_oracle.npz"), u8=u8, audio=np.concatenate(audio),
+    np.savez_compressed(os.path.join(HERE, "oracle_selfcheck_c1.npz"), u8=u8, audio=np.concatenate(audio),
                         chan_iq=np.concatenate(chan), block_frames=n,
                         taps_chan=o.lowpass_design(c1["chan_passband"], c1["input_rate"]),
                         taps_audio=o.lowpass_design(c1["audio_passband"], c1["chan_rate"]))

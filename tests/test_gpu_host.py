@@ -228,11 +228,12 @@ np.savez(out, rc=rc, audio=audio[:n.value], left=L.wr_host_registry_sizes())
 
 @pytest.mark.parametrize("with_frontend", [1, 0])
 def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
-    """BASELINE config 1 end to end: FileTuner replays an RTL-SDR format recording (the committed
-    golden capture), one DownConverter + FM Receiver.  With a FrontEnd the float block is staged
+    """BASELINE config 1 end to end: FileTuner replays an RTL-SDR format recording (the capture and
+    the ORACLE's outputs for it, oracle_selfcheck_c1.npz -- a self-check, not a reference pin), one
+    DownConverter + FM Receiver.  With a FrontEnd the float block is staged
     once for SpectrumSink and receiver; without it the raw bytes go to the GPU (u8 ingest)."""
     lib = os.path.join(CXXT, "libwr_host_pipeline.so")
-    g = np.load(os.path.join(ROOT, "tests", "golden", "chain_oracle.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_selfcheck_c1.npz"))
     c1 = synth.C1
     n = int(g["block_frames"])
     path = str(tmp_path / "capture.bin")

@@ -105,10 +105,13 @@ def test_fast_nco_modes_within_tolerance(dev, oracle, nco):
 
 
 def test_c1_single_receiver_u8_file(dev, oracle):
-    """BASELINE config 1: one DownConverter + FM demod off an RTL-SDR format (u8) capture,
-    against the committed fixture (oracle regression vectors) and the live oracle."""
+    """BASELINE config 1: one DownConverter + FM demod off an RTL-SDR format (u8) capture, against
+    oracle_selfcheck_c1.npz.  That file holds outputs of OUR oracle (DownConverter / LowPass cannot be
+    built from the reference here: no FFTW) -- it guards against drift of oracle and kernels over
+    time and is NOT a pin to the reference; the pinned pieces are in demod_reference.npz and
+    dspblock_traces.json."""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "chain_oracle.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_selfcheck_c1.npz"))
     c1 = synth.C1
     n = int(g["block_frames"])
     iq = oracle.u8_to_float(g["u8"])
