@@ -72,8 +72,10 @@ def cpu_baseline(cfg, ifs, blocks):
     cores = max(1, min(len(os.sched_getaffinity(0)), len(ifs)))
     one = oracle.bench_receivers(*args, 1)
     if blocks <= 0:
-        # one block on T threads takes about one / T seconds if the cores scale; aim at ~12 s
-        blocks = int(max(2, min(64, round(12.0 / max(one / cores, 1e-3)))))
+        # calibrate on two blocks (the threads share the memory system: they do not scale like the
+        # cores), then as many blocks as take about 12 s
+        probe = oracle.bench_receivers_mt(*args, 2, cores)
+        blocks = int(max(2, min(256, round(12.0 / max(probe / 2.0, 1e-3)))))
     secs = oracle.bench_receivers_mt(*args, blocks, cores)
     return {
         "value": round(n * blocks / secs / 1e6, 4),

@@ -155,7 +155,9 @@ int wr_u8_to_f32(wr_dev *dev, const uint8_t *in_dev, float *out_dev, size_t coun
  * attached to it (radio.cxx:151-156).  Every receiver chain
  * DownConverter -> LowPass -> Demodulator -> LowPass (radio.cxx:68-82) of the tuner
  * is evaluated by ONE launch sequence per input block.
- * max_block_frames bounds nframes of wr_tuner_submit. */
+ * max_block_frames bounds nframes of wr_tuner_submit; max_channels <= WR_MAX_CHANNELS
+ * (WR_ERR_ARG otherwise; the reference has no limit but its CPU, radio.cxx:151-156). */
+#define WR_MAX_CHANNELS 4096
 int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input_rate,
                     unsigned int max_channels, size_t max_block_frames, int nco_mode);
 int wr_tuner_destroy(wr_tuner *tuner);

@@ -414,4 +414,65 @@ int wr_host_registry_sizes(void)
 	return (int)(Radio::frontEnds().size() * 1000 + Radio::receivers().size());
 }
 
+/* stop() -> setSampleRate / setBlockSize -> start(): the source's tuner batch must follow the new
+ * input rate (the NCO step of every channel, downconverter.cxx:80) and the new block size.  One
+ * front end; `blocks1` blocks at (rate1, block1), then `blocks2` at (rate2, block2) from frame
+ * blocks1*block1 of the same recording on.  audio_out: [2 phases][nrx][audio_cap]. */
+int wr_host_run_rerate(const float *iq, size_t nframes, unsigned int rate1, unsigned int block1,
+                       unsigned int rate2, unsigned int block2, unsigned int blocks1, unsigned int blocks2,
+                       unsigned int nrx, const int *if_hz, int mode,
+                       unsigned int chan_passband, unsigned int chan_rate,
+                       unsigned int audio_passband, unsigned int audio_rate,
+                       float *audio_out, size_t audio_cap, size_t *len1, size_t *len2)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	g_pos = 0;
+	FrontEnd *fe = new FrontEnd(makeTuner);
+	fe->tuner()->setSampleRate(rate1);
+	fe->tuner()->setChannels(2);
+	fe->tuner()->setBlockSize(block1 * 2);
+	std::vector<Receiver *> rx;
+	for (unsigned int n = 0; n < nrx; n++) {
+		Receiver *r = new Receiver();
+		r->downconverter()->setIF(if_hz[n]);
+		r->channelFilter()->setPassband(chan_passband);
+		r->channelFilter()->setOutputSampleRate(chan_rate);
+		r->audioFilter()->setPassband(audio_passband);
+		r->audioFilter()->setOutputSampleRate(audio_rate);
+		r->demodulator()->setMode((Demodulator::Mode)mode);
+		r->stream()->setCapacity(audio_cap);
+		r->setFrontEnd(fe);
+		rx.push_back(r);
+	}
+	int rc = fe->tuner()->start() ? 0 : -1;
+	for (unsigned int b = 0; b < blocks1 && rc == 0; b++)
+		Radio::run();
+	*len1 = *len2 = 0;
+	for (size_t n = 0; n < rx.size() && rc == 0; n++) {
+		const vector<float> &a = rx[n]->stream()->samples();
+		if (a.size() > audio_cap) { rc = -2; break; }
+		memcpy(audio_out + n * audio_cap, a.data(), a.size() * sizeof(float));
+		*len1 = a.size();
+	}
+	fe->tuner()->stop();
+	fe->tuner()->setSampleRate(rate2);
+	fe->tuner()->setBlockSize(block2 * 2);
+	if (rc == 0 && !fe->tuner()->start())
+		rc = -3;
+	for (unsigned int b = 0; b < blocks2 && rc == 0; b++)
+		Radio::run();
+	for (size_t n = 0; n < rx.size() && rc == 0; n++) {
+		const vector<float> &a = rx[n]->stream()->samples();
+		if (a.size() > audio_cap) { rc = -2; break; }
+		memcpy(audio_out + (rx.size() + n) * audio_cap, a.data(), a.size() * sizeof(float));
+		*len2 = a.size();
+	}
+	fe->tuner()->stop();
+	for (size_t n = 0; n < rx.size(); n++)
+		delete rx[n];
+	delete fe;
+	return rc;
+}
+
 } // extern "C"

@@ -36,7 +36,12 @@ def test_single_gpu_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 1 <= r["launches_timed"] <= 5
     assert r["kernel_ms"] < j["ms_per_step"]                      # the dominant kernel is part of a step
     c = j["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["kind"] == "port" and c["cores"] == len(os.sched_getaffinity(0)) and c["value"] > 0
+    assert c["one_core"]["cores"] == 1 and c["one_core"]["value"] > 0
+    assert c["value"] >= c["one_core"]["value"]                    # more threads do not lose
+    c3 = j["secondary"]["c3"]                                        # BASELINE config 3 beside the headline
+    assert c3["value"] > 0 and c3["roofline"]["algorithmic_bytes_per_frame"] == 12 * 65536
+    assert abs(c3["roofline"]["frac"] - c3["roofline"]["achieved"] / 8000.0) < 1e-4
 
 
 def test_two_rank_launch_path():

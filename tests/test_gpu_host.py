@@ -211,6 +211,51 @@ def test_stop_start_keeps_phase_and_two_front_ends(tmp_path, oracle):
             assert np.array_equal(got[t * len(ifs) + c].view(np.uint32), want.view(np.uint32)), (t, c)
 
 
+RERATE_RUNNER = r'''
+import ctypes as C, sys, numpy as np
+lib, npz = sys.argv[1], sys.argv[2]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz)
+iq = np.ascontiguousarray(d["iq"], np.float32); ifs = np.ascontiguousarray(d["ifs"], np.int32); p = [int(v) for v in d["params"]]
+nrx = ifs.size; cap = p[11]
+audio = np.zeros((2 * nrx, cap), np.float32); n1, n2 = C.c_size_t(), C.c_size_t()
+fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+L.wr_host_run_rerate.argtypes = [fp, C.c_size_t] + [C.c_uint] * 7 + [ip, C.c_int] + [C.c_uint] * 4 + [fp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+rc = L.wr_host_run_rerate(iq.ctypes.data_as(fp), iq.size // 2, p[0], p[1], p[2], p[3], p[4], p[5], nrx, ifs.ctypes.data_as(ip), p[6],
+                          p[7], p[8], p[9], p[10], audio.ctypes.data_as(fp), cap, C.byref(n1), C.byref(n2))
+np.savez(sys.argv[3], rc=rc, a1=audio[:nrx, :n1.value], a2=audio[nrx:, :n2.value], left=L.wr_host_registry_sizes())
+'''
+
+
+def test_stop_set_rate_and_block_size_start(tmp_path, oracle):
+    """ADVICE r01: the source's wr_tuner used to survive stop()/start() with the OLD input rate and
+    block size.  stop -> setSampleRate(1 M instead of 2 M) + setBlockSize(60 000 instead of 40 000
+    frames) -> start: the NCO steps follow the new rate (downconverter.cxx:80), the larger block is
+    accepted, phase and prev_i/q carry over (Q5), the filters restart empty."""
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    ifs, mode = [50_000, -75_000, 4321], 3
+    r1, b1, r2, b2, n1, n2 = 2_000_000, 40_000, 1_000_000, 60_000, 2, 2
+    iq = synth.fm_stream(n1 * b1 + n2 * b2, r1, ifs, amp=0.2)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    cap = 4096
+    np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
+             params=np.array([r1, b1, r2, b2, n1, n2, mode, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], cap], np.int64))
+    subprocess.check_call([sys.executable, "-c", RERATE_RUNNER, lib, inp, out],
+                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
+    r = np.load(out)
+    assert int(r["rc"]) == 0 and int(r["left"]) == 0
+    for c, f in enumerate(ifs):
+        rx = oracle.Receiver(r1, f, CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+        a1 = np.concatenate([rx.run(iq[2 * b * b1: 2 * (b + 1) * b1])[0] for b in range(n1)])
+        assert np.array_equal(r["a1"][c].view(np.uint32), a1.view(np.uint32)), c
+        nx = oracle.Receiver(r2, f, CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+        nx.s.phase, nx.s.prev_i, nx.s.prev_q = rx.s.phase, rx.s.prev_i, rx.s.prev_q
+        base = n1 * b1
+        a2 = np.concatenate([nx.run(iq[2 * (base + b * b2): 2 * (base + (b + 1) * b2)])[0] for b in range(n2)])
+        assert np.array_equal(r["a2"][c].view(np.uint32), a2.view(np.uint32)), c
+
+
 FILE_RUNNER = r'''
 import ctypes as C, sys, numpy as np
 lib, path, out = sys.argv[1], sys.argv[2], sys.argv[3]

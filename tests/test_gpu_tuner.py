@@ -550,3 +550,40 @@ def test_one_odd_receiver_costs_its_own_lane_group(dev, oracle, nco):
         for c in range(130):
             assert np.abs(audio[c] - want[b][c]).max() <= 4e-6, (b, c)
     t.destroy()
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE, capi.WR_NCO_SPLIT])
+def test_more_than_sixteen_lane_groups(dev, oracle, nco):
+    """1100 receivers = 18 lane groups: a DDC launch maps 16 of them, the rest go out in launches
+    of their own (and one receiver with its own passband sits in group 17).  Receivers of the first,
+    the 16th, the 17th and the 18th group against the oracle over two blocks."""
+    fs, n, nch = 2_000_000, 20_000, 1100
+    ifs = [(-nch // 2 + c) * 900 + 77 for c in range(nch)]
+    t = Tuner(dev, fs, nch, n, nco)
+    odd = 1090
+    chans = [t.add_receiver(f, 128_000 if c != odd else 300_000, 5_000, capi.WR_USB, 160, 1_000)
+             for c, f in enumerate(ifs)]
+    probe = [0, 63, 960, 1023, 1024, 1025, 1087, 1088, odd, 1099]
+    rxs = {c: oracle.Receiver(fs, ifs[c], 128_000 if c != odd else 300_000, 5_000, oracle.USB, 160, 1_000)
+           for c in probe}
+    start = 0
+    for _ in range(2):
+        iq = synth.fm_stream(n, fs, [ifs[c] for c in probe[::2]], start_frame=start, seed=3, fm_base=30.0, beta=2.0)
+        start += n
+        t.submit_host(iq)
+        for c in probe:
+            wa, wc, _ = rxs[c].run(iq)
+            gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)
+            ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
+            assert gc.size == wc.size and ga.size == wa.size
+            if nco == capi.WR_NCO_EXACT:
+                assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), c
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), c
+            else:
+                assert np.abs(gc - wc).max() <= IQ_ATOL, c
+                assert np.abs(ga - wa).max() <= AUDIO_ATOL, c
+    t.destroy()
+    # the library refuses what it cannot seat
+    import ctypes as C
+    h = C.c_void_p()
+    assert dev.lib.wr_tuner_create(C.byref(h), dev.h, fs, 4097, n, nco) == capi.WR_ERR_ARG

@@ -51,7 +51,15 @@ struct wr_dev {
 	float *scratch;            /* growable scratch */
 	size_t scratch_floats;
 	float *coeff;              /* [WR_FIR_MAX] staging for wr_fir_decimate */
+	/* `scratch` and `coeff` are one buffer each per device, used by calls that may come from
+	 * different threads (SpectrumSink::getSpectrum on HTTP threads while Radio::run() pumps,
+	 * httpserver.cxx:262; two front ends on one GPU).  Work is stream-ordered once enqueued, so the
+	 * lock covers a call's ENQUEUE sequence (grow -> producer kernel -> consuming copy): nobody
+	 * else's kernel can land between a producer and its consumer, and nobody frees the buffer
+	 * under an enqueue in progress. */
+	std::mutex *scratch_lock;
 };
+#define SCRATCH_GUARD(d) std::lock_guard<std::mutex> scratch_guard_(*(d)->scratch_lock)
 
 struct Chan {
 	bool in_use;
@@ -290,7 +298,10 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	wrd_split_tables(hi.data(), lo.data());
 	int rc = WR_OK;
 	d->turn_host = (float *)malloc(WR_TABLE_SIZE * sizeof(float));
-	if (!d->turn_host) {
+	d->scratch_lock = new (std::nothrow) std::mutex();
+	if (!d->turn_host || !d->scratch_lock) {
+		free(d->turn_host);
+		delete d->scratch_lock;
 		delete d;
 		return fail(WR_ERR_NOMEM, "out of memory");
 	}
@@ -328,6 +339,7 @@ extern "C" int wr_dev_close(wr_dev *d)
 	(void)hipFree(d->coeff);
 	(void)hipFree(d->scratch);
 	free(d->turn_host);
+	delete d->scratch_lock;
 	if (d->own_stream)
 		(void)hipStreamDestroy(d->stream);
 	delete d;
@@ -411,6 +423,7 @@ extern "C" int wr_fir_decimate_n(wr_dev *d, const float *in_dev, size_t nframes,
 	if (!fir_length_ok(fir_length))
 		return fail(WR_ERR_ARG, "wr_fir_decimate: fir_length %u is not a power of two in [2, %d]", fir_length,
 		            WR_FIR_MAX);
+	SCRATCH_GUARD(d);
 	int rc = dev_scratch(d, (size_t)(fir_length - 1) * channels);
 	if (rc)
 		return rc;
@@ -549,6 +562,9 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 		return fail(WR_ERR_ARG, "wr_tuner_create: bad argument");
 	if (nco_mode != WR_NCO_SPLIT && nco_mode != WR_NCO_EXACT && nco_mode != WR_NCO_ROTATE)
 		return fail(WR_ERR_ARG, "wr_tuner_create: bad nco_mode %d", nco_mode);
+	if (max_channels > WR_MAX_CHANNELS)
+		return fail(WR_ERR_ARG, "wr_tuner_create: %u channels, at most %u per tuner (64 lane groups of 64)",
+		            max_channels, (unsigned)WR_MAX_CHANNELS);
 	*tuner = nullptr;
 	if (dev_bind(dev))
 		return WR_ERR_HIP;
@@ -1267,6 +1283,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 		HIP_TRY(hipMemcpyAsync(out_host, g->dev.audio + (size_t)c->slot * g->k2max, n * sizeof(float),
 		                       hipMemcpyDeviceToHost, d->stream));
 	} else {
+		SCRATCH_GUARD(d);
 		int rc = dev_scratch(d, n);
 		if (rc)
 			return rc;
@@ -1641,6 +1658,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 				HIP_TRY(hipMemcpyAsync(s->stage, s->stage + 2 * consumed, rest * 2 * sizeof(float),
 				                       hipMemcpyDeviceToDevice, st));
 			} else {
+				SCRATCH_GUARD(d);
 				int rc = dev_scratch(d, rest * 2);
 				if (rc)
 					return rc;
@@ -1682,6 +1700,7 @@ extern "C" int wr_spectrum_get_db(wr_spectrum *s, float *magnitudes_host)
 	wr_dev *d = s->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	SCRATCH_GUARD(d);
 	int rc = dev_scratch(d, s->n);
 	if (rc)
 		return rc;
@@ -1703,6 +1722,7 @@ extern "C" int wr_spectrum_get_waterfall_row(wr_spectrum *s, unsigned int width,
 	wr_dev *d = s->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	SCRATCH_GUARD(d);
 	int rc = dev_scratch(d, (size_t)width * 2);
 	if (rc)
 		return rc;

@@ -1234,16 +1234,30 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
                              const WrPostArgs *post, unsigned long long gsel = 0, bool whole = true)
 {
 	constexpr unsigned int W = DdcGeom<NCO, UTAPS>::waves;
-	const unsigned int allgroups = L.slots_used / 64;
+	const unsigned int allgroups = L.slots_used / 64;        /* <= 64: wr_tuner_create caps max_channels */
 	unsigned long long gmap[2] = {0, 0};
 	unsigned int ngroups = 0;
-	for (unsigned int g = 0; g < allgroups && ngroups < 16u; ++g)
+	unsigned long long rest = 0;                             /* selected groups beyond the 16 one launch maps */
+	for (unsigned int g = 0; g < allgroups; ++g)
 		if (!gsel || ((gsel >> g) & 1ull)) {
-			gmap[ngroups >> 3] |= (unsigned long long)g << ((ngroups & 7u) * 8u);
-			++ngroups;
+			if (ngroups < 16u) {
+				gmap[ngroups >> 3] |= (unsigned long long)g << ((ngroups & 7u) * 8u);
+				++ngroups;
+			} else {
+				rest |= 1ull << g;
+			}
 		}
 	if (!ngroups)
 		return hipSuccess;
+	if (rest) {
+		/* more than 1024 channels: the groups beyond the first 16 go out in launches of their own,
+		 * which neither roll the state again nor carry the post stage or the profiling events */
+		WrTunerLaunch L2 = L;
+		L2.ev_start = L2.ev_stop = nullptr;
+		hipError_t e = launch_ddc<NCO, UTAPS, 0>(st, L2, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, rest, false);
+		if (e != hipSuccess)
+			return e;
+	}
 	size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
 	             : (W * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
 	               + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
@@ -1325,12 +1339,10 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 {
 	/* Lane groups whose 64 channels share one channel filter take the uniform-taps kernel, the
 	 * others the per-lane-taps one: one odd receiver costs its own lane group, not the tuner.
-	 * (More than 16 lane groups in use, i.e. more than 1024 channels: one launch, as a whole.) */
+	 * (A launch maps 16 lane groups; launch_ddc sends further ones out in launches of their own.) */
 	const unsigned int allgroups = L.slots_used / 64;
 	const unsigned long long all = (allgroups >= 64u) ? ~0ull : ((1ull << allgroups) - 1ull);
-	unsigned long long uni = L.uniform_taps ? all : (L.uniform_mask & all);
-	if (allgroups > 16u)
-		uni = L.uniform_taps ? all : 0ull;
+	const unsigned long long uni = L.uniform_taps ? all : (L.uniform_mask & all);
 	const unsigned long long odd = all & ~uni;
 	bool whole = true;
 	if (uni) {

@@ -222,6 +222,26 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	}
 
 	std::lock_guard<std::mutex> g(batch->_lock);
+	{
+		/* The wr_tuner outlives stop()/start() of the source (its channels park their state in
+		 * their blocks meanwhile).  What a stopped source may have changed -- setSampleRate,
+		 * setBlockSize (dspblock.h:60-66; refused while running) -- is baked into the tuner: the
+		 * NCO step of every channel follows from the input rate (downconverter.cxx:80) and the
+		 * device buffers are sized for the block.  With no channel enrolled nothing is lost by
+		 * building a new one. */
+		size_t wantFrames = src->blockSize() / 2;
+		if (wantFrames == 0)
+			wantFrames = 1;
+		if (batch->_tuner && batch->_channels.empty() &&
+		    (batch->_rate != src->outputSampleRate() || batch->_maxFrames != wantFrames)) {
+			wr_tuner_destroy(batch->_tuner);
+			batch->_tuner = NULL;
+			batch->_ringHeld = false;
+			batch->_audioSlots = 0;
+			batch->_audioPtr = NULL;
+			batch->_submitOk = false;
+		}
+	}
 	if (!batch->_tuner) {
 		batch->_rate = src->outputSampleRate();
 		batch->_maxFrames = src->blockSize() / 2;
@@ -309,12 +329,17 @@ bool TunerBatch::pushParams(Channel *ch)
 		return true;                    /* the chain is still starting: next block */
 	if (wr_chan_set_if(_tuner, ch->id, ch->mixer->_ifHz) != WR_OK)
 		return false;
-	if (f1->_coeff.size() == WR_FIR_LENGTH &&
-	    wr_chan_set_taps(_tuner, ch->id, 0, f1->_coeff.data(), f1->decimation()) != WR_OK)
-		return false;
-	if (f2->_coeff.size() == WR_FIR_LENGTH &&
-	    wr_chan_set_taps(_tuner, ch->id, 1, f2->_coeff.data(), f2->decimation()) != WR_OK)
-		return false;
+	LowPass *fs[2] = {f1, f2};
+	for (int stage = 0; stage < 2; stage++) {
+		vector<float> taps;
+		{
+			std::lock_guard<std::mutex> g(fs[stage]->_coeffLock);      /* see LowPass::recalculate */
+			taps = fs[stage]->_coeff;
+		}
+		if (taps.size() == WR_FIR_LENGTH &&
+		    wr_chan_set_taps(_tuner, ch->id, stage, taps.data(), fs[stage]->decimation()) != WR_OK)
+			return false;
+	}
 	if (wr_chan_set_mode(_tuner, ch->id, (int)ch->demod->_mode) != WR_OK)
 		return false;
 	ch->dirty = false;

@@ -95,8 +95,13 @@ void LowPass::deinit()
 
 void LowPass::recalculate()
 {
-	_coeff.resize(_firLength);
-	wr_lowpass_design_n(_firLength, _passband, inputSampleRate(), _coeff.data(), NULL);
+	/* designed aside and swapped in whole: the run thread never sees half-written taps */
+	vector<float> fresh(_firLength);
+	wr_lowpass_design_n(_firLength, _passband, inputSampleRate(), fresh.data(), NULL);
+	{
+		std::lock_guard<std::mutex> g(_coeffLock);
+		_coeff.swap(fresh);
+	}
 	wrhost::TunerBatch::markDirty(_channel);
 }
 
@@ -125,7 +130,13 @@ bool LowPass::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuf
 		}
 		din = (const float *)_in->ptr;
 	}
-	if (wr_fir_decimate_n(dev, din, nframes, ch, decimation(), _firLength, _coeff.data(),
+	vector<float> taps;
+	{
+		std::lock_guard<std::mutex> g(_coeffLock);
+		taps = _coeff;
+	}
+	if (taps.size() != _firLength ||
+	    wr_fir_decimate_n(dev, din, nframes, ch, decimation(), _firLength, taps.data(),
 	                      (float *)_history->ptr, (float *)_out->ptr) != WR_OK) {
 		LOG_ERROR("LowPass: %s\n", wr_last_error());
 		return false;

@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "dspblock.h"
 
 using namespace std;
@@ -45,6 +47,8 @@ private:
 	unsigned int	_reqDecimation;
 	unsigned int	_reqOutputRate;
 	vector<float>	_coeff;			/* _firLength taps, lowpass.cxx:183-189 */
+	std::mutex		_coeffLock;		/* setPassband() arrives on HTTP threads (httpserver.cxx:262): a new
+									 * design is swapped in under this lock, readers copy under it */
 	wrhost::Channel*	_channel;
 	int				_stage;			/* 0 channel filter, 1 audio filter of an enrolled chain */
 	wrhost::DevBuf*	_in;
