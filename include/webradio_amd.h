@@ -255,6 +255,15 @@ int wr_tuner_audio_ring_stats(wr_tuner *tuner, unsigned int *queued, unsigned lo
 /* LowPass::deinit + init (dsp/lowpass.cxx:118-129, 81-116): both filter histories of the
  * channel become empty again; NCO phase and Demodulator prev_i/q are kept (quirk Q5). */
 int wr_chan_reset_history(wr_tuner *tuner, int chan);
+/* Time sharding of ONE stream over several GPUs (BASELINE config 5; the reference has no
+ * counterpart, its pipeline is one thread, radio.cxx:56-59): put every channel of the tuner in
+ * the state it has when the stream STARTS at `frame` -- filter histories empty
+ * (lowpass.cxx:138-139), Demodulator::prev_i/q zero (demodulator.cxx:60-70) -- except
+ * DownConverter::phase, which takes its closed-form value after `frame` input frames from
+ * phase 0 (downconverter.cxx:103).  A block [halo | chunk] submitted next reproduces the
+ * sequential result for the chunk once the first halo/(D1*D2) audio frames are dropped
+ * (webradio_amd/timeshard.py).  One call, no per-channel traffic. */
+int wr_tuner_seek(wr_tuner *tuner, unsigned long long frame);
 /* scale applied to the audio as it is stored (default 1).  The MP3 encoder behind every
  * Receiver multiplies by 32768 before LAME (web/mp3encoder.cxx:65-72); a sink that wants
  * that format gets it from the audio kernel's store instead of a host loop. */

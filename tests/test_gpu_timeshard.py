@@ -78,3 +78,40 @@ def test_time_shard_two_ranks(dev, tmp_path):
     got = np.concatenate([parts[c] for c in range(N)], axis=1)
     want = _sequential(dev, capi.WR_NCO_SPLIT)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+def test_c5_parameters_one_rank_against_oracle(dev, oracle, nco):
+    """BASELINE config 5 on its own parameters: fs = 1 Gsps, 256 channels on the 3.125 MHz raster,
+    D1 = 4000 with the 64 MHz passband whose product 64 * passband just fits 32 bits
+    (lowpass.cxx:167), D2 = 5, halo 260 000 frames.  Three chunks time-sharded on one rank
+    (wr_tuner_seek + one [halo | chunk] block each) against the ORACLE's sequential pass over the
+    same stream, on a sample of the channels."""
+    c5 = synth.C5
+    fs, d1, d2 = c5["input_rate"], 4000, 5
+    H = timeshard.halo_frames(d1, d2)
+    assert H == 260_000 and timeshard.discarded_audio_frames(d1, d2) == 13
+    assert oracle.lowpass_maxbin(c5["chan_passband"], fs) == 2
+    ifs = synth.c2_ifs(256, c5)
+    T, n = 280_000, 3
+    probe = [0, 1, 63, 64, 128, 200, 255]
+    iq = synth.fm_stream(T * n, fs, [ifs[c] for c in probe[::2]], amp=0.1, fm_base=3000.0, fm_step=500.0, beta=2.0)
+    shard = timeshard.TunerShard(dev, fs, ifs, c5["chan_passband"], c5["chan_rate"], capi.WR_FM, c5["audio_passband"],
+                                 c5["audio_rate"], T + H, nco)
+
+    class Solo:
+        rank, world = 0, 1
+        def exchange(self, tail):
+            return None
+    out = timeshard.run_time_sharded(Solo(), lambda c: iq[2 * c * T: 2 * (c + 1) * T], n, T, d1, d2, shard,
+                                     lambda a: a, lambda a: a)
+    shard.close()
+    got = np.concatenate([out[c] for c in range(n)], axis=1)
+    assert got.shape == (256, T * n // (d1 * d2))
+    for c in probe:
+        rx = oracle.Receiver(fs, ifs[c], c5["chan_passband"], c5["chan_rate"], oracle.FM, c5["audio_passband"],
+                             c5["audio_rate"])
+        want = rx.run(iq)[0]
+        tol = 4.8e-7 if nco == capi.WR_NCO_EXACT else 1e-5
+        if c in probe[::2] or nco == capi.WR_NCO_EXACT:      # FM on a noise-only channel is ill-conditioned (SURVEY H3)
+            assert np.abs(got[c] - want).max() <= tol, c

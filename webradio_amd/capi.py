@@ -58,6 +58,7 @@ SIGNATURES = {
     "wr_chan_set_mode": (C.c_int, [_vp, C.c_int, C.c_int]),
     "wr_tuner_keep_stages": (C.c_int, [_vp, _u32]),
     "wr_tuner_flush": (C.c_int, [_vp]),
+    "wr_tuner_seek": (C.c_int, [_vp, C.c_ulonglong]),
     "wr_tuner_audio_ring": (C.c_int, [_vp, _u32]),
     "wr_tuner_audio_ring_acquire": (C.c_int, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t), C.POINTER(_u32), C.POINTER(C.c_ulonglong)]),

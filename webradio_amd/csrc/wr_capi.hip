@@ -1525,6 +1525,50 @@ extern "C" int wr_chan_reset_history(wr_tuner *t, int chan)
 	return WR_OK;
 }
 
+/* Time sharding of one stream (BASELINE config 5): every channel of the tuner as if the
+ * stream began at `frame` -- both filter histories empty, Demodulator::prev_i/q zero -- except the
+ * NCO, whose phase takes the closed-form value it has after `frame` input frames from phase 0
+ * (downconverter.cxx:103: phase = frame * phaseStep mod 2^31).  One call for the whole tuner, a
+ * handful of stream-ordered fills: no per-channel round trips. */
+extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	wr_dev *d = t->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	hipStream_t st = d->stream;
+	/* a post stage still waiting for the next submit would write ITS end-of-block state over ours */
+	int rc = tuner_flush(t);
+	if (rc)
+		return rc;
+	for (Group *g : t->groups) {
+		if (g->dirty) {
+			rc = group_upload(t, g);
+			if (rc)
+				return rc;
+		}
+		const size_t S = g->slots;
+		for (size_t s = 0; s < S; ++s) {
+			const int ci = g->owner[s];
+			if (ci < 0)
+				continue;
+			Chan &c = t->chans[ci];
+			c.phaseL = (unsigned int)((unsigned long long)c.stepL * frame);     /* host mirror; mod 2^32, left-aligned */
+			c.phase_dirty = c.prev_dirty = c.cs_hist_reset = c.dem_hist_reset = false;
+			c.prev_iq[0] = c.prev_iq[1] = 0.0f;
+		}
+		/* on the device from the step array itself: no host data in flight, nothing to wait for */
+		HIP_TRY(wrk_seek(st, g->dev, (unsigned int)S, g->sp, g->parity, frame));
+	}
+	for (Chan &c : t->chans)
+		if (c.in_use && c.group < 0) {
+			c.phaseL = (unsigned int)((unsigned long long)c.stepL * frame);
+			c.prev_iq[0] = c.prev_iq[1] = 0.0f;
+		}
+	return WR_OK;
+}
+
 /* --------------------------------------------------------------- spectrum -- */
 
 static void plan_free(WrFftPlan &p)

@@ -119,6 +119,8 @@ hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A);
 bool wrk_tuner_post_supported(unsigned int d2);
 hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
                           const float *hist, float *hist_next);
+hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int sp, int parity,
+                    unsigned long long frame);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
                            size_t col_offset_floats, unsigned int width_floats, float *dst);
 

@@ -1485,6 +1485,35 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	return hipGetLastError();
 }
 
+/* wr_tuner_seek: the state every channel has when the stream starts at `frame` -- empty filter
+ * histories (a zero LO row = an empty LowPass::block), Demodulator::prev_i/q = 0 -- and the NCO phase
+ * in closed form, frame * step mod 2^32 left-aligned (downconverter.cxx:103).  One small launch. */
+__global__ void __launch_bounds__(256)
+k_seek(unsigned int *__restrict__ phase, const unsigned int *__restrict__ step, unsigned long long frame,
+       float2 *__restrict__ hist_cs, float2 *__restrict__ hist_lo, float2 *__restrict__ prev_iq,
+       float *__restrict__ dem_hist, unsigned int slots)
+{
+	const unsigned int gsz = gridDim.x * blockDim.x;
+	const unsigned int rows = WR_HIST * slots;
+	for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows; e += gsz) {
+		hist_cs[e] = make_float2(0.0f, 0.0f);
+		hist_lo[e] = make_float2(0.0f, 0.0f);
+		dem_hist[e] = 0.0f;
+		if (e < slots) {
+			phase[e] = (unsigned int)((unsigned long long)step[e] * frame);
+			prev_iq[e] = make_float2(0.0f, 0.0f);
+		}
+	}
+}
+
+hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int sp, int parity, unsigned long long frame)
+{
+	const unsigned int rows = WR_HIST * slots;
+	k_seek<<<(rows + 255u) / 256u, 256, 0, st>>>(G.phase[sp], G.step, frame, (float2 *)G.hist_cs[sp],
+	                                             (float2 *)G.hist_lo[sp], (float2 *)G.prev_iq[parity], G.dem[parity], slots);
+	return hipGetLastError();
+}
+
 __global__ void k_input_hist(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes,
                              const float2 *__restrict__ hist, float2 *__restrict__ hist_next)
 {

@@ -128,6 +128,24 @@ class Tuner:
         """Launch a post stage (demod + audio filter) that is still waiting for the next submit."""
         check(self.lib.wr_tuner_flush(self.h))
 
+    def seek(self, frame):
+        """Every channel as if the stream started at `frame` (NCO phase closed-form): time sharding."""
+        check(self.lib.wr_tuner_seek(self.h, C.c_ulonglong(frame)))
+
+    def fetch_audio_all(self):
+        """The last block's audio of every slot in one transfer: array [slots][frames]."""
+        stride, frames, slots = C.c_size_t(), C.c_size_t(), C.c_uint()
+        self.lib.wr_tuner_fetch_audio_all(self.h, None, 0, C.byref(stride), C.byref(frames), C.byref(slots))
+        out = np.empty(max(1, slots.value * frames.value), dtype=np.float32)
+        check(self.lib.wr_tuner_fetch_audio_all(self.h, ptr(out), out.size, C.byref(stride), C.byref(frames),
+                                                C.byref(slots)))
+        return out[: slots.value * frames.value].reshape(slots.value, frames.value)
+
+    def slot(self, ch):
+        s = C.c_int()
+        check(self.lib.wr_chan_slot(self.h, ch, C.byref(s)))
+        return s.value
+
     def audio_ring(self, depth):
         """Pinned host ring for the audio of every submit (0 = off)."""
         check(self.lib.wr_tuner_audio_ring(self.h, depth))

@@ -18,6 +18,20 @@ C2 = dict(
     block_frames=4_000_000,   # 40 ms
 )
 
+# BASELINE config 5 ("C5"): ONE 1 Gsps stream, otherwise C2 with D1 = 4000; the passband
+# 64 MHz is the largest whose product 64 * passband still fits 32 bits (lowpass.cxx:167, Q6)
+C5 = dict(
+    input_rate=1_000_000_000,
+    channels=256,
+    if0=-398_437_500,
+    if_step=3_125_000,
+    chan_passband=64_000_000,
+    chan_rate=250_000,        # D1 = 4000
+    audio_passband=8_000,
+    audio_rate=50_000,        # D2 = 5
+    block_frames=20_000_000,  # chunk T: 20 ms, a multiple of D1 * D2 = 20 000
+)
+
 # BASELINE config 1 ("C1"): one receiver off a 2.048 Msps RTL-SDR style stream
 C1 = dict(
     input_rate=2_048_000,

@@ -110,36 +110,35 @@ def _concat(a, b):
 
 
 class TunerShard:
-    """`process` callback on a GPU: a wr_tuner that is reset to an empty state for every block."""
+    """`process` callback on a GPU: a wr_tuner that starts every block from the state of a stream
+    beginning at the block's first frame (wr_tuner_seek: one call for all channels) and hands the
+    audio of all channels back with one transfer (wr_tuner_fetch_audio_all)."""
 
     def __init__(self, dev, input_rate, ifs, chan_passband, chan_rate, mode, audio_passband, audio_rate,
                  max_frames, nco=0):
         from .device import Tuner
         from . import capi
-        import ctypes as C
-        self.capi, self.C = capi, C
+        self.capi = capi
         self.t = Tuner(dev, input_rate, len(ifs), max_frames, nco)
         self.dev = dev
         self.ch = [self.t.add_receiver(f, chan_passband, chan_rate, mode, audio_passband, audio_rate) for f in ifs]
-        self.steps = []
-        step = C.c_int()
-        for f in ifs:
-            capi.check(self.t.lib.wr_phase_step(f, input_rate, C.byref(step)))
-            self.steps.append(step.value)
+        self.slots = None
         self.d = (input_rate // chan_rate) * (chan_rate // audio_rate)
 
-    def __call__(self, block, start_frame, nframes):
-        capi = self.capi
-        zero = np.zeros(2, np.float32)
-        for ch, st in zip(self.ch, self.steps):
-            self.t.set_state(ch, phase_at(st, start_frame), zero)
-            capi.check(self.t.lib.wr_chan_reset_history(self.t.h, ch))
+    def submit(self, block, start_frame, nframes):
+        """seek + submit, nothing fetched: the audio stays in HBM (wr_tuner_audio_dev)"""
+        self.t.seek(start_frame)
         if isinstance(block, np.ndarray):
             self.t.submit_host(block)
         else:
             self.t.submit_device(block, nframes)
-        k2 = nframes // self.d
-        return np.stack([self.t.fetch(ch, capi.WR_STAGE_AUDIO, k2) for ch in self.ch])
+
+    def __call__(self, block, start_frame, nframes):
+        self.submit(block, start_frame, nframes)
+        audio = self.t.fetch_audio_all()                     # [slots][frames], one device-to-host copy
+        if self.slots is None:
+            self.slots = [self.t.slot(ch) for ch in self.ch]
+        return audio[self.slots, : nframes // self.d]
 
     def close(self):
         self.t.destroy()
