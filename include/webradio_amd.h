@@ -121,7 +121,15 @@ void *wr_dev_stream(wr_dev *dev);
 int wr_dev_malloc(wr_dev *dev, size_t bytes, void **ptr_dev);
 int wr_dev_free(wr_dev *dev, void *ptr_dev);
 int wr_dev_upload(wr_dev *dev, void *dst_dev, const void *src_host, size_t bytes);    /* sync */
-int wr_dev_download(wr_dev *dev, void *dst_host, const void *src_dev, size_t bytes);  /* sync */
+int wr_dev_download(wr_dev *dev, void *dst_host, const void *src_dev, size_t bytes);
+/* For callers that upload the same host buffer block after block (DspSource's output vector,
+ * dspblock.h:118, 130-137): page-lock it once, then enqueue the copy and carry on -- the DMA runs
+ * beside the caller's own work.  The buffer must not be written until wr_dev_wait_uploads()
+ * (or wr_dev_sync) returns, and must be unregistered before it is freed. */
+int wr_dev_host_register(wr_dev *dev, void *host, size_t bytes);
+int wr_dev_host_unregister(wr_dev *dev, void *host);
+int wr_dev_upload_async(wr_dev *dev, void *dst_dev, const void *src_host, size_t bytes);
+int wr_dev_wait_uploads(wr_dev *dev);  /* sync */
 
 /* ------------------------------------------- one kernel per reference block -- */
 /* DownConverter::process (dsp/downconverter.cxx:91-114).  Frame n uses phase
@@ -251,6 +259,8 @@ int wr_tuner_audio_ring(wr_tuner *tuner, unsigned int depth);
 int wr_tuner_audio_ring_acquire(wr_tuner *tuner, const float **audio_host, size_t *chan_stride,
                                 size_t *frames, unsigned int *slots_used, unsigned long long *seq);
 int wr_tuner_audio_ring_release(wr_tuner *tuner);
+/* *ready = 1 when the oldest queued block's copy has landed: acquire would return without waiting */
+int wr_tuner_audio_ring_ready(wr_tuner *tuner, int *ready);
 int wr_tuner_audio_ring_stats(wr_tuner *tuner, unsigned int *queued, unsigned long long *overruns);
 /* LowPass::deinit + init (dsp/lowpass.cxx:118-129, 81-116): both filter histories of the
  * channel become empty again; NCO phase and Demodulator prev_i/q are kept (quirk Q5). */

@@ -112,8 +112,9 @@ int main(int argc, char **argv)
 		for (size_t i = 0; i < a.size(); i++)
 			sum += fabs(a[i]);
 	}
-	printf("{\"receivers\": %u, \"blocks\": %u, \"block_frames\": %u, \"ms_per_block\": %.3f, "
+	printf("{\"audio\": \"%s\", \"receivers\": %u, \"blocks\": %u, \"block_frames\": %u, \"ms_per_block\": %.3f, "
 	       "\"msps_tuner_input\": %.1f, \"audio_samples_per_receiver\": %lu, \"audio_abs_sum\": %.3f}\n",
+	       (getenv("WEBRADIO_AUDIO_LATE") && atoi(getenv("WEBRADIO_AUDIO_LATE"))) ? "one block late (WEBRADIO_AUDIO_LATE=1)" : "on time",
 	       nrx, blocks, frames, dt / blocks * 1e3, (double)frames * blocks / dt / 1e6,
 	       total / (unsigned long)rx.size(), sum);
 	if (getenv("WR_HOST_BENCH_PROFILE")) {

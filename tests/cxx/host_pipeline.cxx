@@ -11,6 +11,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <string>
 
 #include <atomic>
 #include <thread>
@@ -19,6 +21,7 @@
 
 #include "radio.h"
 #include "filetuner.h"
+#include "gpubatch.h"
 
 namespace {
 
@@ -472,6 +475,91 @@ int wr_host_run_rerate(const float *iq, size_t nframes, unsigned int rate1, unsi
 	for (size_t n = 0; n < rx.size(); n++)
 		delete rx[n];
 	delete fe;
+	return rc;
+}
+
+/* Two front ends pumped by Radio::run() (radio.cxx:56-59: one after the other), `blocks` runs with
+ * a pause in between; returns every receiver's audio and the tuner batches' trace (WEBRADIO_TRACE=1:
+ * "S0A0S1A1|..." -- S submit, A audio that was already in the ring, W audio waited for, digit = front
+ * end, | = end of a Radio::run()).  With WEBRADIO_AUDIO_LATE=1 no run() waits for the GPU.
+ * audio_out: [2][nrx][audio_cap]. */
+int wr_host_run_two_traced(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
+                           unsigned int nrx, const int *if_hz, int mode,
+                           unsigned int chan_passband, unsigned int chan_rate,
+                           unsigned int audio_passband, unsigned int audio_rate, unsigned int blocks,
+                           float *audio_out, size_t audio_cap, size_t *audio_len, char *trace_out, size_t trace_cap)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	struct Replay3 : public Tuner {
+		Replay3(const string &n) : Tuner(n, "Replay3"), pos(0) {}
+		size_t pos;
+		bool init() { return true; }
+		void deinit() {}
+		bool process(const vector<sample_t> &, vector<sample_t> &out) {
+			size_t frames = out.size() / 2;
+			if (pos + frames > g_frames)
+				return false;
+			memcpy(out.data(), g_iq + 2 * pos, out.size() * sizeof(float));
+			pos += frames;
+			return true;
+		}
+	};
+	struct F { static Tuner *make(const string &n) { return new Replay3(n); } };
+	FrontEnd *fe[2] = { new FrontEnd(F::make), new FrontEnd(F::make) };
+	std::vector<Receiver *> rx;
+	for (int t = 0; t < 2; t++) {
+		fe[t]->tuner()->setSampleRate(rate);
+		fe[t]->tuner()->setChannels(2);
+		fe[t]->tuner()->setBlockSize(block_frames * 2);
+		static_cast<Replay3 *>(fe[t]->tuner())->pos = (size_t)t * block_frames;    /* second tuner: one block later */
+		for (unsigned int n = 0; n < nrx; n++) {
+			Receiver *r = new Receiver();
+			r->downconverter()->setIF(if_hz[n]);
+			r->channelFilter()->setPassband(chan_passband);
+			r->channelFilter()->setOutputSampleRate(chan_rate);
+			r->audioFilter()->setPassband(audio_passband);
+			r->audioFilter()->setOutputSampleRate(audio_rate);
+			r->demodulator()->setMode((Demodulator::Mode)mode);
+			r->stream()->setCapacity(audio_cap);
+			r->setFrontEnd(fe[t]);
+			rx.push_back(r);
+		}
+	}
+	int rc = (fe[0]->tuner()->start() && fe[1]->tuner()->start()) ? 0 : -1;
+	wrhost::traceClear();
+	std::string tr;
+	size_t seen = 0;
+	for (unsigned int b = 0; b < blocks && rc == 0; b++) {
+		Radio::run();
+		const std::vector<wrhost::TraceEvent> &ev = wrhost::trace();
+		for (; seen < ev.size(); seen++) {
+			tr += ev[seen].kind;
+			tr += (ev[seen].source == (const void *)static_cast<DspSource *>(fe[0]->tuner())) ? '0' : '1';
+		}
+		tr += '|';
+		timespec ts = { 0, 5000000 };          /* let the GPU finish what was enqueued */
+		nanosleep(&ts, NULL);
+	}
+	size_t len = 0;
+	for (size_t n = 0; n < rx.size() && rc == 0; n++) {
+		const vector<float> &a = rx[n]->stream()->samples();
+		if (n == 0)
+			len = a.size();
+		if (a.size() != len || len > audio_cap) { rc = -2; break; }
+		memcpy(audio_out + n * audio_cap, a.data(), len * sizeof(float));
+	}
+	*audio_len = len;
+	if (trace_out && trace_cap) {
+		strncpy(trace_out, tr.c_str(), trace_cap - 1);
+		trace_out[trace_cap - 1] = 0;
+	}
+	for (int t = 0; t < 2; t++)
+		fe[t]->tuner()->stop();
+	for (size_t n = 0; n < rx.size(); n++)
+		delete rx[n];
+	delete fe[0];
+	delete fe[1];
 	return rc;
 }
 

@@ -256,6 +256,61 @@ def test_stop_set_rate_and_block_size_start(tmp_path, oracle):
         assert np.array_equal(r["a2"][c].view(np.uint32), a2.view(np.uint32)), c
 
 
+TRACED_RUNNER = r'''
+import ctypes as C, sys, numpy as np
+lib, npz = sys.argv[1], sys.argv[2]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz)
+iq = np.ascontiguousarray(d["iq"], np.float32); ifs = np.ascontiguousarray(d["ifs"], np.int32); p = [int(v) for v in d["params"]]
+nrx = ifs.size; cap = p[8]
+audio = np.zeros((2 * nrx, cap), np.float32); n = C.c_size_t(); tr = C.create_string_buffer(4096)
+fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+L.wr_host_run_two_traced.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, ip, C.c_int] + [C.c_uint] * 5 + [fp, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+rc = L.wr_host_run_two_traced(iq.ctypes.data_as(fp), iq.size // 2, p[0], p[1], nrx, ifs.ctypes.data_as(ip), p[6], p[2], p[3], p[4], p[5], p[7],
+                              audio.ctypes.data_as(fp), cap, C.byref(n), tr, 4096)
+np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], trace=np.array(tr.value.decode()), left=L.wr_host_registry_sizes())
+'''
+
+
+def test_late_audio_keeps_both_front_ends_in_flight(tmp_path, oracle):
+    """WEBRADIO_AUDIO_LATE=1: Radio::run() (radio.cxx:56-59 pumps the front ends one after the other)
+    only ENQUEUES a block per front end and hands out the previous block's audio, which is already in
+    the pinned ring: the trace of every run() is submit/audio-was-there for front end 0, then the
+    same for front end 1, never a wait -- so both tuners' blocks are in flight together (on a node,
+    on two GPUs).  The audio is the on-time audio one block late: a block of silence first."""
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    ifs, mode = [50_000, -75_000, 4321], 3
+    rate, block, nblk = CFG["rate"], CFG["block"], 5
+    iq = synth.fm_stream((nblk + 1) * block, rate, ifs, amp=0.2)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    cap = nblk * (block // 2000) + 16
+    np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
+             params=np.array([rate, block, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], mode, nblk, cap], np.int64))
+    res = {}
+    for late in ("0", "1"):
+        subprocess.check_call([sys.executable, "-c", TRACED_RUNNER, lib, inp, out],
+                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1",
+                                       WEBRADIO_AUDIO_LATE=late))
+        r = np.load(out)
+        assert int(r["rc"]) == 0 and int(r["left"]) == 0
+        res[late] = (r["audio"], str(r["trace"]))
+    k2 = block // 2000
+    on_time, late = res["0"][0], res["1"][0]
+    assert on_time.shape == late.shape == (2 * len(ifs), nblk * k2)
+    for t in range(2):                                           # the on-time audio is the oracle's
+        for c, f in enumerate(ifs):
+            rx = oracle.Receiver(rate, f, CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+            want = np.concatenate([rx.run(iq[2 * (b + t) * block: 2 * (b + t + 1) * block])[0] for b in range(nblk)])
+            assert np.array_equal(on_time[t * len(ifs) + c].view(np.uint32), want.view(np.uint32))
+    assert not late[:, :k2].any()                                # one block of silence ...
+    assert np.array_equal(late[:, k2:].view(np.uint32), on_time[:, :-k2].view(np.uint32))    # ... then the same bits
+    runs = res["1"][1].strip("|").split("|")
+    assert runs[0] == "S0S1"                                     # nothing to hand out yet
+    assert all(r == "S0A0S1A1" for r in runs[1:]), runs           # enqueue, take what is there; never wait
+    assert all(r.startswith("S0") and "S1" in r for r in res["0"][1].strip("|").split("|"))
+
+
 FILE_RUNNER = r'''
 import ctypes as C, sys, numpy as np
 lib, path, out = sys.argv[1], sys.argv[2], sys.argv[3]

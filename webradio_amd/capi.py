@@ -42,6 +42,10 @@ SIGNATURES = {
     "wr_dev_free": (C.c_int, [_vp, _vp]),
     "wr_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wr_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "wr_dev_host_register": (C.c_int, [_vp, _vp, _sz]),
+    "wr_dev_host_unregister": (C.c_int, [_vp, _vp]),
+    "wr_dev_upload_async": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "wr_dev_wait_uploads": (C.c_int, [_vp]),
     "wr_mix": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_u32), C.c_int]),
     "wr_fir_decimate": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _vp, _vp]),
     "wr_fir_decimate_n": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp]),
@@ -63,6 +67,7 @@ SIGNATURES = {
     "wr_tuner_audio_ring_acquire": (C.c_int, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t), C.POINTER(_u32), C.POINTER(C.c_ulonglong)]),
     "wr_tuner_audio_ring_release": (C.c_int, [_vp]),
+    "wr_tuner_audio_ring_ready": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "wr_tuner_audio_ring_stats": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_ulonglong)]),
     "wr_chan_get_state": (C.c_int, [_vp, C.c_int, C.POINTER(_u32), _vp]),
     "wr_chan_set_state": (C.c_int, [_vp, C.c_int, _u32, _vp]),

@@ -58,6 +58,8 @@ struct wr_dev {
 	 * else's kernel can land between a producer and its consumer, and nobody frees the buffer
 	 * under an enqueue in progress. */
 	std::mutex *scratch_lock;
+	hipEvent_t upload_done;    /* behind the last wr_dev_upload_async */
+	bool upload_pending;
 };
 #define SCRATCH_GUARD(d) std::lock_guard<std::mutex> scratch_guard_(*(d)->scratch_lock)
 
@@ -340,6 +342,8 @@ extern "C" int wr_dev_close(wr_dev *d)
 	(void)hipFree(d->scratch);
 	free(d->turn_host);
 	delete d->scratch_lock;
+	if (d->upload_done)
+		(void)hipEventDestroy(d->upload_done);
 	if (d->own_stream)
 		(void)hipStreamDestroy(d->stream);
 	delete d;
@@ -386,6 +390,73 @@ extern "C" int wr_dev_upload(wr_dev *d, void *dst_dev, const void *src_host, siz
 		return WR_OK;
 	HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
+	return WR_OK;
+}
+
+/* Page-lock a host buffer the caller will upload from repeatedly (a source's block vector): a copy
+ * out of pageable memory is staged by the runtime and holds the calling thread for its whole
+ * duration; out of registered memory it is one DMA the thread does not wait for. */
+extern "C" int wr_dev_host_register(wr_dev *d, void *host, size_t bytes)
+{
+	if (!d || !host || !bytes)
+		return fail(WR_ERR_ARG, "wr_dev_host_register: bad argument");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+	if (e == hipErrorHostMemoryAlreadyRegistered) {
+		/* a range registered earlier whose memory was freed and handed out again by the allocator */
+		(void)hipGetLastError();
+		(void)hipHostUnregister(host);
+		e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+	}
+	if (e != hipSuccess) {
+		(void)hipGetLastError();                    /* not sticky: a later launch check must not trip over it */
+		return fail(WR_ERR_HIP, "wr_dev_host_register: %s", hipGetErrorString(e));
+	}
+	return WR_OK;
+}
+
+extern "C" int wr_dev_host_unregister(wr_dev *d, void *host)
+{
+	if (!d || !host)
+		return fail(WR_ERR_ARG, "wr_dev_host_unregister: bad argument");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	hipError_t e = hipHostUnregister(host);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(WR_ERR_HIP, "wr_dev_host_unregister: %s", hipGetErrorString(e));
+	}
+	return WR_OK;
+}
+
+/* Enqueue a host-to-device copy on the device's stream and return; the host buffer must stay
+ * untouched until wr_dev_wait_uploads (or wr_dev_sync) returns. */
+extern "C" int wr_dev_upload_async(wr_dev *d, void *dst_dev, const void *src_host, size_t bytes)
+{
+	if (!d || (bytes && (!dst_dev || !src_host)))
+		return fail(WR_ERR_ARG, "wr_dev_upload_async: bad argument");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	if (!d->upload_done)
+		HIP_TRY(hipEventCreateWithFlags(&d->upload_done, hipEventDisableTiming));
+	if (bytes)
+		HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(hipEventRecord(d->upload_done, d->stream));
+	d->upload_pending = true;
+	return WR_OK;
+}
+
+extern "C" int wr_dev_wait_uploads(wr_dev *d)
+{
+	if (!d)
+		return fail(WR_ERR_ARG, "dev is NULL");
+	if (!d->upload_pending)
+		return WR_OK;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	HIP_TRY(hipEventSynchronize(d->upload_done));
+	d->upload_pending = false;
 	return WR_OK;
 }
 
@@ -1478,6 +1549,30 @@ extern "C" int wr_tuner_audio_ring_acquire(wr_tuner *t, const float **audio_host
 	*slots_used = r->slots;
 	if (seq)
 		*seq = r->seq;
+	return WR_OK;
+}
+
+/* has the copy of the oldest queued block landed (would wr_tuner_audio_ring_acquire return at once)? */
+extern "C" int wr_tuner_audio_ring_ready(wr_tuner *t, int *ready)
+{
+	if (!t || !ready)
+		return fail(WR_ERR_ARG, "wr_tuner_audio_ring_ready: bad argument");
+	*ready = 0;
+	hipEvent_t ev;
+	{
+		std::lock_guard<std::mutex> lk(t->ring_lock);
+		if (t->ring.empty() || !t->ring_count || t->ring_held)
+			return WR_OK;
+		const unsigned int n = (unsigned int)t->ring.size();
+		ev = t->ring[(t->ring_head + n - t->ring_count) % n].done;
+	}
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	const hipError_t e = hipEventQuery(ev);
+	if (e == hipSuccess)
+		*ready = 1;
+	else if (e != hipErrorNotReady)
+		return fail(WR_ERR_HIP, "wr_tuner_audio_ring_ready: %s", hipGetErrorString(e));
 	return WR_OK;
 }
 

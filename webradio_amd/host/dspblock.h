@@ -112,6 +112,7 @@ private:
 	uint64_t			_nsTotal;
 	uint64_t			_framesIn;
 	uint64_t			_framesOut;
+	uint64_t			_calls;			/* runFrames() calls: the profiler samples the clock (see runFrames) */
 	bool				_running;
 	bool				_elide;
 	unsigned int		_curInFrames;
@@ -131,7 +132,7 @@ public:
 	unsigned int blockSize() const { return _blockSize; }
 
 	bool start() { return DspBlock::start(); }
-	void stop() { DspBlock::stop(); }
+	void stop();
 	bool run();
 	void setSampleRate(unsigned int rate) { DspBlock::setSampleRate(rate); }
 	void setChannels(unsigned int channels) { DspBlock::setChannels(channels); }
@@ -150,6 +151,12 @@ public:
 	int gpuIndex() const { return _gpuIndex; }
 	void setGpuIndex(int i) { _gpuIndex = i; }
 	void setGpuCleanup(void (*fn)(DspSource*)) { _gpuCleanup = fn; }
+	/* called at the top of run(), before the source's own process() may rewrite its block vector:
+	 * the GPU glue waits there for an upload of the previous block that is still in flight */
+	void setGpuBeforeRun(void (*fn)(DspSource*)) { _gpuBeforeRun = fn; }
+	/* called at the top of stop(), before the block vector is released: the GPU glue lets go of
+	 * whatever it holds on that memory (page locks) */
+	void setGpuBeforeStop(void (*fn)(DspSource*)) { _gpuBeforeStop = fn; }
 	/* the vector the source's process() filled for the current block */
 	const vector<sample_t>& currentBlock() const { return _out; }
 
@@ -161,6 +168,8 @@ private:
 	void*				_gpuStage;
 	int					_gpuIndex;
 	void				(*_gpuCleanup)(DspSource*);
+	void				(*_gpuBeforeRun)(DspSource*);
+	void				(*_gpuBeforeStop)(DspSource*);
 };
 
 #endif /* DSPBLOCK_H_ */

@@ -28,6 +28,31 @@ unsigned int envUnsigned(const char *name, unsigned int fallback)
 }
 }
 
+namespace {
+std::vector<TraceEvent> g_trace;
+std::mutex g_traceLock;
+bool traceOn()
+{
+	static const bool on = envUnsigned("WEBRADIO_TRACE", 0) != 0;
+	return on;
+}
+void traceAdd(const void *src, char kind)
+{
+	if (!traceOn())
+		return;
+	std::lock_guard<std::mutex> g(g_traceLock);
+	TraceEvent e = { src, kind };
+	g_trace.push_back(e);
+}
+}
+
+const std::vector<TraceEvent> &trace() { return g_trace; }
+void traceClear()
+{
+	std::lock_guard<std::mutex> g(g_traceLock);
+	g_trace.clear();
+}
+
 int deviceCount()
 {
 	int n = 0;
@@ -55,12 +80,53 @@ wr_dev *device(int index)
 	return g_devs[index];
 }
 
+/* the device copy of a source's current block, and the host buffers it has been uploaded from:
+ * sources hand out the same one or two vectors block after block (RtlSdrTuner swaps two,
+ * rtlsdrtuner.cxx:280), so they are page-locked once and the copy is a DMA nobody waits for */
 struct SourceStage {
 	DevBuf buf;
 	unsigned long epoch;
 	const void *host;
 	size_t floats;
-	SourceStage() : epoch(0), host(NULL), floats(0) {}
+	wr_dev *dev;
+	struct Pinned { void *ptr; size_t bytes; };
+	std::vector<Pinned> pinned;
+	SourceStage() : epoch(0), host(NULL), floats(0), dev(NULL) {}
+	~SourceStage() { unpin(); }
+	/* the page locks must go before the memory does: freed but still registered, it is handed out
+	 * again by the allocator and a later copy out of it fails ("invalid argument") */
+	void unpin() {
+		if (dev)
+			wr_dev_wait_uploads(dev);
+		for (size_t n = 0; n < pinned.size(); n++)
+			wr_dev_host_unregister(dev, pinned[n].ptr);
+		pinned.clear();
+		epoch = 0;
+		host = NULL;
+	}
+	bool pin(wr_dev *d, const void *p, size_t bytes) {
+		for (size_t n = 0; n < pinned.size(); n++)
+			if (pinned[n].ptr == p && pinned[n].bytes >= bytes)
+				return true;
+		if (envUnsigned("WEBRADIO_NO_PINNING", 0))
+			return false;
+		for (size_t n = 0; n < pinned.size(); n++)
+			if (pinned[n].ptr == p) {                      /* same address, grown: register afresh */
+				wr_dev_host_unregister(d, pinned[n].ptr);
+				pinned.erase(pinned.begin() + n);
+				break;
+			}
+		if (pinned.size() >= 4) {                          /* a source that allocates per block: give up on the oldest */
+			wr_dev_host_unregister(d, pinned[0].ptr);
+			pinned.erase(pinned.begin());
+		}
+		if (wr_dev_host_register(d, const_cast<void *>(p), bytes) != WR_OK)
+			return false;
+		Pinned e = { const_cast<void *>(p), bytes };
+		pinned.push_back(e);
+		dev = d;
+		return true;
+	}
 };
 
 static void releaseSource(DspSource *src)
@@ -68,6 +134,22 @@ static void releaseSource(DspSource *src)
 	delete static_cast<SourceStage *>(src->gpuStage());
 	src->setGpuStage(NULL);
 	TunerBatch::destroyFor(src);
+}
+
+/* top of DspSource::stop(): the block vector is about to be released (dspblock.cxx:153-167) */
+static void beforeSourceStop(DspSource *src)
+{
+	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
+	if (st)
+		st->unpin();
+}
+
+/* top of DspSource::run(): the source is about to refill its block vector */
+static void beforeSourceRun(DspSource *src)
+{
+	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
+	if (st && st->dev)
+		wr_dev_wait_uploads(st->dev);
 }
 
 wr_dev *deviceFor(const DspBlock *block)
@@ -108,12 +190,20 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 		st = new SourceStage();
 		src->setGpuStage(st);
 		src->setGpuCleanup(releaseSource);
+		src->setGpuBeforeRun(beforeSourceRun);
+		src->setGpuBeforeStop(beforeSourceStop);
 	}
 	if (st->epoch != src->epoch() || st->host != host.data() || st->floats != host.size()) {
 		if (only_if_present)
 			return NULL;
 		const size_t bytes = host.size() * sizeof(float);
-		if (!st->buf.reserve(dev, bytes) || wr_dev_upload(dev, st->buf.ptr, host.data(), bytes) != WR_OK) {
+		/* out of page-locked memory the copy is enqueued and the graph walk goes on beside it; the
+		 * source's next run() waits for it before it touches the vector again (beforeSourceRun) */
+		const bool pinned = st->pin(dev, host.data(), bytes);
+		st->dev = dev;
+		if (!st->buf.reserve(dev, bytes) ||
+		    (pinned ? wr_dev_upload_async(dev, st->buf.ptr, host.data(), bytes)
+		            : wr_dev_upload(dev, st->buf.ptr, host.data(), bytes)) != WR_OK) {
 			LOG_ERROR("staging the source block failed: %s\n", wr_last_error());
 			return NULL;
 		}
@@ -153,7 +243,8 @@ void DevBuf::release()
 
 TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
-	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0)
+	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
+	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateQueued(false), _silence(false)
 {
 }
 
@@ -259,7 +350,8 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 			batch->_tuner = NULL;
 			return NULL;
 		}
-		wr_tuner_audio_ring(batch->_tuner, 2);
+		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 3 : 2);
+		batch->_lateQueued = false;
 	}
 	int id = -1;
 	if (wr_chan_add(batch->_tuner, &id) != WR_OK) {
@@ -269,6 +361,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	Channel *ch = new Channel();
 	ch->batch = batch;
 	ch->id = id;
+	ch->slot = -1;
 	ch->mixer = mixer;
 	ch->chanFilter = f1;
 	ch->demod = dm;
@@ -353,10 +446,14 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		return _submitOk;
 	_submittedEpoch = _source->epoch();
 	_submitOk = false;
+	bool pushed = false;
 	for (size_t n = 0; n < _channels.size(); n++)
-		if (_channels[n]->dirty && !pushParams(_channels[n])) {
-			LOG_ERROR("channel parameters rejected: %s\n", wr_last_error());
-			return false;
+		if (_channels[n]->dirty || _channels[n]->slot < 0) {
+			pushed = true;
+			if (_channels[n]->dirty && !pushParams(_channels[n])) {
+				LOG_ERROR("channel parameters rejected: %s\n", wr_last_error());
+				return false;
+			}
 		}
 	if (nframes > _maxFrames) {
 		LOG_ERROR("block of %u frames exceeds the %zu the tuner batch was sized for\n", nframes, _maxFrames);
@@ -389,8 +486,47 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
+	if (pushed)                            /* a filter change may have moved a channel to another rate group */
+		for (size_t n = 0; n < _channels.size(); n++)
+			if (wr_chan_slot(_tuner, _channels[n]->id, &_channels[n]->slot) != WR_OK)
+				_channels[n]->slot = -1;
 	/* the graph hands this block's audio on within this very run(): no waiting for the next launch */
 	wr_tuner_flush(_tuner);
+	traceAdd(_source, 'S');
+	{
+		int ready = 0;
+		if (traceOn() && (!_late || _lateQueued) && wr_tuner_audio_ring_ready(_tuner, &ready) == WR_OK)
+			traceAdd(_source, ready ? 'A' : 'W');
+	}
+	if (_late) {
+		/* WEBRADIO_AUDIO_LATE=1: the sinks get every block's audio ONE run() later (a block's worth
+		 * of latency, 40 ms at C2).  Nothing in run() then waits for the GPU: this block's copy,
+		 * kernels and audio transfer are merely enqueued, what is handed out is the previous
+		 * block's audio, which arrived in the pinned ring while the host was busy elsewhere -- and
+		 * the front ends of a Radio (radio.cxx:56-59 pumps them one after the other) keep all their
+		 * GPUs busy at once.  The first block's run() hands out silence, the last block's audio is
+		 * dropped at stop(). */
+		_silence = !_lateQueued;
+		_lateQueued = true;
+		_audioSlots = 0;
+		if (!_silence) {
+			const float *p = NULL;
+			size_t stride = 0, frames = 0;
+			unsigned int slots = 0;
+			unsigned long long seq = 0;
+			if (wr_tuner_audio_ring_acquire(_tuner, &p, &stride, &frames, &slots, &seq) != WR_OK) {
+				LOG_ERROR("audio ring: %s\n", wr_last_error());
+				return false;
+			}
+			_ringHeld = true;
+			_audioPtr = p;
+			_audioStride = stride;
+			_audioFrames = frames;
+			_audioSlots = slots;
+		}
+		_submitOk = true;
+		return true;
+	}
 	/* one transfer brings back the audio of every channel: through the tuner's pinned ring
 	 * (queued behind the kernels by the submit itself), read in place until the next block */
 	size_t stride = 0, frames = 0;
@@ -430,17 +566,22 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 
 bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 {
-	std::lock_guard<std::mutex> g(_lock);
+	/* no lock: called on the run thread only, after this block's submitOnce() on the same thread
+	 * (the setters on other threads touch Channel::dirty and the blocks' own members, not these) */
 	if (!_submitOk)
 		return false;
 	if (out.empty())
 		return true;
-	int slot = -1;
-	if (_audioSlots && wr_chan_slot(_tuner, ch->id, &slot) == WR_OK && (unsigned int)slot < _audioSlots &&
-	    _audioFrames == out.size()) {
+	if (_late && _silence) {
+		memset(out.data(), 0, out.size() * sizeof(float));
+		return true;
+	}
+	const int slot = ch->slot;
+	if (_audioSlots && slot >= 0 && (unsigned int)slot < _audioSlots && _audioFrames == out.size()) {
 		memcpy(out.data(), _audioPtr + (size_t)slot * _audioStride, out.size() * sizeof(float));
 		return true;
 	}
+	std::lock_guard<std::mutex> g(_lock);
 	size_t got = 0;
 	if (wr_chan_fetch(_tuner, ch->id, WR_STAGE_AUDIO, out.data(), out.size(), &got) != WR_OK) {
 		LOG_ERROR("wr_chan_fetch: %s\n", wr_last_error());

@@ -49,6 +49,14 @@ wr_dev *deviceFor(const DspBlock *block);
 const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out,
                          bool only_if_present = false);
 
+/* WEBRADIO_TRACE=1: what the tuner batches did, in order -- 'S' a block submitted (enqueued, nothing
+ * waited for), 'A' audio taken from the pinned ring that was already there, 'W' audio that had to
+ * be waited for.  (source, kind) pairs; tests read it to see that the front ends of a Radio have
+ * their blocks in flight at the same time. */
+struct TraceEvent { const void *source; char kind; };
+const std::vector<TraceEvent> &trace();
+void traceClear();
+
 /* a resizable device buffer */
 struct DevBuf {
 	DevBuf() : dev(NULL), ptr(NULL), bytes(0) {}
@@ -65,6 +73,7 @@ class TunerBatch;
 struct Channel {
 	TunerBatch *batch;
 	int id;                       /* wr_tuner channel id */
+	int slot;                     /* its row in the tuner's audio array (refreshed when parameters are pushed) */
 	DownConverter *mixer;
 	LowPass *chanFilter;
 	Demodulator *demod;
@@ -113,6 +122,9 @@ private:
 	bool _ringHeld;                   /* a slot of the tuner's pinned audio ring is acquired */
 	size_t _audioStride, _audioFrames;
 	unsigned int _audioSlots;
+	bool _late;                       /* WEBRADIO_AUDIO_LATE: hand out the PREVIOUS block's audio (see submitOnce) */
+	bool _lateQueued;                 /* a block has been submitted whose audio has not been handed out yet */
+	bool _silence;                    /* late mode, first block: nothing to hand out yet */
 	std::mutex _lock;
 };
 
