@@ -587,3 +587,48 @@ def test_more_than_sixteen_lane_groups(dev, oracle, nco):
     import ctypes as C
     h = C.c_void_p()
     assert dev.lib.wr_tuner_create(C.byref(h), dev.h, fs, 4097, n, nco) == capi.WR_ERR_ARG
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_ROTATE, capi.WR_NCO_SPLIT, capi.WR_NCO_EXACT])
+def test_few_distinct_channel_filters_share_the_fast_kernel(dev, oracle, nco):
+    """receiverhandler.cxx:130-137 gives every receiver its own passband control.  Up to four
+    distinct channel filters per lane group stay on the fast (window-folded) ROTATE kernel, one
+    copy of the sample window per filter; the fifth sends the group to the per-lane-taps kernel.
+    150 receivers: group 0 has 4 filters, group 1 two, group 2 one, then filters change while
+    running (one group goes to five and comes back).  Every receiver against the oracle."""
+    cfg = _mini_c2(150)
+    fs = cfg["fs"]
+    pbs = [128_000, 200_000, 64_000, 300_000, 31_250]
+    def pb_of(c, phase):
+        if c < 64:
+            k = c % 4 if phase != 1 else c % 5             # phase 1: five filters in group 0
+            return pbs[k]
+        if c < 128:
+            return pbs[c % 2] if phase < 2 else pbs[0]     # phase 2: group 1 becomes uniform
+        return pbs[0]
+    t = Tuner(dev, fs, 150, 40_000, nco)
+    rxs, chans = [], []
+    for c, f in enumerate(cfg["ifs"]):
+        rxs.append(oracle.Receiver(fs, f, pb_of(c, 0), cfg["chan_rate"], oracle.LSB, cfg["audio_pb"], cfg["audio_rate"]))
+        chans.append(t.add_receiver(f, pb_of(c, 0), cfg["chan_rate"], capi.WR_LSB, cfg["audio_pb"], cfg["audio_rate"]))
+    for b in range(6):
+        phase = b // 2
+        if b in (2, 4):
+            for c in range(150):
+                if pb_of(c, phase) != pb_of(c, phase - 1):
+                    rxs[c].s.chan_fir.coeff[:64] = list(oracle.lowpass_design(pb_of(c, phase), fs))
+                    t.set_filter(chans[c], 0, pb_of(c, phase), cfg["chan_rate"])
+        iq = synth.fm_stream(40_000, fs, cfg["ifs"][::16], start_frame=b * 40_000, amp=0.1)
+        t.submit_host(iq)
+        audio = t.fetch_audio_all()
+        for c in range(150):
+            wa, wc, _ = rxs[c].run(iq)
+            ga = audio[t.slot(chans[c])]
+            if nco == capi.WR_NCO_EXACT:
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (b, c)
+            else:
+                assert np.abs(ga - wa).max() <= 4e-6, (b, c)
+            if c % 37 == 0:
+                gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * 40_000)
+                assert np.abs(gc - wc).max() <= (0.0 if nco == capi.WR_NCO_EXACT else IQ_ATOL), (b, c)
+    t.destroy()

@@ -103,7 +103,10 @@ struct Group {
 	std::vector<int> owner;    /* slot -> chan or -1 */
 	bool dirty;                /* parameters must be uploaded before the next launch */
 	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
-	unsigned long long uniform_mask = 0; /* bit i: lane group i does (the others take the per-lane-taps kernel) */
+	unsigned long long uniform_mask = 0; /* bit i: lane group i does */
+	unsigned long long fewsets_mask = 0; /* bit i: lane group i has at most WR_TAPSETS distinct channel filters
+	                                        (the others take the per-lane-taps kernel) */
+	unsigned char nsets[64] = {0};       /* how many */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -566,6 +569,7 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.taps2);
 	(void)hipFree(g->dev.rot);
 	(void)hipFree(g->dev.taps1u);
+	(void)hipFree(g->dev.tapsel);
 	(void)hipFree(g->dev.prev_iq[0]);
 	(void)hipFree(g->dev.prev_iq[1]);
 	(void)hipFree(g->dev.chan_iq[0]);
@@ -610,7 +614,8 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.rot, S * 4);
-	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S * WR_TAPSETS);
+	if (!rc) rc = dev_alloc_zero(&g->dev.tapsel, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
@@ -1029,38 +1034,60 @@ static int group_upload(wr_tuner *t, Group *g)
 			taps2[(size_t)j * S + s] = c.taps[1][j];
 		}
 	}
-	/* Receivers of a tuner nearly always share one channel filter (radio.cxx:78-79 sets
-	 * the same passband/rate for all).  When every 64-slot lane group is uniform, the
-	 * kernel folds the taps into the shared sample window; idle slots of such a group
-	 * are given the group's taps so that any slot can serve as its representative. */
+	/* Receivers of a tuner nearly always share one channel filter (radio.cxx:78-79 sets the same
+	 * passband/rate for all), and when they do not (receiverhandler.cxx:130-137: every receiver has
+	 * its own passband control) a lane group still holds only a few distinct ones.  The fast kernel
+	 * folds the taps into the shared sample window, one copy of the window per distinct filter (up
+	 * to WR_TAPSETS); a lane group with more than that takes the per-lane-taps kernel. */
 	bool uniform = true;
-	unsigned long long umask = 0;
+	unsigned long long umask = 0, fmask = 0;
+	std::vector<float> taps1u(S * WR_TAPSETS, 0.0f);
+	std::vector<int> tapsel(S, 0);
+	memset(g->nsets, 0, sizeof(g->nsets));
 	for (size_t base = 0; base < S; base += WR_LANES) {
-		int rep = -1;
-		bool uni = true;
+		const size_t grp = base / WR_LANES;
+		int reps[WR_TAPSETS];
+		unsigned int nrep = 0;
+		bool few = true;
 		for (size_t s = base; s < base + WR_LANES; ++s) {
 			int ci = g->owner[s];
 			if (ci < 0)
 				continue;
-			if (rep < 0)
-				rep = ci;
-			else if (memcmp(t->chans[ci].taps[0], t->chans[rep].taps[0], sizeof(float) * WR_FIR_LENGTH))
-				uni = false;
+			unsigned int q = 0;
+			for (; q < nrep; ++q)
+				if (!memcmp(t->chans[ci].taps[0], t->chans[reps[q]].taps[0], sizeof(float) * WR_FIR_LENGTH))
+					break;
+			if (q == nrep) {
+				if (nrep == WR_TAPSETS) {
+					few = false;
+					break;
+				}
+				reps[nrep++] = ci;
+			}
+			tapsel[s] = (int)q;
 		}
-		if (rep >= 0 && uni)
+		if (!few || grp >= 64) {
 			for (size_t s = base; s < base + WR_LANES; ++s)
-				if (g->owner[s] < 0)
-					for (int j = 0; j < WR_FIR_LENGTH; ++j)
-						taps1[(size_t)j * S + s] = t->chans[rep].taps[0][j];
-		if (rep >= 0 && !uni)
+				tapsel[s] = 0;
+			if (nrep)
+				uniform = false;
+			continue;
+		}
+		for (unsigned int q = 0; q < nrep; ++q)
+			for (size_t j = 0; j < WR_LANES; ++j)               /* window order: sample j meets coeff[63 - j] */
+				taps1u[(grp * WR_TAPSETS + q) * WR_LANES + j] = t->chans[reps[q]].taps[0][WR_FIR_LENGTH - 1 - j];
+		g->nsets[grp] = (unsigned char)(nrep ? nrep : 1);
+		fmask |= 1ull << grp;
+		if (nrep <= 1)
+			umask |= 1ull << grp;
+		else
 			uniform = false;
-		if (uni && base / WR_LANES < 64)
-			umask |= 1ull << (base / WR_LANES);
 	}
 	g->uniform_taps = uniform;
-	g->uniform_mask = umask;           /* a lane group that is not uniform takes the per-lane-taps kernel, alone */
-	/* per-slot turns of the ROTATE NCO and the window-ordered taps of each lane group (see WrGroupDev) */
-	std::vector<float> rot(S * 4, 0.0f), taps1u(S, 0.0f);
+	g->uniform_mask = umask;
+	g->fewsets_mask = fmask;
+	/* per-slot turns of the ROTATE NCO (see WrGroupDev) */
+	std::vector<float> rot(S * 4, 0.0f);
 	{
 		const float *turn = t->dev->turn_host;
 		for (size_t s = 0; s < S; ++s) {
@@ -1069,8 +1096,6 @@ static int group_upload(wr_tuner *t, Group *g)
 			rot[4 * s + 1] = turn[Sx & 0xFFFFu];
 			rot[4 * s + 2] = turn[(Sx + 16385u) & 0xFFFFu];
 			rot[4 * s + 3] = turn[(Sx + 1u) & 0xFFFFu];
-			const size_t base = s - s % WR_LANES, j = s % WR_LANES;
-			taps1u[s] = taps1[(size_t)(WR_FIR_LENGTH - 1 - j) * S + base];
 		}
 	}
 	/* pageable sources: hipMemcpyAsync stages them before returning */
@@ -1081,6 +1106,7 @@ static int group_upload(wr_tuner *t, Group *g)
 	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1u, taps1u.data(), taps1u.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.tapsel, tapsel.data(), tapsel.size() * sizeof(int), hipMemcpyHostToDevice, st));
 	for (size_t s = 0; s < S; ++s) {
 		int ci = g->owner[s];
 		if (ci < 0)
@@ -1231,8 +1257,9 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.k2 = L.k1 / g->d2;
 		L.k2max = g->k2max;
 		L.nco_mode = t->nco_mode;
-		L.uniform_taps = g->uniform_taps ? 1 : 0;
 		L.uniform_mask = g->uniform_mask;
+		L.fewsets_mask = g->fewsets_mask;
+		memcpy(L.nsets, g->nsets, sizeof(L.nsets));
 		L.audio_scale = t->audio_scale;
 		L.ev_start = L.ev_stop = nullptr;
 		if (prof_now) {
@@ -1267,7 +1294,7 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
 		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
 		const bool defer = !two_kernels && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE
-		                   && (g->uniform_taps || (g->uniform_mask & ((L.slots_used / 64 >= 64) ? ~0ull : ((1ull << (L.slots_used / 64)) - 1ull))) != 0);
+		                   && (g->fewsets_mask & ((L.slots_used / 64 >= 64) ? ~0ull : ((1ull << (L.slots_used / 64)) - 1ull))) != 0;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, L, g->dev));
 			HIP_TRY(wrk_tuner_audio(st, L, g->dev));

@@ -15,6 +15,9 @@
 #define WR_HIST      (WR_FIR_LENGTH - 1)   /* 63 frames of FIR history, lowpass.cxx:133 */
 #define WR_LANES     64                    /* wavefront width on gfx950 */
 #define WR_SPLIT_N   256                   /* entries of the coarse and of the fine NCO table */
+#define WR_TAPSETS   4                     /* distinct channel filters a lane group may mix in the fast DDC kernel:
+                                              receivers of one tuner mostly share a passband (radio.cxx:78-79),
+                                              the UI lets each choose its own (receiverhandler.cxx:130-137) */
 
 /* ---- host design math (wr_design.cpp) ---- */
 void     wrd_sin_table(float *table);
@@ -45,8 +48,10 @@ struct WrGroupDev {
 	 * requests behind the other 31 waves of its CU, and every wave of the launch does so at once) */
 	float        *rot;          /* WR_NCO_ROTATE: [slots][4] the two turns of the slot's step:
 	                               cis(2 pi S / 65536), cis(2 pi (S+1) / 65536), S = step >> 16 */
-	float        *taps1u;       /* [slots] lane group g's channel filter when all its slots share one:
-	                               taps1u[g*64 + j] = coeff[63 - j], the tap of window sample j */
+	float        *taps1u;       /* [groups][WR_TAPSETS][64] the distinct channel filters of lane group g (when
+	                               there are at most WR_TAPSETS): taps1u[(g*WR_TAPSETS + q)*64 + j] =
+	                               coeff_q[63 - j], the tap of window sample j */
+	int          *tapsel;       /* [slots] which of its group's filters the slot's channel uses */
 	float        *prev_iq[2];   /* [slots][2] Demodulator::prev_i/prev_q, ping-pong by block parity */
 	float        *chan_iq[2];   /* [k1max][slots][2] channel-filter output, time major; double buffered so
 	                               that block b+1's DDC can run while block b is being demodulated */
@@ -70,8 +75,9 @@ struct WrTunerLaunch {
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
 	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
-	int          uniform_taps;  /* every 64-slot lane group carries one tap set (all its slots) */
-	unsigned long long uniform_mask;   /* bit g: lane group g does (up to 64 groups; beyond that only uniform_taps) */
+	unsigned long long uniform_mask;   /* bit g: all channels of lane group g share ONE channel filter */
+	unsigned long long fewsets_mask;   /* bit g: lane group g has at most WR_TAPSETS distinct channel filters */
+	unsigned char nsets[64];           /* distinct channel filters of lane group g (valid where fewsets_mask says) */
 	void        *ev_start, *ev_stop;   /* hipEvent_t pair the DDC launch itself stamps (profiling), or NULL */
 };
 

@@ -584,6 +584,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next,
             const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
             const float *__restrict__ taps1, const float4 *__restrict__ rot, const float *__restrict__ taps1u,
+            const int *__restrict__ tapsel, unsigned int kmax,
             float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post,
@@ -628,9 +629,12 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 * the kernel's only LDS, so byte 1 of both is free for the table index) */
 	const unsigned int a_hi = (unsigned int)(uintptr_t)hi_l;
 	const unsigned int a_lo = (unsigned int)(uintptr_t)lo_l;
-	/* this wave's sample windows: 64 x float2 each, [buffer][tap] */
+	/* this wave's sample windows: 64 x float2 each, [buffer][tap set][tap].  UTAPS: the window holds
+	 * tap * sample, once per distinct channel filter of the lane group (`kmax` of them at most in
+	 * this launch, WR_TAPSETS the limit); a lane reads the copy made with ITS filter. */
+	const unsigned int nset = UTAPS ? kmax : 1u;
 	v2f *win = lds + (NCO == WR_NCO_SPLIT ? DDC_TABLE_BYTES / 8u : NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N : 0u)
-	           + wave * 128u;
+	           + wave * (128u * nset);
 
 	/* the tuner's next input history = last 63 frames of [hist | cur] (lowpass.cxx:138-142
 	 * keeps them per LowPass; here once per tuner).  It goes to the OTHER history buffer,
@@ -661,16 +665,20 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	unsigned int k = LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
 	if (k >= wpg)
 		k = k1u;                                         /* the few waves left over stay idle */
-	const float *ltaps = (const float *)(lds + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N : 0u) + waves_per_wg * 128u);
+	const float *ltaps = (const float *)(lds + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N : 0u) + waves_per_wg * 128u * nset);
 	if (LTAPS) {
-		float *lt = (float *)(lds + 2u * WR_SPLIT_N + waves_per_wg * 128u);
+		float *lt = (float *)(lds + 2u * WR_SPLIT_N + waves_per_wg * 128u * nset);
 		for (unsigned int e = threadIdx.x; e < WR_FIR_LENGTH * 64u; e += blockDim.x)
 			lt[e] = taps1[(size_t)(e >> 6) * slots + g * 64u + (e & 63u)];
 		__syncthreads();
 	}
 
 	float h[(UTAPS || LTAPS) ? 1 : WR_FIR_LENGTH];   /* per-lane taps in registers (SPLIT / EXACT) */
-	float hlane = 0.0f;                         /* UTAPS: lane j holds the tap of sample j */
+	float hlane[UTAPS ? WR_TAPSETS : 1];        /* UTAPS: lane j holds the tap of sample j, per tap set */
+	unsigned int mysel = 0;                     /* UTAPS: which of the group's tap sets this lane's channel uses */
+#pragma unroll
+	for (int q = 0; q < (UTAPS ? WR_TAPSETS : 1); ++q)
+		hlane[q] = 0.0f;
 	unsigned int p0 = 0, st = 0;
 	int fl = 0;
 	unsigned int buf = 0;
@@ -700,8 +708,12 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 				rot1 = (v2f){r.z, r.w};
 			}
 			if (UTAPS) {
-				/* every slot of the group carries the same taps (host guarantee) */
-				hlane = taps1u[s];
+				/* the lane group's channel filters: a few distinct ones at most (host guarantee) */
+				mysel = (unsigned int)tapsel[s];
+#pragma unroll
+				for (int q = 0; q < (UTAPS ? WR_TAPSETS : 1); ++q)
+					if ((unsigned int)q < nset)
+						hlane[q] = taps1u[((size_t)g * WR_TAPSETS + q) * 64u + lane];
 			} else {
 #pragma unroll
 				for (int j = 0; j < ((UTAPS || LTAPS) ? 1 : WR_FIR_LENGTH); ++j)
@@ -734,10 +746,14 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		 * prefetch goes out last -- so that waiting for the anchors never waits for it. */
 		{
 			const float2 xf = xnext;
-			if (UTAPS)
-				win[buf * 64u + lane] = (v2f){hlane * xf.x, hlane * xf.y};
-			else
+			if (UTAPS) {
+#pragma unroll
+				for (int q = 0; q < (UTAPS ? WR_TAPSETS : 1); ++q)
+					if ((unsigned int)q < nset)
+						win[(buf * nset + q) * 64u + lane] = (v2f){hlane[q] * xf.x, hlane[q] * xf.y};
+			} else {
 				win[buf * 64u + lane] = (v2f){xf.x, xf.y};
+			}
 		}
 		v2f csq[ROT_Q];
 		if (NCO == WR_NCO_ROTATE && n0 >= 0) {
@@ -748,7 +764,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		}
 		if (kn < k1u)
 			xnext = window_sample(kn);
-		const lds_v2f *w = (const lds_v2f *)(win + buf * 64u);
+		/* (per lane: lanes of channels with different filters read different copies of the window) */
+		const v2f *wbase = win + (buf * nset + mysel) * 64u;
+		const lds_v2f *w = (const lds_v2f *)wbase;
 		v2f acc = {0.0f, 0.0f};
 
 		if (n0 >= 0 && NCO == WR_NCO_SPLIT) {
@@ -759,7 +777,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			v2f ta[2][NT], tb[2][NT];                /* gathered cis(coarse), cis(fine)       */
 			v4f xw[2][NT / 2];                       /* window samples, two taps per 16 B read */
 			unsigned int ah[NT], al[NT];             /* rotating address registers */
-			const lds_v4f *w4 = (const lds_v4f *)(win + buf * 64u);
+			const lds_v4f *w4 = (const lds_v4f *)wbase;
 #pragma unroll
 			for (int jj = 0; jj < NT; ++jj) {
 				ah[jj] = a_hi;
@@ -813,7 +831,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			const unsigned int P0 = p0 + (unsigned int)n0 * st;
 			unsigned int F = P0 << 16;                /* the 16 fraction bits, left-aligned */
 			const unsigned int fstep = st << 16;
-			const lds_v4f *w4 = (const lds_v4f *)(win + buf * 64u);
+			const lds_v4f *w4 = (const lds_v4f *)wbase;
 			v2f A = {0.0f, 0.0f}, Aq[ROT_Q];
 #pragma unroll
 			for (int jp = 0; jp < WR_FIR_LENGTH / 2; ++jp) {
@@ -1258,8 +1276,17 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		if (e != hipSuccess)
 			return e;
 	}
+	/* tap sets in this launch: the largest count among the groups it covers (SPLIT: one, its
+	 * replicated tables leave no room for more windows) */
+	unsigned int kmax = 1;
+	if (UTAPS && NCO == WR_NCO_ROTATE)
+		for (unsigned int i = 0; i < ngroups; ++i) {
+			const unsigned int g = (unsigned int)((gmap[i >> 3] >> ((i & 7u) * 8u)) & 255u);
+			if (g < 64u && L.nsets[g] > kmax)
+				kmax = L.nsets[g];
+		}
 	size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
-	             : (W * 2u * 512u) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
+	             : (W * 2u * 512u * kmax) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
 	               + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
 	unsigned int wgs_per_cu = DdcGeom<NCO, UTAPS>::wgs_per_cu;
 	unsigned int post_wgs = 0;
@@ -1318,7 +1345,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		                      (const unsigned int *)G.step, (const float2 *)G.hist_cs[L.sp], (const int *)G.flags,
 		                      G.phase[L.sp ^ 1], (float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp],
 		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (const float4 *)G.rot, (const float *)G.taps1u,
-		                      (float2 *)G.chan_iq[L.cb], table_dev,
+		                      (const int *)G.tapsel, kmax, (float2 *)G.chan_iq[L.cb], table_dev,
 		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
 		return hipGetLastError();
 	}
@@ -1327,7 +1354,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		L.k1, L.d1,
 		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
-		(const float4 *)G.rot, G.taps1u, (float2 *)G.chan_iq[L.cb], table_dev,
+		(const float4 *)G.rot, G.taps1u, G.tapsel, kmax, (float2 *)G.chan_iq[L.cb], table_dev,
 		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
 	return hipGetLastError();
 }
@@ -1342,7 +1369,8 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 	 * (A launch maps 16 lane groups; launch_ddc sends further ones out in launches of their own.) */
 	const unsigned int allgroups = L.slots_used / 64;
 	const unsigned long long all = (allgroups >= 64u) ? ~0ull : ((1ull << allgroups) - 1ull);
-	const unsigned long long uni = L.uniform_taps ? all : (L.uniform_mask & all);
+	/* ROTATE takes a group with up to WR_TAPSETS distinct filters, SPLIT one with a single filter */
+	const unsigned long long uni = ((NCO == WR_NCO_ROTATE) ? L.fewsets_mask : L.uniform_mask) & all;
 	const unsigned long long odd = all & ~uni;
 	bool whole = true;
 	if (uni) {
