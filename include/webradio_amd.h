@@ -191,6 +191,31 @@ int wr_chan_set_filter(wr_tuner *tuner, int chan, int stage, unsigned int passba
 /* same with caller-designed taps */
 int wr_chan_set_taps(wr_tuner *tuner, int chan, int stage, const float *coeff_host /* [64] */,
                      unsigned int decimation);
+/* LowPass::_firLength as a run-time value (dsp/lowpass.cxx:38-39 FIXME, :102-110, :167-189 are
+ * written in terms of it) INSIDE the fused path: fir_length a power of two in [2, 64].  A shorter
+ * filter is the 64-tap filter with its oldest taps zero, bit for bit (the sum runs oldest sample
+ * first, lowpass.cxx:150-158).  Longer filters: wr_fir_decimate_n, block by block. */
+int wr_chan_set_filter_n(wr_tuner *tuner, int chan, int stage, unsigned int fir_length,
+                         unsigned int passband, unsigned int out_rate);
+int wr_chan_set_taps_n(wr_tuner *tuner, int chan, int stage, const float *coeff_host /* [fir_length] */,
+                       unsigned int fir_length, unsigned int decimation);
+/* stage 2 (WR_FILTER_CHANNEL2): an optional SECOND channel LowPass between the first one and the
+ * Demodulator -- several LowPass blocks in a row, which is how the reference's own means cut a
+ * narrow channel out of a fast stream (one 64-tap stage gives bin 0 below fs / 128,
+ * lowpass.cxx:167) -- evaluated inside the tuner's launch sequence.  Its input rate is stage 0's
+ * output rate; set it after stage 0 and before stage 1 (the audio filter follows the last channel
+ * stage).  WR_STAGE_CHAN_IQ then is ITS output: what the demodulator sees. */
+#define WR_FILTER_CHANNEL  0
+#define WR_FILTER_AUDIO    1
+#define WR_FILTER_CHANNEL2 2
+/* The two receiver controls the reference's REST interface names but never implements (af_gain and
+ * squelch_threshold are reported as 0 with a FIXME, web/receiverhandler.cxx:112,118-119,127):
+ *   af_gain   the audio sample times 10^(dB/20), in float, after the audio filter;
+ *   squelch   an audio frame is muted (0.0f) when the mean power i^2 + q^2 of the decimation-many
+ *             demodulator input frames behind it is below 10^(dBFS/10); enable = 0 opens it.
+ * 0 dB and an open squelch leave every bit as it was. */
+int wr_chan_set_af_gain(wr_tuner *tuner, int chan, float gain_db);
+int wr_chan_set_squelch(wr_tuner *tuner, int chan, float threshold_dbfs, int enable);
 /* Demodulator::setMode (dsp/demodulator.h:49) */
 int wr_chan_set_mode(wr_tuner *tuner, int chan, int mode);
 /* ask for WR_STAGE_CHAN_IQ / WR_STAGE_DEMOD to be kept for wr_chan_fetch (audio

@@ -285,6 +285,30 @@ def bench_receivers_mt(input_rate, ifs, chan_passband, chan_rate, mode, audio_pa
                                         _p(iq), C.c_size_t(iq.size // 2), C.c_uint(nblocks), C.c_uint(nthreads))
 
 
+def af_gain_squelch(audio, demod_in_iq, d2, gain_db=0.0, squelch_dbfs=None):
+    """The two receiver controls the reference names and never implements ("FIXME: af_gain, squelch",
+    web/receiverhandler.cxx:112,118-119,127) -- so this is the build's OWN definition, restated
+    here in scalar float arithmetic for the tests (include/webradio_amd.h: wr_chan_set_af_gain /
+    wr_chan_set_squelch): an audio frame is muted when the mean power i*i + q*q of the d2
+    demodulator-input frames behind it (summed in order, divided by (float)d2) is below
+    10^(dBFS/10); then the sample is multiplied by 10^(dB/20) as a float."""
+    audio = np.array(audio, dtype=np.float32)
+    z = np.asarray(demod_in_iq, dtype=np.float32).reshape(-1, 2)
+    if squelch_dbfs is not None:
+        thr = np.float32(10.0 ** (float(squelch_dbfs) / 10.0))
+        for k in range(audio.size):
+            p = np.float32(0.0)
+            for i in range(d2):
+                zi, zq = z[k * d2 + i]
+                p = np.float32(p + np.float32(np.float32(zi * zi) + np.float32(zq * zq)))
+            if np.float32(p / np.float32(d2)) < thr:
+                audio[k] = 0.0
+    g = np.float32(10.0 ** (float(gain_db) / 20.0))
+    if g != np.float32(1.0):
+        audio = (audio * g).astype(np.float32)
+    return audio
+
+
 def u8_to_float(b):
     b = np.ascontiguousarray(b, dtype=np.uint8)
     out = np.empty(b.size, np.float32)

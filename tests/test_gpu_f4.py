@@ -1,0 +1,168 @@
+"""-m gpu: SURVEY 8f-4 inside the fused per-tuner path -- LowPass::_firLength as a run-time value
+(dsp/lowpass.cxx:38-39 FIXME), a second channel-filter stage (H4: a 12.5 kHz channel off a fast
+stream needs more than one 64-tap stage), and the two receiver controls the reference only stubs
+(af_gain, squelch: web/receiverhandler.cxx:112,118-119,127) -- against the oracle."""
+import numpy as np
+import pytest
+
+from webradio_amd import capi, synth
+from webradio_amd.device import Tuner
+
+pytestmark = pytest.mark.gpu
+MODE_NAMES = {capi.WR_AM: "AM", capi.WR_FM: "FM", capi.WR_USB: "USB", capi.WR_LSB: "LSB"}
+
+
+class OracleChain:
+    """A Receiver chain assembled from the oracle's blocks with explicit filter lengths:
+    mixer -> LowPass(L1, D1) [-> LowPass(L1b, D1b)] -> demodulator -> LowPass(L2, D2)."""
+
+    def __init__(self, oracle, fs, if_hz, l1, pb1, d1, mode, l2, pb2, d2, stage2=None):
+        self.o, self.mode = oracle, mode
+        self.table = oracle.sin_table()
+        self.step = oracle.phase_step(if_hz, fs)
+        self.phase = 0
+        self.prev = (0.0, 0.0)
+        self.f1 = oracle.Fir(2, d1, oracle.lowpass_design(pb1, fs, l1))
+        r = fs // d1
+        self.f1b = None
+        if stage2:
+            l1b, pb1b, d1b = stage2
+            self.f1b = oracle.Fir(2, d1b, oracle.lowpass_design(pb1b, r, l1b))
+            r //= d1b
+        self.f2 = oracle.Fir(1, d2, oracle.lowpass_design(pb2, r, l2))
+
+    def run(self, iq):
+        mixed, self.phase = self.o.mix(self.table, self.phase, self.step, iq)
+        c = self.f1.process(mixed)
+        if self.f1b is not None:
+            c = self.f1b.process(c)
+        d, self.prev = self.o.demod(self.mode, self.prev, c)
+        return self.f2.process(d), c, d
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+@pytest.mark.parametrize("lengths", [(32, 64), (16, 16), (64, 8), (32, 32)])
+def test_fir_length_inside_the_fused_path(dev, oracle, nco, lengths):
+    """Filters of 8..32 taps ride the fused kernels as 64-tap filters whose oldest taps are zero:
+    bit-identical to the oracle's `_n` filters in EXACT mode (channel IQ, AM audio), within the
+    usual tolerance under ROTATE.  Ragged blocks, 70 receivers (two lane groups)."""
+    l1, l2 = lengths
+    fs, d1, d2 = 2_000_000, 400, 5
+    ifs = [(-35 + c) * 6250 + 321 for c in range(70)]
+    probe = [0, 1, 33, 63, 64, 69]
+    # (a stream keeps one block size: the reference's LowPass loses its history when the size changes,
+    # lowpass.cxx:138-141, quirk Q7 -- the oracle's Fir does too, the product deliberately does not)
+    for n, blocks in ((40_000, 3), (2_000, 5), (48_000, 2)):
+        t = Tuner(dev, fs, 70, n, nco)
+        chans = [t.add_receiver(f, 128_000, fs // d1, capi.WR_AM, 800, fs // d1 // d2, fir_lengths=lengths) for f in ifs]
+        rxs = {c: OracleChain(oracle, fs, ifs[c], l1, 128_000, d1, oracle.AM, l2, 800, d2) for c in probe}
+        pos = 0
+        for _ in range(blocks):
+            iq = synth.fm_stream(n, fs, [ifs[c] for c in probe[::2]], start_frame=pos, amp=0.15, fm_base=30.0, beta=2.0)
+            pos += n
+            t.submit_host(iq)
+            for c in probe:
+                wa, wc, _ = rxs[c].run(iq)
+                gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)
+                ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
+                assert gc.size == wc.size and ga.size == wa.size
+                if nco == capi.WR_NCO_EXACT:
+                    assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, c)
+                    assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, c)
+                else:
+                    assert np.abs(gc - wc).max() <= 1e-6 and np.abs(ga - wa).max() <= 2e-6, (n, c)
+        t.destroy()
+    # what the fused path does not take is refused, not silently shortened
+    import ctypes as C
+    t = Tuner(dev, fs, 1, 1000, nco)
+    c = C.c_int()
+    capi.check(t.lib.wr_chan_add(t.h, C.byref(c)))
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 128, 128_000, 5_000) == capi.WR_ERR_ARG
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 48, 128_000, 5_000) == capi.WR_ERR_ARG
+    t.destroy()
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+def test_two_stage_channel_filter_through_the_tuner(dev, oracle, nco):
+    """a 12.5 kHz channel off a 5 Msps stream.  One 64-tap LowPass cannot do it
+    (64 * 12 500 / 5 M / 2 = bin 0, lowpass.cxx:167: all taps zero); the reference's own means is a
+    second LowPass in a row.  Here: DDC + first stage 5 M -> 250 k (D1 = 20), second channel stage
+    250 k -> 25 k (D = 10, passband 12.5 kHz -> bin 1), AM, audio filter 25 k -> 5 k -- all through
+    wr_tuner_submit, 66 receivers, against the oracle's cascade."""
+    fs = 5_000_000
+    assert oracle.lowpass_maxbin(12_500, fs) == 0 and oracle.lowpass_maxbin(12_500, 250_000) == 1
+    ifs = [(-33 + c) * 30_000 + 4321 for c in range(66)]
+    probe = [0, 31, 63, 64, 65]
+    live = 0.0
+    # one block size per stream (Q7, see above).  1 000 frames: 50 first-stage, 5 second-stage, 1 audio frame
+    for n, blocks in ((200_000, 2), (1_000, 8), (5_000, 4)):
+        t = Tuner(dev, fs, 66, n, nco)
+        chans = [t.add_receiver(f, 160_000, 250_000, capi.WR_AM, 4_000, 5_000, stage2=(64, 12_500, 25_000)) for f in ifs]
+        rxs = {c: OracleChain(oracle, fs, ifs[c], 64, 160_000, 20, oracle.AM, 64, 4_000, 5, stage2=(64, 12_500, 10))
+               for c in probe}
+        pos = 0
+        for _ in range(blocks):
+            t0 = (np.arange(n) + pos) / fs
+            iq = np.zeros(2 * n, np.float32)
+            for c in probe[::2]:                           # AM carriers with a 1 kHz tone
+                env = 0.05 * (1.0 + 0.5 * np.cos(2 * np.pi * 1000.0 * t0))
+                ph = 2 * np.pi * ((ifs[c] * t0) % 1.0)
+                iq[0::2] += (env * np.cos(ph)).astype(np.float32)
+                iq[1::2] += (env * np.sin(ph)).astype(np.float32)
+            pos += n
+            t.submit_host(iq)
+            for c in probe:
+                wa, wc, _ = rxs[c].run(iq)
+                gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)      # the demodulator's input: after stage 2
+                ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
+                assert gc.size == wc.size and ga.size == wa.size, (n, c)
+                if nco == capi.WR_NCO_EXACT:
+                    assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, c)
+                    assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, c)
+                else:
+                    assert np.abs(gc - wc).max() <= 1e-6 and np.abs(ga - wa).max() <= 2e-6, (n, c)
+            live = max(live, float(np.abs(t.fetch(chans[0], capi.WR_STAGE_AUDIO, n)).max()))
+        t.destroy()
+    assert live > 1e-3                                     # a live channel, not zeros
+
+
+@pytest.mark.parametrize("keep_demod", [False, True])
+def test_af_gain_and_squelch(dev, oracle, keep_demod):
+    """af_gain / squelch (named and left as FIXMEs by the reference, receiverhandler.cxx:112-127): the
+    build's definition (include/webradio_amd.h) against its scalar restatement, bit for bit, in the
+    fused post stage and in the two-kernel path; 0 dB and an open squelch change nothing."""
+    fs, d1, d2 = 2_000_000, 400, 5
+    ifs = [50_000, -75_000, 4321, 99_999]
+    t = Tuner(dev, fs, 4, 40_000, capi.WR_NCO_EXACT)
+    if keep_demod:
+        t.keep_stages(capi.WR_STAGE_DEMOD)
+    chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_AM, 160, 1_000) for f in ifs]
+    rxs = [oracle.Receiver(fs, f, 128_000, 5_000, oracle.AM, 160, 1_000) for f in ifs]
+    settings = [(0.0, None), (6.0, None), (-3.5, -46.0), (0.0, -46.0)]
+    pos = 0
+    for b in range(3):
+        if b == 1:                                         # staged, applied from this block on
+            for ch, (g, sq) in zip(chans, settings):
+                t.set_af_gain(ch, g)
+                t.set_squelch(ch, sq if sq is not None else 0.0, sq is not None)
+        # the carrier of receivers 2 and 3 fades in and out: the squelch opens and closes within a block
+        n = 40_000
+        tt = (np.arange(n) + pos) / fs
+        iq = (0.002 * np.random.default_rng(b).standard_normal(2 * n)).astype(np.float32)
+        for f in ifs:
+            env = 0.02 * (1.0 + np.sign(np.sin(2 * np.pi * 150.0 * tt))) * 0.5
+            ph = 2 * np.pi * ((f * tt) % 1.0)
+            iq[0::2] += (env * np.cos(ph)).astype(np.float32)
+            iq[1::2] += (env * np.sin(ph)).astype(np.float32)
+        pos += n
+        t.submit_host(iq)
+        for c, (ch, rx) in enumerate(zip(chans, rxs)):
+            wa, wc, _ = rx.run(iq)
+            g, sq = settings[c] if b >= 1 else (0.0, None)
+            want = oracle.af_gain_squelch(wa, wc, d2, g, sq)
+            got = t.fetch(ch, capi.WR_STAGE_AUDIO, n)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (b, c)
+            if sq is not None:
+                muted = np.count_nonzero(want == 0.0)
+                assert 0 < muted < want.size                # the gate really opens and closes
+    t.destroy()

@@ -59,7 +59,11 @@ SIGNATURES = {
     "wr_chan_set_if": (C.c_int, [_vp, C.c_int, C.c_int]),
     "wr_chan_set_filter": (C.c_int, [_vp, C.c_int, C.c_int, _u32, _u32]),
     "wr_chan_set_taps": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _u32]),
+    "wr_chan_set_filter_n": (C.c_int, [_vp, C.c_int, C.c_int, _u32, _u32, _u32]),
+    "wr_chan_set_taps_n": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _u32, _u32]),
     "wr_chan_set_mode": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "wr_chan_set_af_gain": (C.c_int, [_vp, C.c_int, C.c_float]),
+    "wr_chan_set_squelch": (C.c_int, [_vp, C.c_int, C.c_float, C.c_int]),
     "wr_tuner_keep_stages": (C.c_int, [_vp, _u32]),
     "wr_tuner_flush": (C.c_int, [_vp]),
     "wr_tuner_seek": (C.c_int, [_vp, C.c_ulonglong]),

@@ -69,9 +69,11 @@ struct Chan {
 	unsigned int stepL;        /* phaseStep << 1 */
 	unsigned int phaseL;       /* host mirror of DownConverter::phase << 1 */
 	int mode;
-	bool have[2];
-	float taps[2][WR_FIR_LENGTH];
-	unsigned int decim[2];
+	bool have[3];              /* [0] channel filter, [1] audio filter, [2] optional second channel filter */
+	float taps[3][WR_FIR_LENGTH];
+	unsigned int decim[3];
+	float gain;                /* af_gain as a factor (1 = 0 dB) */
+	float squelch;             /* squelch threshold as a power (0 = open) */
 	bool cs_hist_reset;        /* channel filter history (LO rows of this slot) must be zeroed */
 	int group;                 /* index into wr_tuner::groups, -1 while unconfigured */
 	int slot;
@@ -83,6 +85,9 @@ struct Chan {
 
 struct Group {
 	unsigned int d1, d2;
+	unsigned int d1b = 0;      /* decimation of the second channel-filter stage, 0 = there is none */
+	int p2 = 0;                /* which iq2_hist set the next block reads */
+	bool use_gain = false, use_squelch = false;
 	unsigned int slots;
 	size_t k1max, k2max;
 	WrGroupDev dev;
@@ -570,6 +575,13 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.rot);
 	(void)hipFree(g->dev.taps1u);
 	(void)hipFree(g->dev.tapsel);
+	(void)hipFree(g->dev.taps1b);
+	(void)hipFree(g->dev.iq2_hist[0]);
+	(void)hipFree(g->dev.iq2_hist[1]);
+	(void)hipFree(g->dev.chan_iq2[0]);
+	(void)hipFree(g->dev.chan_iq2[1]);
+	(void)hipFree(g->dev.gain);
+	(void)hipFree(g->dev.squelch);
 	(void)hipFree(g->dev.prev_iq[0]);
 	(void)hipFree(g->dev.prev_iq[1]);
 	(void)hipFree(g->dev.chan_iq[0]);
@@ -580,7 +592,7 @@ static void group_free(Group *g)
 	delete g;
 }
 
-static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **out)
+static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned int d2, Group **out)
 {
 	Group *g = new (std::nothrow) Group();
 	if (!g)
@@ -589,10 +601,11 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	g->parity = g->last_parity = 0;
 	g->sp = g->cb = g->last_cb = 0;
 	g->d1 = d1;
+	g->d1b = d1b;
 	g->d2 = d2;
 	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
-	g->k1max = t->max_block_frames / d1;
-	g->k2max = g->k1max / d2;
+	g->k1max = t->max_block_frames / d1;       /* first-stage frames; the later stages need no more */
+	g->k2max = g->k1max / (d1b ? d1b : 1u) / d2;
 	if (g->k2max == 0)
 		g->k2max = 1;
 	g->owner.assign(g->slots, -1);
@@ -616,6 +629,15 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d2, Group **o
 	if (!rc) rc = dev_alloc_zero(&g->dev.rot, S * 4);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S * WR_TAPSETS);
 	if (!rc) rc = dev_alloc_zero(&g->dev.tapsel, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.gain, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.squelch, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[0], (size_t)WR_HIST * S * 2);      /* wr_tuner_seek clears it */
+	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[1], (size_t)WR_HIST * S * 2);
+	if (d1b) {
+		if (!rc) rc = dev_alloc_zero(&g->dev.taps1b, S * WR_FIR_LENGTH);
+		if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq2[0], (g->k1max / d1b + 1) * S * 2);
+		if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq2[1], (g->k1max / d1b + 1) * S * 2);
+	}
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
@@ -735,6 +757,8 @@ extern "C" int wr_chan_add(wr_tuner *t, int *chan)
 	memset(&c, 0, sizeof(c));
 	c.in_use = true;
 	c.mode = WR_AM;                /* Demodulator ctor, demodulator.cxx:34 */
+	c.gain = 1.0f;                 /* what the reference reports: af_gain 0, squelch_threshold 0 (receiverhandler.cxx:118-119) */
+	c.squelch = 0.0f;
 	c.group = -1;
 	c.slot = -1;
 	*chan = idx;
@@ -800,7 +824,7 @@ static int chan_seat(wr_tuner *t, int idx)
 		return WR_OK;
 	if (c.group >= 0) {
 		Group *g = t->groups[c.group];
-		if (g->d1 == c.decim[0] && g->d2 == c.decim[1]) {
+		if (g->d1 == c.decim[0] && g->d2 == c.decim[1] && g->d1b == (c.have[2] ? c.decim[2] : 0u)) {
 			g->dirty = true;
 			return WR_OK;
 		}
@@ -810,7 +834,8 @@ static int chan_seat(wr_tuner *t, int idx)
 	}
 	int gi = -1;
 	for (size_t i = 0; i < t->groups.size(); ++i)
-		if (t->groups[i]->d1 == c.decim[0] && t->groups[i]->d2 == c.decim[1]) {
+		if (t->groups[i]->d1 == c.decim[0] && t->groups[i]->d2 == c.decim[1] &&
+		    t->groups[i]->d1b == (c.have[2] ? c.decim[2] : 0u)) {
 			gi = (int)i;
 			break;
 		}
@@ -818,7 +843,7 @@ static int chan_seat(wr_tuner *t, int idx)
 		if (dev_bind(t->dev))
 			return WR_ERR_HIP;
 		Group *g = nullptr;
-		int rc = group_create(t, c.decim[0], c.decim[1], &g);
+		int rc = group_create(t, c.decim[0], c.have[2] ? c.decim[2] : 0u, c.decim[1], &g);
 		if (rc)
 			return rc;
 		t->groups.push_back(g);
@@ -862,8 +887,8 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
 	Chan *c = chan_get(t, chan);
 	if (!c)
 		return fail(WR_ERR_ARG, "no channel %d", chan);
-	if (stage != 0 && stage != 1)
-		return fail(WR_ERR_ARG, "stage must be 0 (channel) or 1 (audio)");
+	if (stage < 0 || stage > 2)
+		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
 	if (!decim)
 		return fail(WR_ERR_ARG, "decimation must be >= 1");
 	memcpy(c->taps[stage], coeff, sizeof(float) * WR_FIR_LENGTH);
@@ -872,38 +897,71 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
 	return chan_seat(t, chan);
 }
 
-extern "C" int wr_chan_set_taps(wr_tuner *t, int chan, int stage, const float *coeff_host,
-                                unsigned int decimation)
+/* LowPass::_firLength as a run-time value in the fused path (lowpass.cxx:38-39 "FIXME: Make runtime
+ * variable"): a filter of L <= 64 taps IS the 64-tap filter whose taps L..63 -- the ones that meet
+ * the oldest samples -- are zero.  lowpass.cxx:150-158 adds the products oldest sample first, so the
+ * padded filter starts with 64 - L products that are +-0 and then runs through exactly the additions
+ * of the short one: the same bits (finite input). */
+static bool fused_fir_length_ok(unsigned int n)
+{
+	return n >= 2 && n <= WR_FIR_LENGTH && (n & (n - 1)) == 0;
+}
+
+extern "C" int wr_chan_set_taps_n(wr_tuner *t, int chan, int stage, const float *coeff_host,
+                                  unsigned int fir_length, unsigned int decimation)
 {
 	if (!t || !coeff_host)
 		return fail(WR_ERR_ARG, "wr_chan_set_taps: bad argument");
-	return set_taps_common(t, chan, stage, coeff_host, decimation);
+	if (!fused_fir_length_ok(fir_length))
+		return fail(WR_ERR_ARG, "wr_chan_set_taps_n: fir_length %u is not a power of two in [2, %d] (longer filters "
+		                        "run block by block: wr_fir_decimate_n)", fir_length, WR_FIR_LENGTH);
+	float coeff[WR_FIR_LENGTH] = {0.0f};
+	memcpy(coeff, coeff_host, sizeof(float) * fir_length);
+	return set_taps_common(t, chan, stage, coeff, decimation);
 }
 
-extern "C" int wr_chan_set_filter(wr_tuner *t, int chan, int stage, unsigned int passband,
-                                  unsigned int out_rate)
+extern "C" int wr_chan_set_taps(wr_tuner *t, int chan, int stage, const float *coeff_host,
+                                unsigned int decimation)
+{
+	return wr_chan_set_taps_n(t, chan, stage, coeff_host, WR_FIR_LENGTH, decimation);
+}
+
+extern "C" int wr_chan_set_filter_n(wr_tuner *t, int chan, int stage, unsigned int fir_length,
+                                    unsigned int passband, unsigned int out_rate)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
 		return fail(WR_ERR_ARG, "wr_chan_set_filter: no channel %d", chan);
-	if (stage != 0 && stage != 1)
-		return fail(WR_ERR_ARG, "stage must be 0 (channel) or 1 (audio)");
+	if (stage < 0 || stage > 2)
+		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
+	if (!fused_fir_length_ok(fir_length))
+		return fail(WR_ERR_ARG, "wr_chan_set_filter_n: fir_length %u is not a power of two in [2, %d]", fir_length,
+		            WR_FIR_LENGTH);
 	unsigned int in_rate;
 	if (stage == 0) {
 		in_rate = t->input_rate;
 	} else {
 		if (!c->have[0])
-			return fail(WR_ERR_STATE, "set the channel filter (stage 0) before the audio filter");
+			return fail(WR_ERR_STATE, "set the channel filter (stage 0) before the %s", stage == 1 ? "audio filter"
+			            : "second channel filter");
 		in_rate = t->input_rate / c->decim[0];
+		if (stage == 1 && c->have[2])
+			in_rate /= c->decim[2];               /* the audio filter follows the LAST channel stage */
 	}
 	if (!out_rate || out_rate > in_rate)
 		return fail(WR_ERR_RATE, "output rate %u not a decimation of %u", out_rate, in_rate);
 	unsigned int decim = in_rate / out_rate;           /* dspblock.cxx:119-121 */
 	if (in_rate / decim != out_rate || in_rate % out_rate)
 		return fail(WR_ERR_RATE, "Sample rates must be integer related (%u -> %u)", in_rate, out_rate);
-	float coeff[WR_FIR_LENGTH];
-	wrd_lowpass_design(WR_FIR_LENGTH, passband, in_rate, coeff);
+	float coeff[WR_FIR_LENGTH] = {0.0f};
+	wrd_lowpass_design(fir_length, passband, in_rate, coeff);
 	return set_taps_common(t, chan, stage, coeff, decim);
+}
+
+extern "C" int wr_chan_set_filter(wr_tuner *t, int chan, int stage, unsigned int passband,
+                                  unsigned int out_rate)
+{
+	return wr_chan_set_filter_n(t, chan, stage, WR_FIR_LENGTH, passband, out_rate);
 }
 
 extern "C" int wr_chan_set_mode(wr_tuner *t, int chan, int mode)
@@ -914,6 +972,35 @@ extern "C" int wr_chan_set_mode(wr_tuner *t, int chan, int mode)
 	if (mode < WR_AM || mode > WR_LSB)
 		return fail(WR_ERR_ARG, "wr_chan_set_mode: bad mode %d", mode);
 	c->mode = mode;
+	if (c->group >= 0)
+		t->groups[c->group]->dirty = true;
+	return WR_OK;
+}
+
+/* The two receiver controls the reference's REST interface names and never implements ("FIXME:
+ * af_gain, squelch", receiverhandler.cxx:112,127; both reported as 0, :118-119).  Staged like every
+ * other setter: they take effect at the next block boundary. */
+extern "C" int wr_chan_set_af_gain(wr_tuner *t, int chan, float gain_db)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_set_af_gain: no channel %d", chan);
+	if (!(gain_db == gain_db) || gain_db < -200.0f || gain_db > 200.0f)
+		return fail(WR_ERR_ARG, "wr_chan_set_af_gain: %g dB", (double)gain_db);
+	c->gain = (float)pow(10.0, (double)gain_db / 20.0);
+	if (c->group >= 0)
+		t->groups[c->group]->dirty = true;
+	return WR_OK;
+}
+
+extern "C" int wr_chan_set_squelch(wr_tuner *t, int chan, float threshold_dbfs, int enable)
+{
+	Chan *c = chan_get(t, chan);
+	if (!c)
+		return fail(WR_ERR_ARG, "wr_chan_set_squelch: no channel %d", chan);
+	if (enable && (!(threshold_dbfs == threshold_dbfs) || threshold_dbfs < -300.0f || threshold_dbfs > 100.0f))
+		return fail(WR_ERR_ARG, "wr_chan_set_squelch: %g dBFS", (double)threshold_dbfs);
+	c->squelch = enable ? (float)pow(10.0, (double)threshold_dbfs / 10.0) : 0.0f;
 	if (c->group >= 0)
 		t->groups[c->group]->dirty = true;
 	return WR_OK;
@@ -1021,6 +1108,8 @@ static int group_upload(wr_tuner *t, Group *g)
 	std::vector<unsigned int> step(S, 0);
 	std::vector<int> flags(S, 0), mode(S, -1);      /* mode < 0 marks an idle slot */
 	std::vector<float> taps1(S * WR_FIR_LENGTH, 0.0f), taps2(S * WR_FIR_LENGTH, 0.0f);
+	std::vector<float> taps1b(g->d1b ? S * WR_FIR_LENGTH : 0, 0.0f), gain(S, 1.0f), squelch(S, 0.0f);
+	g->use_gain = g->use_squelch = false;
 	for (size_t s = 0; s < S; ++s) {
 		int ci = g->owner[s];
 		if (ci < 0)
@@ -1032,7 +1121,13 @@ static int group_upload(wr_tuner *t, Group *g)
 		for (int j = 0; j < WR_FIR_LENGTH; ++j) {
 			taps1[(size_t)j * S + s] = c.taps[0][j];
 			taps2[(size_t)j * S + s] = c.taps[1][j];
+			if (g->d1b)
+				taps1b[(size_t)j * S + s] = c.taps[2][j];
 		}
+		gain[s] = c.gain;
+		squelch[s] = c.squelch;
+		g->use_gain = g->use_gain || c.gain != 1.0f;
+		g->use_squelch = g->use_squelch || c.squelch > 0.0f;
 	}
 	/* Receivers of a tuner nearly always share one channel filter (radio.cxx:78-79 sets the same
 	 * passband/rate for all), and when they do not (receiverhandler.cxx:130-137: every receiver has
@@ -1107,6 +1202,10 @@ static int group_upload(wr_tuner *t, Group *g)
 	HIP_TRY(hipMemcpyAsync(g->dev.rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1u, taps1u.data(), taps1u.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.tapsel, tapsel.data(), tapsel.size() * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.gain, gain.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.squelch, squelch.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
+	if (g->d1b)
+		HIP_TRY(hipMemcpyAsync(g->dev.taps1b, taps1b.data(), taps1b.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	for (size_t s = 0; s < S; ++s) {
 		int ci = g->owner[s];
 		if (ci < 0)
@@ -1129,6 +1228,8 @@ static int group_upload(wr_tuner *t, Group *g)
 			HIP_TRY(hipMemset2DAsync(g->dev.hist_cs[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
 			                         WR_HIST, st));
 			HIP_TRY(hipMemset2DAsync(g->dev.hist_lo[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
+			                         WR_HIST, st));
+			HIP_TRY(hipMemset2DAsync(g->dev.iq2_hist[g->p2] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
 			                         WR_HIST, st));
 			c.cs_hist_reset = false;
 		}
@@ -1261,6 +1362,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.fewsets_mask = g->fewsets_mask;
 		memcpy(L.nsets, g->nsets, sizeof(L.nsets));
 		L.audio_scale = t->audio_scale;
+		L.use_gain = g->use_gain ? 1 : 0;
+		L.use_squelch = g->use_squelch ? 1 : 0;
 		L.ev_start = L.ev_stop = nullptr;
 		if (prof_now) {
 			int rc = prof_drain(t, 64);
@@ -1289,15 +1392,27 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			if (rc)
 				return rc;
 		}
+		/* A second channel-filter stage sits between the DDC and the demodulator: its kernel runs
+		 * here, and everything after it works on ITS output (chan_iq2) at ITS rate. */
+		WrTunerLaunch Lp = L;
+		WrGroupDev Gp = g->dev;
+		if (g->d1b) {
+			HIP_TRY(wrk_tuner_iq2(st, g->dev, g->slots, L.slots_used, L.k1, g->d1b, g->cb, g->p2));
+			g->p2 ^= 1;
+			Lp.k1 = L.k1 / g->d1b;
+			Lp.k2 = Lp.k1 / g->d2;
+			Gp.chan_iq[0] = g->dev.chan_iq2[0];
+			Gp.chan_iq[1] = g->dev.chan_iq2[1];
+		}
 		/* demodulator output wanted (wr_tuner_keep_stages) or an unusual audio decimation: demod
 		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
 		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
-		const bool defer = !two_kernels && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE
+		const bool defer = !two_kernels && !g->d1b && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE
 		                   && (g->fewsets_mask & ((L.slots_used / 64 >= 64) ? ~0ull : ((1ull << (L.slots_used / 64)) - 1ull))) != 0;
 		if (two_kernels) {
-			HIP_TRY(wrk_tuner_demod(st, L, g->dev));
-			HIP_TRY(wrk_tuner_audio(st, L, g->dev));
+			HIP_TRY(wrk_tuner_demod(st, Lp, Gp));
+			HIP_TRY(wrk_tuner_audio(st, Lp, Gp));
 		} else if (defer) {
 			g->post_pending = true;
 			g->post_args = wrk_post_args(L, g->dev);
@@ -1305,10 +1420,10 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 			g->pend_k2 = L.k2;
 			g->pend_slots = L.slots_used;
 		} else {
-			HIP_TRY(wrk_tuner_post(st, L, g->dev));
+			HIP_TRY(wrk_tuner_post(st, Lp, Gp));
 		}
 		if (!defer) {
-			int rc = ring_push(t, g, seq, L.k2, L.slots_used);
+			int rc = ring_push(t, g, seq, Lp.k2, L.slots_used);
 			if (rc)
 				return rc;
 		}
@@ -1317,12 +1432,12 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		g->last_cb = g->cb;
 		g->sp ^= 1;                    /* the kernels wrote the other state set */
 		hist_written = true;           /* k_tuner_ddc stored the next input history */
-		if (L.k1) {
+		if (Lp.k1)
 			g->parity ^= 1;            /* k_tuner_demod filled the other prev_iq / dem history */
+		if (L.k1)
 			g->cb ^= 1;
-		}
-		g->last_k1 = L.k1;
-		g->last_k2 = L.k2;
+		g->last_k1 = Lp.k1;            /* frames at the demodulator's input */
+		g->last_k2 = Lp.k2;
 	}
 	if (!hist_written)
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
@@ -1386,8 +1501,8 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 		if (rc)
 			return rc;
 		if (stage == WR_STAGE_CHAN_IQ)
-			HIP_TRY(wrk_gather_rows(d->stream, g->dev.chan_iq[g->last_cb], g->last_k1, S * 2, (size_t)c->slot * 2, 2,
-			                        d->scratch));
+			HIP_TRY(wrk_gather_rows(d->stream, g->d1b ? g->dev.chan_iq2[g->last_cb] : g->dev.chan_iq[g->last_cb],
+			                        g->last_k1, S * 2, (size_t)c->slot * 2, 2, d->scratch));
 		else if (!g->last_demod_kept)
 			return fail(WR_ERR_STATE, "wr_chan_fetch: the demodulator output was not kept "
 			            "(call wr_tuner_keep_stages(tuner, 1u << WR_STAGE_DEMOD) before submitting)");
@@ -1681,7 +1796,7 @@ extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
 			c.prev_iq[0] = c.prev_iq[1] = 0.0f;
 		}
 		/* on the device from the step array itself: no host data in flight, nothing to wait for */
-		HIP_TRY(wrk_seek(st, g->dev, (unsigned int)S, g->sp, g->parity, frame));
+		HIP_TRY(wrk_seek(st, g->dev, (unsigned int)S, g->sp, g->parity, g->p2, frame));
 	}
 	for (Chan &c : t->chans)
 		if (c.in_use && c.group < 0) {

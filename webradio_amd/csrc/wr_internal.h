@@ -52,6 +52,14 @@ struct WrGroupDev {
 	                               there are at most WR_TAPSETS): taps1u[(g*WR_TAPSETS + q)*64 + j] =
 	                               coeff_q[63 - j], the tap of window sample j */
 	int          *tapsel;       /* [slots] which of its group's filters the slot's channel uses */
+	/* optional SECOND channel-filter stage between the DDC and the demodulator (one
+	 * 64-tap stage cannot cut a 12.5 kHz channel out of a 100 Msps stream, lowpass.cxx:167 gives bin 0) */
+	float        *taps1b;       /* [64][slots] its taps */
+	float        *iq2_hist[2];  /* [63][slots][2] its history: the last 63 first-stage frames; ping-pong */
+	float        *chan_iq2[2];  /* [k1max / d1b][slots][2] its output = the demodulator's input */
+	/* receiver controls the reference only stubs (receiverhandler.cxx:112,118-119,127) */
+	float        *gain;         /* [slots] af_gain as a factor (1 = 0 dB) */
+	float        *squelch;      /* [slots] squelch threshold as a power (0 = open) */
 	float        *prev_iq[2];   /* [slots][2] Demodulator::prev_i/prev_q, ping-pong by block parity */
 	float        *chan_iq[2];   /* [k1max][slots][2] channel-filter output, time major; double buffered so
 	                               that block b+1's DDC can run while block b is being demodulated */
@@ -75,6 +83,7 @@ struct WrTunerLaunch {
 	size_t       k2max;         /* channel stride of audio */
 	int          nco_mode;
 	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
+	int          use_gain, use_squelch;   /* some channel has an af_gain / a squelch threshold set */
 	unsigned long long uniform_mask;   /* bit g: all channels of lane group g share ONE channel filter */
 	unsigned long long fewsets_mask;   /* bit g: lane group g has at most WR_TAPSETS distinct channel filters */
 	unsigned char nsets[64];           /* distinct channel filters of lane group g (valid where fewsets_mask says) */
@@ -110,6 +119,9 @@ struct WrPostArgs {
 	float        scale;
 	unsigned int d2;
 	unsigned int groups;         /* lane groups in use */
+	const float *gain;           /* [slots] af_gain factors, or NULL: all 1 */
+	const float *squelch;        /* [slots] squelch thresholds (power of the demodulator's input, mean over the
+	                                d2 frames behind an audio frame), or NULL: all open */
 };
 /* `post` (optional): the post stage of the PREVIOUS block, run by extra workgroups of the same
  * launch beside this block's DDC (only taken up by the ROTATE / uniform-taps kernel; *post_taken
@@ -118,6 +130,10 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
                          int num_cus, const WrPostArgs *post = nullptr, bool *post_taken = nullptr);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
+/* second channel-filter stage: k1a first-stage frames of chan_iq[cb] -> k1a / d1b frames of chan_iq2[cb];
+ * history from iq2_hist[p2], next history into iq2_hist[p2 ^ 1] */
+hipError_t wrk_tuner_iq2(hipStream_t st, const WrGroupDev &G, unsigned int slots, unsigned int slots_used,
+                         size_t k1a, unsigned int d1b, int cb, int p2);
 hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G);
 hipError_t wrk_tuner_post(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
@@ -125,7 +141,7 @@ hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A);
 bool wrk_tuner_post_supported(unsigned int d2);
 hipError_t wrk_input_hist(hipStream_t st, const float *cur, const uint8_t *cur_u8, size_t nframes,
                           const float *hist, float *hist_next);
-hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int sp, int parity,
+hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int sp, int parity, int p2,
                     unsigned long long frame);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
                            size_t col_offset_floats, unsigned int width_floats, float *dst);

@@ -412,6 +412,37 @@ __device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, co
 #endif
 #define POST_B 4u
 #define POST_THREADS 512u
+/* What leaves the audio filter for the sink: af_gain and squelch (the reference has the two fields
+ * and no code behind them, receiverhandler.cxx:112,118-119,127), then the sink's scale.
+ *   af_gain : a factor applied in float;
+ *   squelch : the audio frame is muted (0.0f) when the mean power i*i + q*q of the d2 demodulator
+ *             input frames behind it (frames k*d2 .. k*d2 + d2 - 1, summed in that order, divided by
+ *             (float)d2) is below the threshold.
+ * Factors of exactly 1 and thresholds of exactly 0 leave the value untouched. */
+__device__ __forceinline__ float audio_out(float v, const float *__restrict__ gain, const float *__restrict__ squelch,
+                                           const float2 *__restrict__ chan_iq, unsigned int slots, unsigned int so,
+                                           size_t k, unsigned int d2, float scale)
+{
+	if (squelch) {
+		const float thr = squelch[so];
+		if (thr > 0.0f) {
+			float p = 0.0f;
+			for (unsigned int i = 0; i < d2; ++i) {
+				const float2 z = chan_iq[(k * d2 + i) * slots + so];
+				p = p + (z.x * z.x + z.y * z.y);
+			}
+			if (p / (float)d2 < thr)
+				v = 0.0f;
+		}
+	}
+	if (gain) {
+		const float gn = gain[so];
+		if (gn != 1.0f)
+			v = v * gn;
+	}
+	return (scale == 1.0f) ? v : v * scale;
+}
+
 __device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
                                           unsigned int s, int m, const float2 *__restrict__ prev_iq,
                                           const float *__restrict__ dem_hist, size_t rr)
@@ -543,7 +574,8 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 		const unsigned int so = g * 64u + sl;
 		const size_t k = kbase + kk;
 		if (k < A.k2 && A.mode[so] >= 0)
-			A.audio[(size_t)so * A.k2max + k] = (A.scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * A.scale;
+			A.audio[(size_t)so * A.k2max + k] = audio_out(tile[kk * 65u + sl], A.gain, A.squelch, chan_iq, slots, so, k, D2,
+			                                              A.scale);
 	}
 }
 
@@ -1092,7 +1124,8 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 __global__ void __launch_bounds__(AUD_THREADS)
 k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsigned int d2,
               unsigned int tk, unsigned int slots, const float *__restrict__ taps2,
-              const int *__restrict__ mode, float *__restrict__ audio, size_t k2max, float scale)
+              const int *__restrict__ mode, float *__restrict__ audio, size_t k2max, float scale,
+              const float *__restrict__ gain, const float *__restrict__ squelch, const float2 *__restrict__ chan_iq)
 {
 	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [64][64] taps, [AUD_TMAX][65] out */
 	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
@@ -1129,8 +1162,58 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 		const unsigned int so = g * 64u + sl;
 		const size_t k = kbase + kk;
 		if (k < k2 && mode[so] >= 0)
-			audio[(size_t)so * k2max + k] = (scale == 1.0f) ? tile[kk * 65u + sl] : tile[kk * 65u + sl] * scale;
+			audio[(size_t)so * k2max + k] = audio_out(tile[kk * 65u + sl], gain, squelch, chan_iq, slots, so, k, d2, scale);
 	}
+}
+
+/* A second channel LowPass::process (dsp/lowpass.cxx:131-162, 2 channels) on the channel-rate IQ of
+ * every receiver, between the DDC and the demodulator: out[k][s] = sum_j coeff[63 - j] * X[k*D + j][s]
+ * over X = [63 history rows | the block's k1a first-stage rows], products added oldest row first,
+ * unfused, I and Q apart (lowpass.cxx:150-158 walks the channels innermost).  Thread = (slot, output
+ * frame); a wave reads whole 512-byte rows.  blockIdx.x == tiles: the next history (last 63 rows). */
+#define IQ2_TK 8u
+__global__ void __launch_bounds__(512)
+k_tuner_iq2(const float2 *__restrict__ in, size_t k1a, unsigned int d1b, unsigned int slots,
+            const float *__restrict__ taps, const int *__restrict__ mode,
+            const float2 *__restrict__ hist, float2 *__restrict__ hist_next, float2 *__restrict__ out, unsigned int tiles)
+{
+	const unsigned int lane = threadIdx.x & 63u, row = threadIdx.x >> 6;
+	const unsigned int s = blockIdx.y * 64u + lane;
+	const int m = mode[s];
+	auto xrow = [&](size_t r) -> float2 {              /* row r of [history | block] */
+		return (r < WR_HIST) ? hist[r * slots + s] : in[(r - WR_HIST) * slots + s];
+	};
+	if (blockIdx.x == tiles) {
+		if (m >= 0)
+			for (unsigned int r = row; r < WR_HIST; r += 8u)
+				hist_next[(size_t)r * slots + s] = xrow(k1a + r);
+		return;
+	}
+	const size_t k = (size_t)blockIdx.x * IQ2_TK + row;
+	if (m < 0 || k >= k1a / d1b)
+		return;
+	float ai = 0.0f, aq = 0.0f;
+#pragma unroll 8
+	for (int j = 0; j < WR_FIR_LENGTH; ++j) {
+		const float c = taps[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
+		const float2 x = xrow(k * d1b + j);
+		ai = ai + c * x.x;
+		aq = aq + c * x.y;
+	}
+	out[k * slots + s] = make_float2(ai, aq);
+}
+
+hipError_t wrk_tuner_iq2(hipStream_t st, const WrGroupDev &G, unsigned int slots, unsigned int slots_used,
+                         size_t k1a, unsigned int d1b, int cb, int p2)
+{
+	if (!slots_used || !d1b)
+		return hipSuccess;
+	const unsigned int tiles = (unsigned int)((k1a / d1b + IQ2_TK - 1) / IQ2_TK);
+	dim3 grid(tiles + 1u, slots_used / 64);
+	k_tuner_iq2<<<grid, 512, 0, st>>>((const float2 *)G.chan_iq[cb], k1a, d1b, slots, G.taps1b, G.mode,
+	                                  (const float2 *)G.iq2_hist[p2], (float2 *)G.iq2_hist[p2 ^ 1],
+	                                  (float2 *)G.chan_iq2[cb], tiles);
+	return hipGetLastError();
 }
 
 /* strided row gather: dst[r*width + i] = src[r*row_stride + col_offset + i] */
@@ -1450,6 +1533,8 @@ WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G)
 	A.scale = L.audio_scale;
 	A.d2 = L.d2;
 	A.groups = L.slots_used / 64;
+	A.gain = L.use_gain ? G.gain : nullptr;
+	A.squelch = L.use_squelch ? G.squelch : nullptr;
 	return A;
 }
 
@@ -1509,7 +1594,9 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	}
 	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
 	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
-	                                      G.taps2, G.mode, G.audio, L.k2max, L.audio_scale);
+	                                      G.taps2, G.mode, G.audio, L.k2max, L.audio_scale,
+	                                      L.use_gain ? G.gain : nullptr, L.use_squelch ? G.squelch : nullptr,
+	                                      (const float2 *)G.chan_iq[L.cb]);
 	return hipGetLastError();
 }
 
@@ -1519,7 +1606,7 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 __global__ void __launch_bounds__(256)
 k_seek(unsigned int *__restrict__ phase, const unsigned int *__restrict__ step, unsigned long long frame,
        float2 *__restrict__ hist_cs, float2 *__restrict__ hist_lo, float2 *__restrict__ prev_iq,
-       float *__restrict__ dem_hist, unsigned int slots)
+       float *__restrict__ dem_hist, float2 *__restrict__ iq2_hist, unsigned int slots)
 {
 	const unsigned int gsz = gridDim.x * blockDim.x;
 	const unsigned int rows = WR_HIST * slots;
@@ -1527,6 +1614,7 @@ k_seek(unsigned int *__restrict__ phase, const unsigned int *__restrict__ step, 
 		hist_cs[e] = make_float2(0.0f, 0.0f);
 		hist_lo[e] = make_float2(0.0f, 0.0f);
 		dem_hist[e] = 0.0f;
+		iq2_hist[e] = make_float2(0.0f, 0.0f);
 		if (e < slots) {
 			phase[e] = (unsigned int)((unsigned long long)step[e] * frame);
 			prev_iq[e] = make_float2(0.0f, 0.0f);
@@ -1534,11 +1622,13 @@ k_seek(unsigned int *__restrict__ phase, const unsigned int *__restrict__ step, 
 	}
 }
 
-hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int sp, int parity, unsigned long long frame)
+hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int sp, int parity, int p2,
+                    unsigned long long frame)
 {
 	const unsigned int rows = WR_HIST * slots;
 	k_seek<<<(rows + 255u) / 256u, 256, 0, st>>>(G.phase[sp], G.step, frame, (float2 *)G.hist_cs[sp],
-	                                             (float2 *)G.hist_lo[sp], (float2 *)G.prev_iq[parity], G.dem[parity], slots);
+	                                             (float2 *)G.hist_lo[sp], (float2 *)G.prev_iq[parity], G.dem[parity],
+	                                             (float2 *)G.iq2_hist[p2], slots);
 	return hipGetLastError();
 }
 

@@ -106,14 +106,20 @@ class Tuner:
             self.lib.wr_tuner_destroy(self.h)
             self.h = None
 
-    def add_receiver(self, if_hz, chan_passband, chan_rate, mode, audio_passband, audio_rate):
-        """Receiver() + setFrontEnd(): the wiring of radio.cxx:62-90 with explicit parameters."""
+    def add_receiver(self, if_hz, chan_passband, chan_rate, mode, audio_passband, audio_rate, fir_lengths=None,
+                     stage2=None):
+        """Receiver() + setFrontEnd(): the wiring of radio.cxx:62-90 with explicit parameters.
+        fir_lengths: (channel, audio) LowPass::_firLength, powers of two up to 64 (default 64, 64).
+        stage2: (fir_length, passband, out_rate) of a second channel LowPass in front of the demodulator."""
         c = C.c_int()
         check(self.lib.wr_chan_add(self.h, C.byref(c)))
         ch = c.value
         check(self.lib.wr_chan_set_if(self.h, ch, if_hz))
-        check(self.lib.wr_chan_set_filter(self.h, ch, 0, chan_passband, chan_rate))
-        check(self.lib.wr_chan_set_filter(self.h, ch, 1, audio_passband, audio_rate))
+        l1, l2 = fir_lengths if fir_lengths else (capi.WR_FIR_LENGTH, capi.WR_FIR_LENGTH)
+        check(self.lib.wr_chan_set_filter_n(self.h, ch, 0, l1, chan_passband, chan_rate))
+        if stage2:
+            check(self.lib.wr_chan_set_filter_n(self.h, ch, 2, stage2[0], stage2[1], stage2[2]))
+        check(self.lib.wr_chan_set_filter_n(self.h, ch, 1, l2, audio_passband, audio_rate))
         check(self.lib.wr_chan_set_mode(self.h, ch, mode))
         return ch
 
@@ -173,6 +179,12 @@ class Tuner:
 
     def set_if(self, ch, if_hz):
         check(self.lib.wr_chan_set_if(self.h, ch, if_hz))
+
+    def set_af_gain(self, ch, gain_db):
+        check(self.lib.wr_chan_set_af_gain(self.h, ch, C.c_float(gain_db)))
+
+    def set_squelch(self, ch, threshold_dbfs, enable=True):
+        check(self.lib.wr_chan_set_squelch(self.h, ch, C.c_float(threshold_dbfs), 1 if enable else 0))
 
     def set_mode(self, ch, mode):
         check(self.lib.wr_chan_set_mode(self.h, ch, mode))

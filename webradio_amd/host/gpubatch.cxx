@@ -300,8 +300,9 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 		return NULL;
 	if (f1->_channel || dm->_channel || f2->_channel)
 		return NULL;
-	if (f1->firLength() != WR_FIR_LENGTH || f2->firLength() != WR_FIR_LENGTH)
-		return NULL;                         /* the fused kernels are built for the reference's 64 taps */
+	if (f1->firLength() > WR_FIR_LENGTH || f2->firLength() > WR_FIR_LENGTH)
+		return NULL;                         /* the fused kernels take up to the reference's 64 taps (shorter
+		                                        filters ride as 64 taps with the oldest ones zero) */
 
 	TunerBatch *batch = src->batch();
 	if (!batch) {
@@ -429,8 +430,9 @@ bool TunerBatch::pushParams(Channel *ch)
 			std::lock_guard<std::mutex> g(fs[stage]->_coeffLock);      /* see LowPass::recalculate */
 			taps = fs[stage]->_coeff;
 		}
-		if (taps.size() == WR_FIR_LENGTH &&
-		    wr_chan_set_taps(_tuner, ch->id, stage, taps.data(), fs[stage]->decimation()) != WR_OK)
+		if (!taps.empty() && taps.size() <= WR_FIR_LENGTH &&
+		    wr_chan_set_taps_n(_tuner, ch->id, stage, taps.data(), (unsigned int)taps.size(),
+		                       fs[stage]->decimation()) != WR_OK)
 			return false;
 	}
 	if (wr_chan_set_mode(_tuner, ch->id, (int)ch->demod->_mode) != WR_OK)
