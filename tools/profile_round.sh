@@ -1,9 +1,9 @@
 #!/bin/bash
 # Produces the rocprof evidence for bench.py's roofline numbers (run on the GPU box via gpurun):
-#   gpurun_out/<round>_bench.json            the bench line
+#   gpurun_out/<round>_bench.json            the bench line (C2 headline + secondary.c3 + cpu_baseline)
 #   gpurun_out/<round>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/<round>_pmc_fetch.txt / _pmc_write.txt   FETCH_SIZE / WRITE_SIZE (separate passes)
-round=${1:-r01}
+#   gpurun_out/<round>_pmc_fetch_size.txt / _pmc_write_size.txt   FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
+round=${1:-r02}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R && python bench.py > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err
@@ -24,12 +24,12 @@ with open(R + '/gpurun_out/%s_kernel_stats.csv' % r, 'w') as f:
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
   python3 - "$c" "$round" <<'PY'
 import csv, sys, glob, collections, os
 c, r = sys.argv[1], sys.argv[2]; R = os.environ['GRAFT_REPO_ROOT']
 acc = collections.defaultdict(list)
-for f in glob.glob('/tmp/pmc_%s/*counter_collection.csv' % c):
+for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0][:60]
         if k.startswith(('k_', 'void k_')):
@@ -39,4 +39,4 @@ with open(R + '/gpurun_out/%s_pmc_%s.txt' % (r, c.lower()), 'w') as out:
         out.write('%s %s mean=%.1f KB per launch (n=%d)\n' % (k, c, sum(v) / len(v), len(v)))
 PY
 done
-cat $R/gpurun_out/${round}_bench.json; grep -E "k_tuner" $R/gpurun_out/${round}_kernel_stats.csv; cat $R/gpurun_out/${round}_pmc_*.txt
+cat $R/gpurun_out/${round}_bench.json | cut -c1-600; grep -E "k_tuner|k_fft" $R/gpurun_out/${round}_kernel_stats.csv; cat $R/gpurun_out/${round}_pmc_*.txt
