@@ -13,7 +13,10 @@ which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["split", "exact"]
 ifs = synth.c2_ifs(nch)
 stream = torch.cuda.current_stream().cuda_stream
 dev = Device(0, stream)
-x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
+nb = int(os.environ.get("QT_BLOCKS", "1"))        # 12: cycle through more input than the Infinity Cache holds, as bench.py does
+xs = synth.fm_stream_torch(n * nb, fs, ifs[::4], "cuda")
+blocks = [xs[2 * n * b: 2 * n * (b + 1)] for b in range(nb)]
+x = blocks[0]
 torch.cuda.synchronize()
 for name in which:
     t = Tuner(dev, fs, nch, n, modes[name])
@@ -25,15 +28,15 @@ for name in which:
         t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0) + (3_000_000 if odd else 0),
                        c2["chan_rate"], capi.WR_FM,
                        c2["audio_passband"], c2["audio_rate"])
-    for _ in range(4):
-        t.submit_device(x, n)
+    for i in range(4):
+        t.submit_device(blocks[i % nb], n)
     torch.cuda.synchronize()
     reps = 3 if name == "exact" else 20
     t.profile(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        t.submit_device(x, n)
+    for i in range(reps):
+        t.submit_device(blocks[i % nb], n)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

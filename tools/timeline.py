@@ -24,6 +24,11 @@ rc = lib.wr_debug_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 tl = buf.reshape(NW, SL).astype(np.int64)
 used = tl[:, 0] > 0
 tl = tl[used]
+# only the waves of the LAST launch (stamps of earlier launches with more waves linger)
+nlast = int(os.environ.get("TL_WAVES", "0"))
+if nlast:
+    tl = tl[:nlast]
+nA = int(os.environ.get("TL_A_WAVES", "0"))
 t0 = tl[:, 0].min()
 print("rc", rc, "waves stamped", tl.shape[0])
 def stat(name, v):
@@ -39,5 +44,9 @@ for u in range(8):
         stat("unit %d (%d waves)" % (u, ok.sum()), (a - b)[ok])
 stat("wave end - first start", tl[:, 11] - t0)
 stat("wave life", tl[:, 11] - tl[:, 0])
+if nA:
+    stat("wave life, post-tile workgroups", (tl[:, 11] - tl[:, 0])[:nA])
+    stat("wave life, the others", (tl[:, 11] - tl[:, 0])[nA:])
+    stat("prologue, post-tile workgroups", (tl[:, 1] - tl[:, 0])[:nA])
 print("kernel span (ticks): %d" % (tl[:, 11].max() - t0))
 t.destroy()

@@ -727,6 +727,12 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	/* the window of the NEXT unit is fetched while this one is computed: its global-load
 	 * latency would otherwise sit in front of every unit */
 	float2 xnext = make_float2(0.0f, 0.0f);
+#ifndef DDC_PREFETCH1
+#define DDC_PREFETCH2 1                                 /* measured at C2: 38.1 -> 37.5 us */
+#endif
+#ifdef DDC_PREFETCH2
+	float2 xnext2 = make_float2(0.0f, 0.0f);         /* the unit after the next: an HBM + TLB miss can outlast a unit */
+#endif
 	const unsigned int s = g * 64u + lane;
 	if (k < k1u) {
 		{
@@ -753,6 +759,10 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			}
 		}
 		xnext = window_sample(k);
+#ifdef DDC_PREFETCH2
+		if (k + wpg < k1u)
+			xnext2 = window_sample(k + wpg);
+#endif
 	}
 
 	TL(2);                                                   /* per-channel state loaded (issued) */
@@ -794,8 +804,14 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 			for (int q = 0; q < ROT_Q; ++q)
 				csq[q] = nco<NCO>(P0 + (unsigned int)(q * ROT_SEG + ROT_SEG - 1) * st, table, hi_l, lo_l);
 		}
+#ifdef DDC_PREFETCH2
+		xnext = xnext2;
+		if (kn + wpg < k1u)
+			xnext2 = window_sample(kn + wpg);
+#else
 		if (kn < k1u)
 			xnext = window_sample(kn);
+#endif
 		/* (per lane: lanes of channels with different filters read different copies of the window) */
 		const v2f *wbase = win + (buf * nset + mysel) * 64u;
 		const lds_v2f *w = (const lds_v2f *)wbase;
