@@ -166,3 +166,61 @@ def test_af_gain_and_squelch(dev, oracle, keep_demod):
                 muted = np.count_nonzero(want == 0.0)
                 assert 0 < muted < want.size                # the gate really opens and closes
     t.destroy()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_f4_configurations(dev, oracle, seed):
+    """Seeded mixtures of everything above in one tuner: filter lengths per receiver, receivers with
+    and without a second channel stage (two rate groups), af_gain and squelch on some, detectors
+    mixed, passbands mixed (tap sets), one block size per stream -- every receiver against the
+    oracle's cascade; AM/USB/LSB bit for bit in EXACT mode."""
+    rng = np.random.default_rng(4000 + seed)
+    nco = (capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE)[seed % 2]
+    fs, d1, d1b, d2 = 2_000_000, 40, 10, 5                   # 2 M -> 50 k [-> 5 k] -> /5
+    n = int(rng.choice([d1 * d1b * d2 * 4, d1 * d1b * d2 * 9, 40_000]))
+    nchan = int(rng.choice([3, 20, 70]))
+    modes = [capi.WR_AM, capi.WR_USB, capi.WR_LSB]
+    t = Tuner(dev, fs, nchan, n, nco)
+    specs, chans, rxs = [], [], []
+    for c in range(nchan):
+        f = int(rng.integers(-fs // 2 + 1, fs // 2))
+        l1, l2 = int(rng.choice([8, 16, 32, 64])), int(rng.choice([16, 64]))
+        pb1 = int(rng.choice([fs // 16, fs // 8, fs // 5]))
+        two = bool(rng.integers(0, 2))
+        mode = modes[int(rng.integers(0, 3))]
+        r_in = fs // d1 // (d1b if two else 1)                # the demodulator's input rate
+        pb2 = r_in // 8
+        st2 = (int(rng.choice([32, 64])), (fs // d1) // 8, fs // d1 // d1b) if two else None
+        gain = float(rng.choice([0.0, 0.0, 6.0, -12.5]))
+        sq = float(rng.choice([-60.0, -35.0])) if rng.integers(0, 3) == 0 else None
+        specs.append((f, two, gain, sq))
+        chans.append(t.add_receiver(f, pb1, fs // d1, mode, pb2, r_in // d2, fir_lengths=(l1, l2), stage2=st2))
+        rxs.append(OracleChain(oracle, fs, f, l1, pb1, d1, mode, l2, pb2, d2,
+                               stage2=(st2[0], st2[1], d1b) if two else None))
+        t.set_af_gain(chans[c], gain)
+        t.set_squelch(chans[c], sq if sq is not None else 0.0, sq is not None)
+    carriers = [specs[c][0] for c in range(0, nchan, max(1, nchan // 3))][:3]
+    pos = 0
+    for b in range(3):
+        iq = synth.fm_stream(n, fs, carriers, start_frame=pos, amp=0.2, fm_base=40.0, beta=1.5, seed=seed)
+        pos += n
+        t.submit_host(iq)
+        for c in range(nchan):
+            wa, wc, _ = rxs[c].run(iq)
+            want = oracle.af_gain_squelch(wa, wc, d2, specs[c][2], specs[c][3])
+            gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)
+            ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
+            assert gc.size == wc.size and ga.size == want.size, (seed, b, c)
+            if nco == capi.WR_NCO_EXACT:
+                assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (seed, b, c)
+                assert np.array_equal(ga.view(np.uint32), want.view(np.uint32)), (seed, b, c)
+            else:
+                assert np.abs(gc - wc).max() <= 1e-6, (seed, b, c)
+                g = 10.0 ** (specs[c][2] / 20.0)
+                # a squelch decision may differ where the power sits within 1e-6 of the threshold
+                differ = np.abs(ga - want) > 4e-6 * max(1.0, g)
+                if specs[c][3] is None:
+                    assert not differ.any(), (seed, b, c)
+                else:
+                    assert differ.sum() <= 2, (seed, b, c)
+    t.destroy()
