@@ -412,6 +412,12 @@ long wr_host_run_multistage(const float *iq, size_t nframes, unsigned int rate, 
 	return rc;
 }
 
+/* events the tuner batches have traced so far (WEBRADIO_TRACE=1): non-zero = a chain was fused */
+int wr_host_trace_count(void)
+{
+	return (int)wrhost::trace().size();
+}
+
 int wr_host_registry_sizes(void)
 {
 	return (int)(Radio::frontEnds().size() * 1000 + Radio::receivers().size());

@@ -399,7 +399,7 @@ audio = np.zeros(1 << 16, np.float32)
 n = L.wr_host_run_multistage(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), int(p[2]), int(p[3]), rates.size,
                              rates.ctypes.data_as(up), pbs.ctypes.data_as(up), int(p[4]), int(p[5]),
                              audio.ctypes.data_as(fp), audio.size)
-np.savez(out, n=n, audio=audio[:max(n, 0)])
+np.savez(out, n=n, audio=audio[:max(n, 0)], traced=L.wr_host_trace_count())
 '''
 
 
@@ -450,3 +450,48 @@ def test_multistage_decimation_chain_on_device(tmp_path, oracle):
     spec = np.abs(np.fft.rfft(tail * np.hanning(tail.size)))
     spec[:3] = 0.0                                                    # what is left of the carrier's DC term
     assert abs(np.argmax(spec) * arate / tail.size - 1_000) < 2 * arate / tail.size
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_two_lowpass_stages_in_a_row_ride_the_tuner_batch(tmp_path, oracle, fused):
+    """DownConverter -> LowPass -> LowPass -> Demodulator -> LowPass (a 12.5 kHz channel off 5 Msps:
+    5 M -> 250 k -> 25 k -> AM -> 5 k) built with nothing but connect(): the five blocks enrol as one
+    channel of the source's tuner batch, the second LowPass as the batch's second channel-filter
+    stage (WEBRADIO_TRACE shows the batch submitting); with WEBRADIO_NO_FUSION=1 every block runs its
+    own kernel.  Either way the audio is the oracle cascade's, bit for bit (EXACT NCO)."""
+    fs, block, f_if = 5_000_000, 200_000, 1_234_500
+    rates, pbs = [250_000, 25_000], [160_000, 12_500]
+    apb, arate, mode = 4_000, 5_000, 0
+    assert oracle.lowpass_maxbin(12_500, fs) == 0
+    n = 3 * block
+    t = np.arange(n) / fs
+    am = 1.0 + 0.5 * np.sin(2 * np.pi * 400 * t)
+    rng = np.random.default_rng(5)
+    sig = 0.3 * am * np.exp(2j * np.pi * f_if * t) + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.float32)
+    iq[0::2], iq[1::2] = sig.real, sig.imag
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(inp, iq=iq, params=np.array([fs, block, f_if, mode, apb, arate], np.int64), rates=np.array(rates), pbs=np.array(pbs))
+    env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1")
+    if not fused:
+        env["WEBRADIO_NO_FUSION"] = "1"
+    subprocess.check_call([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=env, timeout=300)
+    r = np.load(out)
+    assert (int(r["traced"]) > 0) == bool(fused)
+    table = oracle.sin_table()
+    firs, rate_in = [], fs
+    for ro, pb in zip(rates, pbs):
+        firs.append(oracle.Fir(2, rate_in // ro, oracle.lowpass_design(pb, rate_in)))
+        rate_in = ro
+    fa = oracle.Fir(1, rate_in // arate, oracle.lowpass_design(apb, rate_in))
+    phase, prev, want = 0, (0.0, 0.0), []
+    for b in range(3):
+        x, phase = oracle.mix(table, phase, oracle.phase_step(f_if, fs), iq[2 * b * block: 2 * (b + 1) * block])
+        for f in firs:
+            x = f.process(x)
+        d, prev = oracle.demod(mode, prev, x)
+        want.append(fa.process(d))
+    want = np.concatenate(want)
+    assert int(r["n"]) == want.size
+    assert np.array_equal(r["audio"].view(np.uint32), want.view(np.uint32))

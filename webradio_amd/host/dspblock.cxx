@@ -13,6 +13,12 @@
  *   stop       :153-167 consumers first, then deinit(), then drop the output buffer
  *   run        :169-212 size the output for in*interp/decim frames (truncating),
  *                       time process(), push the result to each consumer in order
+ *
+ * Attribution: connect/disconnect/start/stop/run follow mikestir/webradio's src/dsp/dspblock.cxx
+ * (Copyright (C) Mike Stirling, AGPL-3.0) step for step, log lines included -- trace-identical
+ * scheduling IS the contract of this row.  What is this backend's own: runFrames
+ * and output elision, the device hand-over between blocks, the sampled profiler clock, the kept
+ * pump vector and the GPU hooks of DspSource.
  */
 #include <algorithm>
 #include <inttypes.h>

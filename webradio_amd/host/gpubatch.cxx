@@ -292,15 +292,21 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	LowPass *f1 = dynamic_cast<LowPass *>(mixer->_consumers[0]);
 	if (!f1 || f1->_consumers.size() != 1)
 		return NULL;
-	Demodulator *dm = dynamic_cast<Demodulator *>(f1->_consumers[0]);
+	/* optionally a second LowPass before the demodulator: how the reference's own means cut a narrow
+	 * channel out of a fast stream (one 64-tap stage gives bin 0 below fs/128, lowpass.cxx:167) */
+	LowPass *f1b = dynamic_cast<LowPass *>(f1->_consumers[0]);
+	if (f1b && f1b->_consumers.size() != 1)
+		return NULL;
+	Demodulator *dm = dynamic_cast<Demodulator *>(f1b ? f1b->_consumers[0] : f1->_consumers[0]);
 	if (!dm || dm->_consumers.size() != 1)
 		return NULL;
 	LowPass *f2 = dynamic_cast<LowPass *>(dm->_consumers[0]);
 	if (!f2)
 		return NULL;
-	if (f1->_channel || dm->_channel || f2->_channel)
+	if (f1->_channel || dm->_channel || f2->_channel || (f1b && f1b->_channel))
 		return NULL;
-	if (f1->firLength() > WR_FIR_LENGTH || f2->firLength() > WR_FIR_LENGTH)
+	if (f1->firLength() > WR_FIR_LENGTH || f2->firLength() > WR_FIR_LENGTH ||
+	    (f1b && f1b->firLength() > WR_FIR_LENGTH))
 		return NULL;                         /* the fused kernels take up to the reference's 64 taps (shorter
 		                                        filters ride as 64 taps with the oldest ones zero) */
 
@@ -365,6 +371,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	ch->slot = -1;
 	ch->mixer = mixer;
 	ch->chanFilter = f1;
+	ch->chanFilter2 = f1b;
 	ch->demod = dm;
 	ch->audioFilter = f2;
 	ch->dirty = true;
@@ -374,6 +381,11 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	mixer->_channel = f1->_channel = dm->_channel = f2->_channel = ch;
 	f1->_stage = 0;
 	f2->_stage = 1;
+	if (f1b) {
+		f1b->_channel = ch;
+		f1b->_stage = 2;
+		f1b->elideOutput(true);
+	}
 	/* nobody reads these three on the host any more */
 	mixer->elideOutput(true);
 	f1->elideOutput(true);
@@ -397,6 +409,10 @@ void TunerBatch::withdraw(Channel *ch)
 			}
 	}
 	ch->mixer->_channel = NULL;
+	if (ch->chanFilter2) {
+		ch->chanFilter2->_channel = NULL;
+		ch->chanFilter2->elideOutput(false);
+	}
 	ch->chanFilter->_channel = NULL;
 	ch->demod->_channel = NULL;
 	ch->audioFilter->_channel = NULL;
@@ -419,20 +435,24 @@ void TunerBatch::markDirty(Channel *ch)
 bool TunerBatch::pushParams(Channel *ch)
 {
 	LowPass *f1 = ch->chanFilter, *f2 = ch->audioFilter;
-	if (!f1->isRunning() || !f2->isRunning() || !ch->demod->isRunning())
+	if (!f1->isRunning() || !f2->isRunning() || !ch->demod->isRunning() ||
+	    (ch->chanFilter2 && !ch->chanFilter2->isRunning()))
 		return true;                    /* the chain is still starting: next block */
 	if (wr_chan_set_if(_tuner, ch->id, ch->mixer->_ifHz) != WR_OK)
 		return false;
-	LowPass *fs[2] = {f1, f2};
-	for (int stage = 0; stage < 2; stage++) {
+	LowPass *fs[3] = {f1, ch->chanFilter2, f2};
+	const int stages[3] = {WR_FILTER_CHANNEL, WR_FILTER_CHANNEL2, WR_FILTER_AUDIO};
+	for (int n = 0; n < 3; n++) {
+		if (!fs[n])
+			continue;
 		vector<float> taps;
 		{
-			std::lock_guard<std::mutex> g(fs[stage]->_coeffLock);      /* see LowPass::recalculate */
-			taps = fs[stage]->_coeff;
+			std::lock_guard<std::mutex> g(fs[n]->_coeffLock);          /* see LowPass::recalculate */
+			taps = fs[n]->_coeff;
 		}
 		if (!taps.empty() && taps.size() <= WR_FIR_LENGTH &&
-		    wr_chan_set_taps_n(_tuner, ch->id, stage, taps.data(), (unsigned int)taps.size(),
-		                       fs[stage]->decimation()) != WR_OK)
+		    wr_chan_set_taps_n(_tuner, ch->id, stages[n], taps.data(), (unsigned int)taps.size(),
+		                       fs[n]->decimation()) != WR_OK)
 			return false;
 	}
 	if (wr_chan_set_mode(_tuner, ch->id, (int)ch->demod->_mode) != WR_OK)

@@ -9,7 +9,8 @@
  *   - when a DownConverter that hangs directly off a DspSource is started and the blocks
  *     after it form exactly the Receiver chain of radio.cxx:68-76
  *     (DownConverter -> LowPass -> Demodulator -> LowPass), the four blocks are enrolled
- *     as one CHANNEL of the source's TunerBatch (a wr_tuner on one GPU);
+ *     as one CHANNEL of the source's TunerBatch (a wr_tuner on one GPU); so is the same chain
+ *     with a second LowPass in front of the demodulator (narrow channels off a fast stream);
  *   - the first enrolled DownConverter::process() of a source block ("epoch") uploads the
  *     tuner buffer once and submits every channel; later process() calls of enrolled
  *     blocks in the same epoch are no-ops, except the audio LowPass, which copies its
@@ -76,6 +77,7 @@ struct Channel {
 	int slot;                     /* its row in the tuner's audio array (refreshed when parameters are pushed) */
 	DownConverter *mixer;
 	LowPass *chanFilter;
+	LowPass *chanFilter2;         /* a second LowPass in front of the demodulator, or NULL */
 	Demodulator *demod;
 	LowPass *audioFilter;
 	bool dirty;                   /* parameters changed since the last submit */

@@ -108,8 +108,8 @@ void LowPass::recalculate()
 bool LowPass::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer)
 {
 	if (_channel) {
-		if (_stage == 0)
-			return true;                 /* channel filter: computed inside the batch */
+		if (_stage != 1)
+			return true;                 /* a channel filter (first or second stage): computed inside the batch */
 		return _channel->batch->audio(_channel, outBuffer);   /* audio filter: one slice of the batch's transfer */
 	}
 	const unsigned int ch = inputChannels();

@@ -6,6 +6,11 @@
  * (The reference's own radio.cxx also compiles unchanged against the headers of this
  * directory -- tests/test_boundary.py proves it -- this is the backend's own copy of
  * the wiring so that it can be used without the reference tree.)
+ *
+ * Attribution: the class declarations (FrontEnd, Receiver, namespace Radio: member names,
+ * signatures, order) are those of mikestir/webradio's src/radio.h (Copyright (C) Mike Stirling,
+ * AGPL-3.0), kept source-compatible on purpose so that main.cxx and src/web compile against
+ * this header unchanged.
  */
 #ifndef RADIO_H_
 #define RADIO_H_

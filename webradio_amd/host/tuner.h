@@ -2,6 +2,12 @@
  * tuner.h -- a SampleSource with a centre frequency, ppm offset, AGC and gain.
  * Same public/protected surface and defaults as webradio's src/io/tuner.h:36-77 (the web
  * handlers and FrontEnd call these; hardware tuners override the virtual setters).
+ *
+ * Attribution: the class DECLARATION below -- member names, signatures, default values -- is
+ * that of mikestir/webradio's src/io/tuner.h (Copyright (C) Mike Stirling, AGPL-3.0), kept
+ * token-compatible on purpose: the reference's radio.cxx, tunerhandler.cxx and
+ * tunercontrolhandler.cxx must compile against this header unchanged.  Nothing but
+ * the interface is taken; there is no implementation in it to take.
  */
 #ifndef TUNER_H_
 #define TUNER_H_
