@@ -9,7 +9,7 @@ python3 - "$tag" <<'PY'
 import csv, sys, glob, collections, os
 tag = sys.argv[1]
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob('/tmp/pmc_%s/*counter_collection.csv' % tag):
+for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % tag, recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0][:60]
         rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
