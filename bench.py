@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--resident-blocks", type=int, default=12,
                     help="consecutive blocks of the stream kept in HBM and cycled through (12 x 32 MB is "
                          "more than the 256 MB Infinity Cache holds, so every step reads its block from HBM)")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="after the W warm-up steps, keep stepping (untimed) for this long before the timed region: an "
+                         "MI355X that was idle starts a kernel stream at a reduced clock and takes ~50 ms of continuous "
+                         "load to reach its steady state (measured: the same launch 42-44 us in the first 6 ms, 34.4 us "
+                         "from 45 ms on, profiles/r02_clock_ramp.txt).  0 turns it off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=0,
                     help="blocks of the all-cores CPU baseline (0: as many as take about 10-20 s)")
@@ -93,7 +98,7 @@ def cpu_baseline(cfg, ifs, blocks):
     }
 
 
-def c3_secondary(torch, dev, blocks, n, steps):
+def c3_secondary(torch, dev, blocks, n, steps, settle_ms):
     """BASELINE config 3: SpectrumSink (io/spectrumsink.cxx:88-142) as a waterfall -- 65536-point
     Hamming-windowed FFT every 32768 frames, dB with fft-shift -- over the same resident stream:
     consecutive 4 M-frame blocks (more than the Infinity Cache holds), one row buffer per block.
@@ -106,6 +111,11 @@ def c3_secondary(torch, dev, blocks, n, steps):
     for b in range(min(2, nb)):
         spec.batch_db(blocks[b], rows, outs[b])
     torch.cuda.synchronize()
+    t_settle = time.perf_counter()                     # clocks: see --settle-ms
+    while settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+        for i in range(50):
+            spec.batch_db(blocks[i % nb], rows, outs[i % nb])
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(steps):
@@ -190,10 +200,19 @@ def run_c5(args, torch, dist, rank, world, device_index):
 
     for i in range(args.warmup):
         step(i)
+    done = args.warmup
+    if args.settle_ms > 0:                              # clocks: see --settle-ms
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(50):
+                step(done)
+                done += 1
+            torch.cuda.synchronize()
     tuner.profile(max(1, args.profile_stride))
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(done, done + args.steps):
         step(i)
     tuner.flush()
     torch.cuda.synchronize()
@@ -318,6 +337,17 @@ def main():
     for _ in range(args.warmup):
         tuner.submit_device(blocks[step % nb], n)
         step += 1
+    # untimed: the same steps until the clocks have settled (see --settle-ms)
+    settle_steps = 0
+    if args.settle_ms > 0:
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(100):
+                tuner.submit_device(blocks[step % nb], n)
+                step += 1
+            settle_steps += 100
+            torch.cuda.synchronize()
     tuner.profile(max(1, args.profile_stride))
     barrier()
     t0 = time.perf_counter()
@@ -347,7 +377,7 @@ def main():
     if world == 1 and not args.no_secondary:
         tuner.flush()
         torch.cuda.synchronize()
-        c3 = c3_secondary(torch, dev, blocks, n, max(nb, min(args.steps, 60)))
+        c3 = c3_secondary(torch, dev, blocks, n, max(nb, min(args.steps, 60)), args.settle_ms)
 
     if rank == 0:
         total_samples = float(n) * args.steps * world
@@ -373,6 +403,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle": {"ms": args.settle_ms, "steps": settle_steps,
+                       "why": "untimed steps after the warm-up until the GPU clock has ramped up (an idle MI355X needs "
+                              "~50 ms of continuous load); the timed region is the K steps after them"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Produces the rocprof evidence for bench.py's roofline numbers (run on the GPU box via gpurun):
 #   gpurun_out/<round>_bench.json            the bench line (C2 headline + secondary.c3 + cpu_baseline)
-#   gpurun_out/<round>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/<round>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command (all launches: warm-up,
+#                                            clock settling and the timed steps)
+#   gpurun_out/<round>_kernel_stats_timed.csv   the same trace, the timed region's launches only
 #   gpurun_out/<round>_pmc_fetch_size.txt / _pmc_write_size.txt   FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
 round=${1:-r02}
 R=$GRAFT_REPO_ROOT
@@ -22,6 +24,27 @@ with open(R + '/gpurun_out/%s_kernel_stats.csv' % r, 'w') as f:
         short = name.split('(')[0][:90]          # torch's generator kernels have page-long names
         w.writerow([short, x['Calls'], x['TotalDurationNs'], x['AverageNs'], x['Percentage'], x['MinNs'], x['MaxNs']])
 PY
+# the timed region alone: the last `steps` launches of the dominant kernel (the ones before them are
+# warm-up and the clock-settling steps, see bench.py --settle-ms)
+python3 - "$round" 60 <<'PY'
+import csv, sys, glob, os
+r, steps = sys.argv[1], int(sys.argv[2]); R = os.environ['GRAFT_REPO_ROOT']
+rows = []
+for f in glob.glob('/tmp/prof_%s/**/*kernel_trace.csv' % r, recursive=True):
+    for x in csv.DictReader(open(f)):
+        rows.append((int(x['Start_Timestamp']), x['Kernel_Name'].split('(')[0].replace('void ', ''), (int(x['End_Timestamp']) - int(x['Start_Timestamp']))))
+rows.sort()
+with open(R + '/gpurun_out/%s_kernel_stats_timed.csv' % r, 'w') as f:
+    w = csv.writer(f); w.writerow(['Name', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'what'])
+    for name in sorted(set(n for _, n, _ in rows if n.startswith('k_'))):
+        d = [v for _, n, v in rows if n == name]
+        if name.startswith('k_tuner_ddc') and len(d) > steps + 2:
+            d = d[-(steps + 1):-1] if name.endswith('5u>') else d
+            what = 'timed region: the last %d launches' % len(d)
+        else:
+            what = 'all launches'
+        w.writerow([name, len(d), '%.1f' % (sum(d) / len(d)), min(d), max(d), what])
+PY
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
@@ -39,4 +62,4 @@ with open(R + '/gpurun_out/%s_pmc_%s.txt' % (r, c.lower()), 'w') as out:
         out.write('%s %s mean=%.1f KB per launch (n=%d)\n' % (k, c, sum(v) / len(v), len(v)))
 PY
 done
-cat $R/gpurun_out/${round}_bench.json | cut -c1-600; grep -E "k_tuner|k_fft" $R/gpurun_out/${round}_kernel_stats.csv; cat $R/gpurun_out/${round}_pmc_*.txt
+cat $R/gpurun_out/${round}_bench.json | cut -c1-600; grep -E "k_tuner|k_fft" $R/gpurun_out/${round}_kernel_stats.csv; cat $R/gpurun_out/${round}_kernel_stats_timed.csv; cat $R/gpurun_out/${round}_pmc_*.txt

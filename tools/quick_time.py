@@ -31,8 +31,8 @@ for name in which:
     for i in range(4):
         t.submit_device(blocks[i % nb], n)
     torch.cuda.synchronize()
-    reps = 3 if name == "exact" else 20
-    t.profile(True)
+    reps = 3 if name == "exact" else int(os.environ.get("QT_REPS", "20"))
+    t.profile(int(os.environ.get("QT_PROFILE", "1")))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(reps):
