@@ -59,7 +59,8 @@ def parse():
                     help="blocks of the all-cores CPU baseline (0: as many as take about 10-20 s)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 (SpectrumSink) measurement")
     ap.add_argument("--profile-stride", type=int, default=8,
-                    help="bracket every n-th step's dominant kernel with HIP events (an event pair costs ~4 us)")
+                    help="one HIP event pair around every n consecutive launches of the dominant kernel (n = 1: every "
+                         "launch stamps its own start and stop, which costs ~2 us of stream time per launch)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     return ap.parse_args()
@@ -437,6 +438,8 @@ def main():
                 "traffic_unit": "bytes per launch, PMC FETCH_SIZE+WRITE_SIZE (profiles/traffic.json)",
                 "kernel_ms": round(ddc_ms, 5),
                 "launches_timed": launches,
+                "timing": "HIP events on the launch stream inside the timed region, one pair around every %d consecutive "
+                          "launches: the mean per launch includes the gaps between launches" % max(1, args.profile_stride),
                 "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SAMPLE,
                 "note": "the path is fp32-VALU bound at 256 channels (DESIGN.md): "
                         "HBM fraction is reported as the contract asks, not as the binding roof",

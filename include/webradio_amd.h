@@ -305,12 +305,13 @@ int wr_tuner_seek(wr_tuner *tuner, unsigned long long frame);
 int wr_tuner_set_audio_scale(wr_tuner *tuner, float scale);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
- * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75): with `enable` = 1 every submit (with
- * `enable` = n > 1 every n-th submit: an event pair costs a few microseconds of stream time)
- * brackets its dominant kernel (the fused mixer + channel filter) with HIP events on
- * the tuner's stream.  wr_tuner_profile_read synchronises, returns the number of
- * bracketed launches since the last read and their mean duration in milliseconds, and
- * resets the counters. */
+ * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75), with HIP events on the tuner's stream.
+ * `enable` = 1: every submit's dominant launch (the fused mixer + channel filter) stamps its
+ * own start and stop.  `enable` = n > 1: one event before the launch of every n-th submit and one
+ * after the launch n - 1 submits later -- the mean per launch then includes the gaps between
+ * launches and costs 1/n of the events' own few microseconds.  wr_tuner_profile_read
+ * synchronises, returns the number of launches covered since the last read and their mean
+ * duration in milliseconds, and resets the counters. */
 int wr_tuner_profile(wr_tuner *tuner, int enable);
 int wr_tuner_profile_read(wr_tuner *tuner, unsigned int *launches, double *mean_ms);
 

@@ -23,18 +23,20 @@ def _line(out):
 
 
 def test_single_gpu_line():
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2",
                                    "--cpu-blocks", "1"], cwd=ROOT)
     j = _line(out)
     for k in REQUIRED + ["cpu_baseline"]:
         assert k in j, k
-    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["scaling"] == "weak"
+    assert j["n_gpus"] == 1 and j["steps"] == 40 and j["warmup"] == 2 and j["scaling"] == "weak"
     assert j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
-    assert abs(j["value"] - 4.0e6 * 5 / (j["ms_per_step"] * 5 / 1e3) / 1e6) / j["value"] < 1e-3
+    assert abs(j["value"] - 4.0e6 * 40 / (j["ms_per_step"] * 40 / 1e3) / 1e6) / j["value"] < 1e-3
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 1 <= r["launches_timed"] <= 5
-    assert r["kernel_ms"] < j["ms_per_step"]                      # the dominant kernel is part of a step
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 8 <= r["launches_timed"] <= 40
+    # the dominant kernel IS the step (the previous block's post stage rides in the same launch); its
+    # event-timed mean covers groups of 8 launches with their gaps
+    assert r["kernel_ms"] <= j["ms_per_step"] * 1.05
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == min(256, len(os.sched_getaffinity(0))) and c["value"] > 0
     assert c["one_core"]["cores"] == 1 and c["one_core"]["value"] > 0

@@ -131,8 +131,10 @@ struct wr_tuner {
 	bool submitted;
 	float audio_scale;
 	bool profiling;
-	unsigned int prof_stride;  /* bracket every prof_stride-th submit */
+	unsigned int prof_stride;  /* 1: every submit's launch stamps its own start/stop; n > 1: one event pair
+	                              around every n consecutive submits (see wr_tuner_profile) */
 	unsigned int prof_tick;
+	std::vector<unsigned int> ev_span;   /* launches between the events of pair i */
 	std::vector<hipEvent_t> ev;    /* start/stop pairs */
 	size_t ev_used;                /* events recorded and not yet read */
 	double prof_ms;
@@ -1253,10 +1255,12 @@ static int prof_drain(wr_tuner *t, size_t keep)
 	for (size_t i = 0; i + 1 < t->ev_used; i += 2) {
 		float ms = 0.0f;
 		HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
-		t->prof_ms += ms;
-		t->prof_n++;
+		const unsigned int span = (i / 2 < t->ev_span.size() && t->ev_span[i / 2]) ? t->ev_span[i / 2] : 1u;
+		t->prof_ms += ms;                           /* prof_ms / prof_n = mean per launch */
+		t->prof_n += span;
 	}
 	t->ev_used = 0;
+	t->ev_span.clear();
 	return WR_OK;
 }
 
@@ -1264,6 +1268,8 @@ extern "C" int wr_tuner_profile(wr_tuner *t, int enable)
 {
 	if (!t)
 		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (t->ev_used & 1)
+		t->ev_used--;                               /* a group left open: its start event is dropped */
 	t->profiling = enable != 0;
 	t->prof_stride = enable > 1 ? (unsigned int)enable : 1u;
 	t->prof_tick = 0;
@@ -1330,7 +1336,13 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 
 	bool hist_written = false;
 	const unsigned long long seq = t->submit_seq++;
-	const bool prof_now = t->profiling && (t->prof_tick++ % t->prof_stride) == 0;
+	/* stride 1: this submit's launch stamps its own start and stop (hipExtLaunchKernelGGL).  Stride
+	 * n > 1: an event before the launch of the group's first submit and one after the launch of its
+	 * last -- n launches and the gaps between them per pair, at 1/n of the events' own cost. */
+	const unsigned int prof_pos = t->profiling ? t->prof_tick++ % t->prof_stride : 0u;
+	const bool prof_now = t->profiling && t->prof_stride == 1;
+	const bool group_first = t->profiling && t->prof_stride > 1 && prof_pos == 0;
+	const bool group_last = t->profiling && t->prof_stride > 1 && prof_pos == t->prof_stride - 1 && (t->ev_used & 1);
 	for (Group *g : t->groups) {
 		if (g->active <= 0) {
 			g->last_k1 = g->last_k2 = 0;
@@ -1365,8 +1377,8 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		L.use_gain = g->use_gain ? 1 : 0;
 		L.use_squelch = g->use_squelch ? 1 : 0;
 		L.ev_start = L.ev_stop = nullptr;
-		if (prof_now) {
-			int rc = prof_drain(t, 64);
+		if (prof_now || group_first) {
+			int rc = (t->ev_used & 1) ? WR_OK : prof_drain(t, 64);
 			if (rc)
 				return rc;
 			while (t->ev.size() < t->ev_used + 2) {
@@ -1374,16 +1386,30 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 				HIP_TRY(hipEventCreate(&e));
 				t->ev.push_back(e);
 			}
+		}
+		if (prof_now) {
 			L.ev_start = t->ev[t->ev_used];     /* stamped by the launch itself (wrk_tuner_ddc) */
 			L.ev_stop = t->ev[t->ev_used + 1];
+		}
+		if (group_first && !(t->ev_used & 1)) {
+			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
+			t->ev_used += 1;
 		}
 		/* The previous block's post stage rides along with this block's DDC where the kernel
 		 * variant can take it (wrk_tuner_ddc says); otherwise it goes out on its own first. */
 		bool rode = false;
 		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 		                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
-		if (prof_now)
+		if (prof_now) {
+			t->ev_span.resize(t->ev_used / 2 + 1, 1u);
 			t->ev_used += 2;
+		}
+		if (group_last && (t->ev_used & 1)) {
+			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
+			t->ev_span.resize(t->ev_used / 2 + 1, 1u);
+			t->ev_span[t->ev_used / 2] = t->prof_stride;
+			t->ev_used += 1;
+		}
 		if (g->post_pending) {
 			if (!rode)
 				HIP_TRY(wrk_tuner_post_args(st, g->post_args));

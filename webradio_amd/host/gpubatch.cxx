@@ -112,11 +112,13 @@ struct SourceStage {
 			return false;
 		for (size_t n = 0; n < pinned.size(); n++)
 			if (pinned[n].ptr == p) {                      /* same address, grown: register afresh */
+				wr_dev_wait_uploads(d);                    /* (a copy out of it may still be in flight) */
 				wr_dev_host_unregister(d, pinned[n].ptr);
 				pinned.erase(pinned.begin() + n);
 				break;
 			}
 		if (pinned.size() >= 4) {                          /* a source that allocates per block: give up on the oldest */
+			wr_dev_wait_uploads(d);
 			wr_dev_host_unregister(d, pinned[0].ptr);
 			pinned.erase(pinned.begin());
 		}
@@ -536,15 +538,15 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 			size_t stride = 0, frames = 0;
 			unsigned int slots = 0;
 			unsigned long long seq = 0;
-			if (wr_tuner_audio_ring_acquire(_tuner, &p, &stride, &frames, &slots, &seq) != WR_OK) {
-				LOG_ERROR("audio ring: %s\n", wr_last_error());
-				return false;
+			if (wr_tuner_audio_ring_acquire(_tuner, &p, &stride, &frames, &slots, &seq) == WR_OK) {
+				_ringHeld = true;
+				_audioPtr = p;
+				_audioStride = stride;
+				_audioFrames = frames;
+				_audioSlots = slots;
 			}
-			_ringHeld = true;
-			_audioPtr = p;
-			_audioStride = stride;
-			_audioFrames = frames;
-			_audioSlots = slots;
+			/* else: nothing queued -- receivers in several rate groups are not ringed (see the C ABI);
+			 * audio() then fetches per channel, which is this block's audio, on time */
 		}
 		_submitOk = true;
 		return true;
