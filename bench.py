@@ -249,8 +249,9 @@ def run_c5(args, torch, dist, rank, world, device_index):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_tuner_ddc on [halo | chunk] (the previous chunk's demod + audio filter run on their own here: "
-                          "wr_tuner_seek needs them finished)",
+                "kernel": "the launches of one step -- k_seek, k_tuner_ddc on [halo | chunk], k_tuner_post (the demod + audio "
+                          "filter run on their own here: wr_tuner_seek needs the previous chunk's finished) -- timed "
+                          "together: kernel_ms is the mean per step over groups of consecutive steps",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                 "kernel_ms": round(ddc_ms, 5), "launches_timed": launches,

@@ -1421,8 +1421,19 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	const size_t units = L.k1 * ngroups;
 	unsigned int wgs = (unsigned int)((units + W - 1) / W);
 	const unsigned int cap = (unsigned int)num_cus * wgs_per_cu;
-	if (wgs > cap)
+	if (wgs > cap) {
+#ifdef DDC_FILL_ALL_SLOTS
 		wgs = cap;
+#else
+		/* as many workgroups as make the units come out EVEN: with every slot filled (6 144 waves for
+		 * C2's 40 000 units: 6.5 units per wave) half the waves take one unit more than the others
+		 * and run the last round at half occupancy; 715 of the 768 workgroups give every wave seven */
+		const size_t rounds = (units + (size_t)cap * W - 1) / ((size_t)cap * W);
+		wgs = (unsigned int)((units + (size_t)W * rounds - 1) / ((size_t)W * rounds));
+		if (wgs > cap)
+			wgs = cap;
+#endif
+	}
 	if (NCO == WR_NCO_ROTATE && !UTAPS) {
 		/* per-lane taps live in LDS, one lane group per WORKGROUP: a whole number of
 		 * workgroups per group, at least one */
