@@ -234,3 +234,50 @@ def _slot(t, chan):
     s = C.c_int()
     capi.check(t.lib.wr_chan_slot(t.h, chan, C.byref(s)))
     return s.value
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+def test_blocks_per_launch_gives_the_same_bits(dev, oracle, nco):
+    """wr_tuner_set_blocks_per_launch: back-to-back device blocks held and launched as one.  Same
+    stream through a tuner that launches every block and one that joins up to three: the audio is
+    the same bits -- whole groups, a group cut short by a fetch, a block that does not follow on in
+    memory, a retune staged between two held blocks (it must take effect at ITS block boundary)."""
+    import torch
+    fs, n, nch = 2_000_000, 40_000, 70
+    ifs = [(-35 + c) * 6250 + 99 for c in range(nch)]
+    nblk = 9
+    iq = synth.fm_stream(nblk * n, fs, ifs[::9], amp=0.1, fm_base=30.0, beta=2.0)
+    x = torch.from_numpy(iq).cuda()
+    other = x[: 2 * n].clone()                                  # block 5 comes from somewhere else in memory
+    other.copy_(x[2 * 5 * n: 2 * 6 * n])
+
+    def run(join, fetch_at):
+        t = Tuner(dev, fs, nch, 3 * n, nco)
+        chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_USB, 160, 1_000) for f in ifs]
+        if join:
+            t.blocks_per_launch(3)
+        out = []
+        for b in range(nblk):
+            if b == 7:
+                t.set_if(chans[3], ifs[3] + 1234)               # staged: applies from block 7 on
+            src = other if b == 5 else x[2 * b * n: 2 * (b + 1) * n]
+            t.submit_device(src, n)
+            if b in fetch_at:                                   # reading results launches what is held
+                out.append(t.fetch_audio_all().copy())
+        t.destroy()
+        return np.concatenate(out, axis=1)
+
+    k2 = n // 2000
+    every = run(False, set(range(nblk)))
+    assert every.shape[1] == nblk * k2
+    # launches the joining tuner forms: [0,1,2]  [3,4] (block 5 does not follow on in memory)  [5] (cut
+    # by the fetch)  [6] (cut by the staged retune)  [7,8] (cut by the final fetch)
+    grouped = run(True, {2, 4, 5, 6, 8})
+    assert grouped.shape == every.shape
+    assert np.array_equal(every.view(np.uint32), grouped.view(np.uint32))
+    # a fetch in the middle of a group launches the part that is there: [0,1] [2,3,4] [5] ([6] not
+    # fetched) [7,8]
+    cut = run(True, {1, 4, 5, 8})
+    keep = np.r_[0:6 * k2, 7 * k2:9 * k2]
+    assert cut.shape[1] == 8 * k2
+    assert np.array_equal(every[:, keep].view(np.uint32), cut.view(np.uint32))

@@ -6,7 +6,7 @@ from webradio_amd import capi, synth
 from webradio_amd.device import Device, Tuner
 
 c2 = synth.C2
-fs, n = c2["input_rate"], c2["block_frames"]
+fs, n = c2["input_rate"], c2["block_frames"] * int(os.environ.get("QT_COALESCE", "1"))   # n blocks per launch
 nch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 modes = {"split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT, "rotate": capi.WR_NCO_ROTATE}
 which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["split", "exact"]

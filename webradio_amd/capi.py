@@ -66,6 +66,7 @@ SIGNATURES = {
     "wr_chan_set_squelch": (C.c_int, [_vp, C.c_int, C.c_float, C.c_int]),
     "wr_tuner_keep_stages": (C.c_int, [_vp, _u32]),
     "wr_tuner_flush": (C.c_int, [_vp]),
+    "wr_tuner_set_blocks_per_launch": (C.c_int, [_vp, _u32]),
     "wr_tuner_seek": (C.c_int, [_vp, C.c_ulonglong]),
     "wr_tuner_audio_ring": (C.c_int, [_vp, _u32]),
     "wr_tuner_audio_ring_acquire": (C.c_int, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),

@@ -154,6 +154,13 @@ struct wr_tuner {
 	unsigned long long ring_overruns = 0;
 	unsigned long long submit_seq = 0;             /* blocks submitted so far */
 	bool defer_post = true;                        /* see Group::post_pending; WR_DEFER_POST=0 turns it off */
+	/* wr_tuner_set_blocks_per_launch: consecutive WR_DEVICE blocks that lie back to back in memory are
+	 * held (pointer and length only) and launched as ONE block -- the bits do not depend on how the
+	 * stream is cut into blocks, the fixed cost of a launch (~4.5 us at C2) is paid once per group */
+	unsigned int coalesce = 1;
+	const float *held_base = nullptr;
+	size_t held_frames = 0, held_each = 0;
+	unsigned int held_count = 0;
 	std::mutex ring_lock;                          /* producer (submit) vs consumer thread */
 };
 
@@ -729,8 +736,24 @@ static int tuner_quiesce(wr_tuner *t);
 static int tuner_flush(wr_tuner *t);
 static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used);
 
+static int tuner_launch_held(wr_tuner *t);
+
+/* Blocks waiting for their successors (wr_tuner_set_blocks_per_launch) go out before anything is
+ * staged or read: a setter takes effect at the boundary after the last block SUBMITTED, and a
+ * getter sees the state after it. */
+static int settle_held(wr_tuner *t)
+{
+	if (!t || !t->held_count)
+		return WR_OK;
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	return tuner_launch_held(t);
+}
+
 static Chan *chan_get(wr_tuner *t, int chan)
 {
+	if (settle_held(t))
+		return nullptr;
 	if (!t || chan < 0 || (size_t)chan >= t->chans.size() || !t->chans[chan].in_use)
 		return nullptr;
 	return &t->chans[chan];
@@ -740,6 +763,8 @@ extern "C" int wr_chan_add(wr_tuner *t, int *chan)
 {
 	if (!t || !chan)
 		return fail(WR_ERR_ARG, "wr_chan_add: bad argument");
+	if (int rc = settle_held(t))
+		return rc;
 	int live = 0;
 	for (const Chan &c : t->chans)
 		live += c.in_use ? 1 : 0;
@@ -1012,6 +1037,8 @@ extern "C" int wr_tuner_keep_stages(wr_tuner *t, unsigned int stage_mask)
 {
 	if (!t)
 		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (int rc = settle_held(t))
+		return rc;
 	t->keep_mask = stage_mask;
 	return WR_OK;
 }
@@ -1072,8 +1099,15 @@ extern "C" int wr_chan_slot(wr_tuner *t, int chan, int *slot)
 }
 
 /* launch whatever post stage is still pending (results of the last submit wanted now) */
+static int tuner_launch_held(wr_tuner *t);
+
 static int tuner_flush(wr_tuner *t)
 {
+	{
+		int rc = tuner_launch_held(t);
+		if (rc)
+			return rc;
+	}
 	for (Group *g : t->groups) {
 		if (!g->post_pending)
 			continue;
@@ -1304,7 +1338,69 @@ extern "C" int wr_tuner_submit_u8(wr_tuner *t, const uint8_t *iq_u8, size_t nfra
 	return tuner_submit(t, iq_u8, nframes, where, true);
 }
 
+static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8);
+
+static int tuner_launch_held(wr_tuner *t)
+{
+	if (!t->held_count)
+		return WR_OK;
+	const float *base = t->held_base;
+	const size_t frames = t->held_frames;
+	t->held_count = 0;
+	t->held_base = nullptr;
+	t->held_frames = 0;
+	return tuner_submit_now(t, base, frames, WR_DEVICE, false);
+}
+
+/* may this block wait for its successor?  Only whole audio frames: a block that is not a multiple
+ * of every rate group's decimations restarts the decimation phase at its start (dspblock.cxx:177-178
+ * truncates per block), which a merged block would not */
+static bool block_can_be_held(const wr_tuner *t, size_t nframes)
+{
+	for (const Group *g : t->groups) {
+		if (g->active <= 0)
+			continue;
+		const size_t q = (size_t)g->d1 * (g->d1b ? g->d1b : 1u) * g->d2;
+		if (!q || nframes % q)
+			return false;
+	}
+	return true;
+}
+
 static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8)
+{
+	if (!t || (nframes && !iq))
+		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
+	if (t->coalesce > 1 && where == WR_DEVICE && !u8 && nframes && block_can_be_held(t, nframes)) {
+		const float *p = (const float *)iq;
+		/* (a setter called since the last submit has sent the held blocks out already: settle_held) */
+		const bool follows = t->held_count && p == t->held_base + 2 * t->held_frames &&
+		                     nframes == t->held_each && t->held_frames + nframes <= t->max_block_frames;
+		if (!follows) {
+			int rc = tuner_launch_held(t);
+			if (rc)
+				return rc;
+			if (nframes * 2 > t->max_block_frames)          /* no room for a second one: nothing to wait for */
+				return tuner_submit_now(t, iq, nframes, where, u8);
+			t->held_base = p;
+			t->held_frames = 0;
+			t->held_each = nframes;
+		}
+		t->held_frames += nframes;
+		t->held_count++;
+		if (t->held_count >= t->coalesce || t->held_frames + nframes > t->max_block_frames)
+			return tuner_launch_held(t);
+		return WR_OK;
+	}
+	{
+		int rc = tuner_launch_held(t);                      /* keep the stream in order */
+		if (rc)
+			return rc;
+	}
+	return tuner_submit_now(t, iq, nframes, where, u8);
+}
+
+static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8)
 {
 	if (!t || (nframes && !iq))
 		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
@@ -1479,6 +1575,19 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 	return WR_OK;
 }
 
+extern "C" int wr_tuner_set_blocks_per_launch(wr_tuner *t, unsigned int nblocks)
+{
+	if (!t || !nblocks)
+		return fail(WR_ERR_ARG, "wr_tuner_set_blocks_per_launch: bad argument");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	int rc = tuner_launch_held(t);
+	if (rc)
+		return rc;
+	t->coalesce = nblocks;
+	return WR_OK;
+}
+
 extern "C" int wr_tuner_flush(wr_tuner *t)
 {
 	if (!t)
@@ -1546,6 +1655,8 @@ extern "C" int wr_tuner_audio_dev(wr_tuner *t, const float **audio_dev, size_t *
 {
 	if (!t || !audio_dev || !chan_stride || !frames)
 		return fail(WR_ERR_ARG, "wr_tuner_audio_dev: bad argument");
+	if (int rc = settle_held(t))
+		return rc;
 	Group *g = nullptr;
 	for (Group *x : t->groups)
 		if (x->active > 0) {
@@ -1573,6 +1684,8 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 {
 	if (!t || !chan_stride || !frames || !slots_used)
 		return fail(WR_ERR_ARG, "wr_tuner_fetch_audio_all: bad argument");
+	if (int rc = settle_held(t))
+		return rc;
 	Group *g = nullptr;
 	for (Group *x : t->groups)
 		if (x->active > 0) {
@@ -1662,6 +1775,8 @@ extern "C" int wr_tuner_audio_ring(wr_tuner *t, unsigned int depth)
 		return fail(WR_ERR_ARG, "wr_tuner_audio_ring: depth %u", depth);
 	if (dev_bind(t->dev))
 		return WR_ERR_HIP;
+	if (int rc = settle_held(t))
+		return rc;
 	{
 		int rc = tuner_quiesce(t);               /* no copy may be in flight into a slot we free */
 		if (rc)
@@ -1772,6 +1887,8 @@ extern "C" int wr_tuner_set_audio_scale(wr_tuner *t, float scale)
 {
 	if (!t)
 		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (int rc = settle_held(t))
+		return rc;
 	t->audio_scale = scale;
 	return WR_OK;
 }

@@ -134,6 +134,10 @@ class Tuner:
         """Launch a post stage (demod + audio filter) that is still waiting for the next submit."""
         check(self.lib.wr_tuner_flush(self.h))
 
+    def blocks_per_launch(self, n):
+        """Hold up to n back-to-back device blocks and launch them as one (the same bits, per group)."""
+        check(self.lib.wr_tuner_set_blocks_per_launch(self.h, n))
+
     def seek(self, frame):
         """Every channel as if the stream started at `frame` (NCO phase closed-form): time sharding."""
         check(self.lib.wr_tuner_seek(self.h, C.c_ulonglong(frame)))
