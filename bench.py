@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--resident-blocks", type=int, default=12,
                     help="consecutive blocks of the stream kept in HBM and cycled through (12 x 32 MB is "
                          "more than the 256 MB Infinity Cache holds, so every step reads its block from HBM)")
+    ap.add_argument("--blocks-per-launch", type=int, default=4,
+                    help="wr_tuner_set_blocks_per_launch: consecutive resident blocks the tuner holds and launches "
+                         "as one (a step stays one 40 ms block; audio is delivered per launch).  1 = every block "
+                         "its own launch, also measured and reported as secondary.c2_one_block_per_launch")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="after the W warm-up steps, keep stepping (untimed) for this long before the timed region: an "
                          "MI355X that was idle starts a kernel stream at a reduced clock and takes ~50 ms of continuous "
@@ -318,16 +322,19 @@ def main():
     n = cfg["block_frames"]
     ifs = synth.c2_ifs(args.channels)
     # one independent tuner per GPU: its own stream of FM carriers, seed 12345 + tuner index
+    B = max(1, args.blocks_per_launch)
     nb = max(1, args.resident_blocks)
+    nb = (nb + B - 1) // B * B                  # whole launches before the resident stream wraps
     stream_iq = synth.fm_stream_torch(n * nb, cfg["input_rate"], ifs[::4], "cuda", seed=12345 + rank)
     blocks = [stream_iq[2 * n * b: 2 * n * (b + 1)] for b in range(nb)]
     stream = torch.cuda.current_stream().cuda_stream
     dev = Device(device_index, stream)
     nco = {"rotate": capi.WR_NCO_ROTATE, "split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT}[args.nco]
-    tuner = Tuner(dev, cfg["input_rate"], args.channels, n, nco)
+    tuner = Tuner(dev, cfg["input_rate"], args.channels, n * B, nco)
     for f in ifs:
         tuner.add_receiver(f, cfg["chan_passband"], cfg["chan_rate"], capi.WR_FM, cfg["audio_passband"],
                            cfg["audio_rate"])
+    tuner.blocks_per_launch(B)
 
     def barrier():
         torch.cuda.synchronize()
@@ -350,20 +357,38 @@ def main():
                 step += 1
             settle_steps += 100
             torch.cuda.synchronize()
-    tuner.profile(max(1, args.profile_stride))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tuner.submit_device(blocks[step % nb], n)
-        step += 1
-    # the demod + audio filter of a block ride along with the NEXT block's launch (wr_tuner_flush in
-    # include/webradio_amd.h): have the last block's run too, inside the timed region
-    tuner.flush()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches, ddc_ms = tuner.profile_read()
-    tuner.profile(False)
+    def launches_of(steps):
+        # the launches `steps` consecutive steps from the start of the resident stream make: a launch
+        # closes when it holds B blocks or the next block does not follow on in memory (the wrap)
+        count, held = 0, 0
+        for i in range(steps):
+            held += 1
+            if held == B or (i + 1) % nb == 0 or i + 1 == steps:
+                count, held = count + 1, 0
+        return count
+
+    def timed_steps(steps, stride):
+        # exactly `steps` steps between two barriers; what was held before goes out first, untimed
+        tuner.flush()
+        tuner.profile(stride)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tuner.submit_device(blocks[i % nb], n)
+        # the demod + audio filter of a block ride along with the NEXT launch (wr_tuner_flush in
+        # include/webradio_amd.h): have the last one's run too, inside the timed region
+        tuner.flush()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        got, ms = tuner.profile_read()
+        tuner.profile(False)
+        return dt, got, ms
+
+    n_launches = launches_of(args.steps)
+    stride = max(1, min(args.profile_stride, n_launches // 2))
+    elapsed, launches, ddc_ms = timed_steps(args.steps, stride)
+    frames_per_launch = float(n) * args.steps / n_launches
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -371,8 +396,23 @@ def main():
         elapsed = float(tt.item())
 
     # sanity: the audio of a carrier channel is finite and non-trivial (nothing was skipped)
-    a = tuner.fetch(0, capi.WR_STAGE_AUDIO, n)
-    assert a.size == n // 400 // 5 and bool((a == a).all()) and float(abs(a).max()) > 0.0
+    a = tuner.fetch(0, capi.WR_STAGE_AUDIO, n * B)
+    assert a.size and a.size % (n // 400 // 5) == 0 and bool((a == a).all()) and float(abs(a).max()) > 0.0
+
+    # the same steps with every block a launch of its own (what a caller that wants each block's audio
+    # before submitting the next gets), outside the headline's timed region
+    one = None
+    if B > 1 and world == 1 and not args.no_secondary:
+        tuner.blocks_per_launch(1)
+        k1 = min(args.steps, 96)
+        for i in range(600):                     # ~25 ms of this launch shape before its timed steps
+            tuner.submit_device(blocks[i % nb], n)
+        dt1, got1, ms1 = timed_steps(k1, max(1, min(args.profile_stride, k1 // 2)))
+        one = {"blocks_per_launch": 1, "steps": k1, "ms_per_step": round(dt1 / k1 * 1e3, 5),
+               "value": round(float(n) * k1 / dt1 / 1e6, 2), "unit": "complex Msamples/s",
+               "kernel_ms": round(ms1, 5), "launches_timed": got1,
+               "roofline_frac": round((n * ALGO_BYTES_PER_SAMPLE / 1e9) / (ms1 / 1e3) / HBM_PEAK_GBPS, 5) if ms1 > 0 else None}
+        tuner.blocks_per_launch(B)
 
     # BASELINE config 3 off the same resident stream, outside the timed region of the headline
     c3 = None
@@ -384,9 +424,10 @@ def main():
     if rank == 0:
         total_samples = float(n) * args.steps * world
         value = total_samples / elapsed / 1e6
-        achieved = (n * ALGO_BYTES_PER_SAMPLE / 1e9) / (ddc_ms / 1e3) if ddc_ms > 0 else 0.0
+        nl = frames_per_launch                    # tuner input frames per launch
+        achieved = (nl * ALGO_BYTES_PER_SAMPLE / 1e9) / (ddc_ms / 1e3) if ddc_ms > 0 else 0.0
         # lane groups x channel-rate frames x 64 taps x VALU instructions per tap
-        tap_instr = ((args.channels + 63) // 64) * (n // (cfg["input_rate"] // cfg["chan_rate"])) * 64 \
+        tap_instr = ((args.channels + 63) // 64) * (nl / (cfg["input_rate"] // cfg["chan_rate"])) * 64 \
             * VALU_PER_TAP.get(args.nco, 0)
         # HBM bytes of the dominant kernel from the PMC passes of tools/profile_round.sh (they
         # cannot be collected from inside this process); null when the committed figure is
@@ -394,7 +435,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.channels == 256 and args.nco == tj.get("nco", "split"):
+            if args.channels == 256 and args.nco == tj.get("nco", "split") and tj.get("frames_per_launch", n) == nl:
                 traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -421,6 +462,12 @@ def main():
                 "channels": args.channels,
                 "block_frames": n,
                 "resident_blocks": nb,
+                "blocks_per_launch": B,
+                "blocks_per_launch_note": "wr_tuner_set_blocks_per_launch(%d): the tuner holds consecutive blocks and "
+                                          "launches them as one (bit-identical audio, tests/test_gpu_ring.py); a block's "
+                                          "audio is available when its launch has run, up to %d blocks (%d ms of signal) "
+                                          "later than with one launch per block -- secondary.c2_one_block_per_launch "
+                                          "is the same job without it" % (B, B - 1, (B - 1) * 40),
                 "nco": args.nco,
                 "tuners_per_gpu": 1,
                 "parallelism": "one tuner per GPU, no collective",
@@ -441,7 +488,8 @@ def main():
                 "launches_timed": launches,
                 "timing": "HIP events on the launch stream inside the timed region, one pair around every %d consecutive "
                           "launches: the mean per launch includes the gaps between launches" % max(1, args.profile_stride),
-                "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SAMPLE,
+                "algorithmic_bytes_per_launch": nl * ALGO_BYTES_PER_SAMPLE,
+                "frames_per_launch": nl,
                 "note": "the path is fp32-VALU bound at 256 channels (DESIGN.md): "
                         "HBM fraction is reported as the contract asks, not as the binding roof",
                 # the binding resource, for context: VALU wave-instructions the DDC taps need (7 per
@@ -452,14 +500,18 @@ def main():
                     "isolated_rate_wave_instr_per_s": 0.954e12,
                     "frac": round(tap_instr / 0.954e12 / (ddc_ms / 1e3), 4) if ddc_ms > 0 else None,
                     # SURVEY 8d's algorithmic flop count against the fp32 vector peak
-                    "fp32_tflops": round(n * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12, 2) if ddc_ms > 0 else None,
-                    "fp32_frac_of_vector_peak": round(n * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12
+                    "fp32_tflops": round(nl * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12, 2) if ddc_ms > 0 else None,
+                    "fp32_frac_of_vector_peak": round(nl * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12
                                                       / FP32_VECTOR_PEAK_TFLOPS, 4) if ddc_ms > 0 else None,
                 },
             },
         }
-        if world == 1 and c3 is not None:
-            out["secondary"] = {"c3": c3}
+        if world == 1 and (c3 is not None or one is not None):
+            out["secondary"] = {}
+            if one is not None:
+                out["secondary"]["c2_one_block_per_launch"] = one
+            if c3 is not None:
+                out["secondary"]["c3"] = c3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ifs, args.cpu_blocks)
     else:

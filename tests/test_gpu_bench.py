@@ -33,10 +33,14 @@ def test_single_gpu_line():
     assert abs(j["value"] - 4.0e6 * 40 / (j["ms_per_step"] * 40 / 1e3) / 1e6) / j["value"] < 1e-3
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 8 <= r["launches_timed"] <= 40
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    B = j["config"]["blocks_per_launch"]
+    assert B == 4 and r["frames_per_launch"] == 4.0e6 * B and 4 <= r["launches_timed"] <= 40 // B
     # the dominant kernel IS the step (the previous block's post stage rides in the same launch); its
     # event-timed mean covers groups of 8 launches with their gaps
-    assert r["kernel_ms"] <= j["ms_per_step"] * 1.05
+    assert r["kernel_ms"] <= j["ms_per_step"] * B * 1.05
+    one = j["secondary"]["c2_one_block_per_launch"]
+    assert one["blocks_per_launch"] == 1 and one["value"] > 0 and one["kernel_ms"] <= one["ms_per_step"] * 1.05
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == min(256, len(os.sched_getaffinity(0))) and c["value"] > 0
     assert c["one_core"]["cores"] == 1 and c["one_core"]["value"] > 0

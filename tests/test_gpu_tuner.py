@@ -632,3 +632,46 @@ def test_few_distinct_channel_filters_share_the_fast_kernel(dev, oracle, nco):
                 gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * 40_000)
                 assert np.abs(gc - wc).max() <= (0.0 if nco == capi.WR_NCO_EXACT else IQ_ATOL), (b, c)
     t.destroy()
+
+
+@pytest.mark.parametrize("d2,blocks,mode", [(5, [38_400, 39_100, 38_400], capi.WR_USB),
+                                            (2, [61_440, 61_440], capi.WR_USB),
+                                            (5, [38_400, 38_400], capi.WR_FM)])
+def test_post_stage_runs_of_tiles(dev, oracle, d2, blocks, mode):
+    """The post stage in runs: with enough tiles a workgroup takes 2 or 4 consecutive 16-frame tiles
+    and keeps the staged demodulator rows they share in LDS (post_role).  1024 receivers = 16 lane
+    groups; (D2 5, 384 audio frames) = 24 tiles a group: runs of 2, a ragged last tile in the second
+    block; (D2 2, 1536 frames) = 96 tiles: runs of 4 and rows carried over that overlap the fresh
+    ones; lane group 3 has two audio filters (taps per lane from memory, the others' come through
+    the scalar cache).  EXACT mode, USB: the same bits as the oracle; FM: within tolerance."""
+    fs, nch = 2_000_000, 1024
+    chan_rate, audio_rate = 100_000, 100_000 // d2
+    ifs = [(-nch // 2 + c) * 900 + 77 for c in range(nch)]
+    t = Tuner(dev, fs, nch, max(blocks), capi.WR_NCO_EXACT)
+    apb = lambda c: 3_000 if (192 <= c < 256 and c % 3 == 0) else 4_000        # group 3: mixed audio filters
+    chans = [t.add_receiver(f, 40_000, chan_rate, mode, apb(c), audio_rate) for c, f in enumerate(ifs)]
+    probe = [0, 63, 192, 193, 195, 255, 600, 960, 1023]
+    rxs = {c: oracle.Receiver(fs, ifs[c], 40_000, chan_rate, {capi.WR_USB: oracle.USB, capi.WR_FM: oracle.FM}[mode],
+                              apb(c), audio_rate) for c in probe}
+    # through the audio ring, blocks submitted back to back: the post stage of every block but the
+    # last rides in the next block's launch (taps from memory or the scalar cache), the last one's
+    # runs as a kernel of its own (taps in registers)
+    t.audio_ring(len(blocks))
+    start, want = 0, []
+    for n in blocks:
+        iq = synth.fm_stream(n, fs, [ifs[c] for c in probe], start_frame=start, seed=11, amp=0.1, fm_base=300.0, beta=2.0)
+        start += n
+        t.submit_host(iq)
+        want.append({c: rxs[c].run(iq)[0] for c in probe})
+    t.flush()
+    for b, n in enumerate(blocks):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b and audio.shape[1] == n // 20 // d2
+        for c in probe:
+            ga, wa = audio[t.slot(chans[c])], want[b][c]
+            if mode == capi.WR_USB:
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (c, b)
+            else:
+                assert np.abs(ga - wa).max() <= AUDIO_ATOL, (c, b)
+    t.destroy()

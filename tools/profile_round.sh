@@ -24,26 +24,31 @@ with open(R + '/gpurun_out/%s_kernel_stats.csv' % r, 'w') as f:
         short = name.split('(')[0][:90]          # torch's generator kernels have page-long names
         w.writerow([short, x['Calls'], x['TotalDurationNs'], x['AverageNs'], x['Percentage'], x['MinNs'], x['MaxNs']])
 PY
-# the timed region alone: the last `steps` launches of the dominant kernel (the ones before them are
-# warm-up and the clock-settling steps, see bench.py --settle-ms)
-python3 - "$round" 60 <<'PY'
-import csv, sys, glob, os
-r, steps = sys.argv[1], int(sys.argv[2]); R = os.environ['GRAFT_REPO_ROOT']
+# by launch shape: with bench.py's default --blocks-per-launch 4 the dominant kernel runs with the grid of a
+# 16 M-frame launch (headline) and, in secondary.c2_one_block_per_launch, with the grid of a 4 M-frame launch.
+# Each shape's timed region is its last launches (before them: warm-up and the clock-settling steps, see
+# bench.py --settle-ms): the last 15 are reported beside the mean over all.
+python3 - "$round" <<'PY'
+import csv, sys, glob, os, collections
+r = sys.argv[1]; R = os.environ['GRAFT_REPO_ROOT']
 rows = []
 for f in glob.glob('/tmp/prof_%s/**/*kernel_trace.csv' % r, recursive=True):
     for x in csv.DictReader(open(f)):
-        rows.append((int(x['Start_Timestamp']), x['Kernel_Name'].split('(')[0].replace('void ', ''), (int(x['End_Timestamp']) - int(x['Start_Timestamp']))))
+        rows.append((int(x['Start_Timestamp']), x['Kernel_Name'].split('(')[0].replace('void ', ''),
+                     int(x.get('Grid_Size_X', x.get('Grid_Size', 0)) or 0) // max(1, int(x.get('Workgroup_Size_X', x.get('Workgroup_Size', 1)) or 1)),
+                     int(x['End_Timestamp']) - int(x['Start_Timestamp'])))
 rows.sort()
+g = collections.OrderedDict()
+for _, name, wgs, d in rows:
+    if name.startswith('k_'):
+        g.setdefault((name, wgs), []).append(d)
 with open(R + '/gpurun_out/%s_kernel_stats_timed.csv' % r, 'w') as f:
-    w = csv.writer(f); w.writerow(['Name', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'what'])
-    for name in sorted(set(n for _, n, _ in rows if n.startswith('k_'))):
-        d = [v for _, n, v in rows if n == name]
-        if name.startswith('k_tuner_ddc') and len(d) > steps + 2:
-            d = d[-(steps + 1):-1] if name.endswith('5u>') else d
-            what = 'timed region: the last %d launches' % len(d)
-        else:
-            what = 'all launches'
-        w.writerow([name, len(d), '%.1f' % (sum(d) / len(d)), min(d), max(d), what])
+    w = csv.writer(f); w.writerow(['Name', 'Workgroups', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'Last15AverageNs'])
+    for (name, wgs), d in sorted(g.items()):
+        if len(d) < 3 and not name.startswith('k_fft'):
+            continue
+        last = d[-16:-1] if len(d) > 40 else d
+        w.writerow([name, wgs, len(d), '%.1f' % (sum(d) / len(d)), min(d), max(d), '%.1f' % (sum(last) / len(last))])
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
@@ -55,10 +60,13 @@ acc = collections.defaultdict(list)
 for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0][:60]
+        wgs = int(row.get('Grid_Size', 0) or 0) // max(1, int(row.get('Workgroup_Size', 1) or 1))
         if k.startswith(('k_', 'void k_')):
-            acc[k].append(float(row['Counter_Value']))
+            acc['%s [%d workgroups]' % (k, wgs)].append(float(row['Counter_Value']))
 with open(R + '/gpurun_out/%s_pmc_%s.txt' % (r, c.lower()), 'w') as out:
-    for k, v in acc.items():
+    for k, v in sorted(acc.items()):
+        if len(v) < 3 and 'k_fft' not in k:
+            continue
         out.write('%s %s mean=%.1f KB per launch (n=%d)\n' % (k, c, sum(v) / len(v), len(v)))
 PY
 done

@@ -14,7 +14,7 @@ x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
 t = Tuner(dev, fs, 256, n, capi.WR_NCO_ROTATE)
 for f in ifs:
     t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
-for _ in range(6):
+for _ in range(int(os.environ.get('TL_WARM', '6'))):
     t.submit_device(x, n)
 torch.cuda.synchronize()
 lib = C.CDLL(capi.LIB_PATH)
@@ -50,3 +50,18 @@ if nA:
     stat("prologue, post-tile workgroups", (tl[:, 1] - tl[:, 0])[:nA])
 print("kernel span (ticks): %d" % (tl[:, 11].max() - t0))
 t.destroy()
+
+# the post-stage tenants (previous block's demod + audio filter in extra workgroups of the launch)
+pb = np.zeros(8192 * 4, dtype=np.uint64)
+try:
+    rc = lib.wr_debug_timeline_post(pb.ctypes.data_as(C.c_void_p), C.c_size_t(pb.size))
+    pt = pb.reshape(8192, 4).astype(np.int64)
+    pt = pt[pt[:, 0] > 0]
+    print("post waves stamped", pt.shape[0])
+    stat("post: wave start - first start", pt[:, 0] - t0)
+    stat("post: stage phase (loads + demod)", pt[:, 1] - pt[:, 0])
+    stat("post: filter phase", pt[:, 2] - pt[:, 1])
+    stat("post: audio write", pt[:, 3] - pt[:, 2])
+    stat("post: wave end - first start", pt[:, 3] - t0)
+except AttributeError:
+    pass

@@ -109,6 +109,7 @@ struct Group {
 	bool dirty;                /* parameters must be uploaded before the next launch */
 	bool uniform_taps;         /* each 64-slot lane group uses one channel-filter tap set */
 	unsigned long long uniform_mask = 0; /* bit i: lane group i does */
+	unsigned long long uniform2_mask = 0; /* bit i: the channels of lane group i share one AUDIO filter */
 	unsigned long long fewsets_mask = 0; /* bit i: lane group i has at most WR_TAPSETS distinct channel filters
 	                                        (the others take the per-lane-taps kernel) */
 	unsigned char nsets[64] = {0};       /* how many */
@@ -583,6 +584,7 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.taps2);
 	(void)hipFree(g->dev.rot);
 	(void)hipFree(g->dev.taps1u);
+	(void)hipFree(g->dev.taps2u);
 	(void)hipFree(g->dev.tapsel);
 	(void)hipFree(g->dev.taps1b);
 	(void)hipFree(g->dev.iq2_hist[0]);
@@ -637,6 +639,7 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
 	if (!rc) rc = dev_alloc_zero(&g->dev.rot, S * 4);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S * WR_TAPSETS);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps2u, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.tapsel, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.gain, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.squelch, S);
@@ -1214,6 +1217,28 @@ static int group_upload(wr_tuner *t, Group *g)
 		else
 			uniform = false;
 	}
+	/* the audio filter likewise (one per lane group or the per-lane path; its taps go through the
+	 * scalar cache, see post_role) */
+	std::vector<float> taps2u(S, 0.0f);
+	unsigned long long u2mask = 0;
+	for (size_t base = 0; base < S && base / WR_LANES < 64; base += WR_LANES) {
+		int rep = -1;
+		bool same = true;
+		for (size_t s = base; s < base + WR_LANES && same; ++s) {
+			int ci = g->owner[s];
+			if (ci < 0)
+				continue;
+			if (rep < 0)
+				rep = ci;
+			else
+				same = !memcmp(t->chans[ci].taps[1], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH);
+		}
+		if (!same || rep < 0)
+			continue;
+		memcpy(&taps2u[base], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH);
+		u2mask |= 1ull << (base / WR_LANES);
+	}
+	g->uniform2_mask = u2mask;
 	g->uniform_taps = uniform;
 	g->uniform_mask = umask;
 	g->fewsets_mask = fmask;
@@ -1237,6 +1262,7 @@ static int group_upload(wr_tuner *t, Group *g)
 	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1u, taps1u.data(), taps1u.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g->dev.taps2u, taps2u.data(), taps2u.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.tapsel, tapsel.data(), tapsel.size() * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.gain, gain.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.squelch, squelch.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1467,6 +1493,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		L.k2max = g->k2max;
 		L.nco_mode = t->nco_mode;
 		L.uniform_mask = g->uniform_mask;
+		L.uniform2_mask = g->uniform2_mask;
 		L.fewsets_mask = g->fewsets_mask;
 		memcpy(L.nsets, g->nsets, sizeof(L.nsets));
 		L.audio_scale = t->audio_scale;

@@ -43,6 +43,8 @@ struct WrGroupDev {
 	int          *mode;         /* wr_mode, or -1 for an idle slot (what the post-DDC kernels test) */
 	float        *taps1;        /* [64][slots] channel-filter taps, taps1[j*slots+s] = coeff[j] */
 	float        *taps2;        /* [64][slots] audio-filter taps */
+	float        *taps2u;       /* [lane groups][64] the group's one audio filter, where its channels share one
+	                               (WrTunerLaunch::uniform2_mask) */
 	/* what a DDC wave needs before its first tap, laid out so that it is ONE coalesced load each (a
 	 * wave that gathers them -- 64 tap rows, four table entries per lane -- queues 320 cache-line
 	 * requests behind the other 31 waves of its CU, and every wave of the launch does so at once) */
@@ -85,6 +87,7 @@ struct WrTunerLaunch {
 	float        audio_scale;   /* multiplies the audio on store (1 = as the reference) */
 	int          use_gain, use_squelch;   /* some channel has an af_gain / a squelch threshold set */
 	unsigned long long uniform_mask;   /* bit g: all channels of lane group g share ONE channel filter */
+	unsigned long long uniform2_mask;  /* bit g: ... and ONE audio filter (WrGroupDev::taps2u) */
 	unsigned long long fewsets_mask;   /* bit g: lane group g has at most WR_TAPSETS distinct channel filters */
 	unsigned char nsets[64];           /* distinct channel filters of lane group g (valid where fewsets_mask says) */
 	void        *ev_start, *ev_stop;   /* hipEvent_t pair the DDC launch itself stamps (profiling), or NULL */
@@ -112,8 +115,12 @@ struct WrPostArgs {
 	const float *dem_hist;       /* [63][slots] audio filter history */
 	float       *dem_hist_next;
 	size_t       k2;
-	unsigned int ntiles;         /* tiles of POST_TK audio frames per lane group */
+	unsigned int tiles;          /* tiles of POST_TK audio frames per lane group */
+	unsigned int run;            /* consecutive tiles one workgroup takes */
+	unsigned int ntiles;         /* workgroups per lane group = ceil(tiles / run), plus the one that writes the state */
 	const float *taps2;
+	const float *taps2u;         /* [groups][64], read through the scalar cache */
+	unsigned long long uni2;     /* bit g: lane group g's channels share one audio filter (taps2u) */
 	float       *audio;
 	size_t       k2max;
 	float        scale;

@@ -32,6 +32,9 @@ typedef __attribute__((address_space(3))) v4f lds_v4f;
 
 #define PHASE_FLAG_ACTIVE   1
 
+/* loads through this address space are scalar (s_load) whenever the address is wave-uniform */
+#define WR_CONSTANT __attribute__((address_space(4)))
+
 #ifdef DDC_TIMELINE
 /* development aid (tools/mkvariant.sh ... -DDDC_TIMELINE): per-wave s_memtime stamps of k_tuner_ddc */
 #define TL_SLOTS 12
@@ -41,8 +44,17 @@ extern "C" int wr_debug_timeline(unsigned long long *out, size_t n)
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_tl), n * sizeof(unsigned long long));
 }
 #define TL(slot) do { if (lane == 0 && wid < 16384u && (slot) < TL_SLOTS) g_ddc_tl[wid * TL_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+/* the post-stage tenants of the same launch: wave start, stage phase done, filter done, wave end (of
+ * the last tile of a run) */
+__device__ unsigned long long g_post_tl[8192 * 4];
+extern "C" int wr_debug_timeline_post(unsigned long long *out, size_t n)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_post_tl), n * sizeof(unsigned long long));
+}
+#define TLP(slot) do { const unsigned int pw_ = (bx + g * (A.ntiles + 1u)) * NROW + row; if (lane == 0 && pw_ < 8192u) g_post_tl[pw_ * 4u + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TL(slot) do { } while (0)
+#define TLP(slot) do { } while (0)
 #endif
 
 /* ------------------------------------------------------------------------- */
@@ -411,6 +423,12 @@ __device__ __forceinline__ float2 input_frame(const float2 *__restrict__ cur, co
 #define POST_TK 16u
 #endif
 #define POST_B 4u
+#ifndef POST_LB
+#define POST_LB 5u                       /* rows whose loads a wave of the stage phase has in flight together (measured
+                                            at C2, us per block at 1 / 4 blocks per launch: 3 rows 34.7 / 30.5, 5 rows
+                                            34.0 / 29.7, 6 rows 35.0 / 31.3, 9 rows 35.7 / 31.0 -- more rows, more
+                                            registers: spills) */
+#endif
 #define POST_THREADS 512u
 /* What leaves the audio filter for the sink: af_gain and squelch (the reference has the two fields
  * and no code behind them, receiverhandler.cxx:112,118-119,127), then the sink's scale.
@@ -465,7 +483,7 @@ __device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, un
  * [POST_TK][65] floats. */
 template <unsigned int D2, bool HREGS>
 __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, unsigned int g,
-                                          float *stage, float *tile)
+                                          float *stage, float *tile, int *modes)
 {
 	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
 	constexpr unsigned int NROW = POST_THREADS / 64u;
@@ -491,8 +509,7 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 		return;
 	}
 
-	const size_t kbase = (size_t)bx * POST_TK;
-	const size_t r0 = kbase * D2;
+	TLP(0);
 	/* the filter waves fetch their taps first: the latency hides behind the stage phase */
 	float h[HREGS ? WR_FIR_LENGTH : 1];
 	if (HREGS && row < POST_TK / POST_B) {
@@ -500,82 +517,155 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 		for (int j = 0; j < (HREGS ? WR_FIR_LENGTH : 1); ++j)
 			h[j] = taps2[(size_t)j * slots + s];
 	}
-	{
-		/* a run of consecutive rows per thread: each channel frame is loaded once and stays in a
-		 * register as the next row's predecessor */
-		constexpr unsigned int PER = (NEED + NROW - 1u) / NROW;
-		const unsigned int beg = row * PER;
-		const unsigned int end = (beg + PER < NEED) ? beg + PER : NEED;
-		float2 zp = make_float2(0.0f, 0.0f);
-		if (m >= 0 && beg < end) {
-			const size_t rr = r0 + beg;
-			if (rr == WR_HIST)
-				zp = prev_iq[s];
-			else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
-				zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
+	/* A.run consecutive tiles per workgroup: the last NEED - FRESH staged rows of a tile are the
+	 * first rows of the next one and stay in LDS (moved down), so that only a run's first tile
+	 * demodulates its 64 - D2 rows of overlap a second time (one tile per workgroup: 139 rows
+	 * demodulated for every 80 new ones at D2 = 5) */
+	if (row == 0)
+		modes[lane] = m;                                /* for the audio write: no memory round trip there */
+	constexpr unsigned int FRESH = POST_TK * D2;
+	constexpr unsigned int CARRY = NEED - FRESH;
+	constexpr unsigned int CARRY_PER = (CARRY * 64u + POST_THREADS - 1u) / POST_THREADS;
+	for (unsigned int tt = 0; tt < A.run; ++tt) {
+		const unsigned int tl = bx * A.run + tt;
+		if (tl >= A.tiles)
+			break;
+		const size_t kbase = (size_t)tl * POST_TK;
+		const size_t r0 = kbase * D2;
+		unsigned int first = 0;
+		if (tt) {
+			/* (the barrier that ended the previous tile's filter phase is behind us: nobody reads
+			 * the stage any more) */
+			float keep[CARRY_PER];
+#pragma unroll
+			for (unsigned int i = 0; i < CARRY_PER; ++i) {
+				const unsigned int e = threadIdx.x + i * POST_THREADS;
+				keep[i] = (e < CARRY * 64u) ? stage[FRESH * 64u + e] : 0.0f;
+			}
+			__syncthreads();                            /* source and destination overlap when FRESH < CARRY */
+#pragma unroll
+			for (unsigned int i = 0; i < CARRY_PER; ++i) {
+				const unsigned int e = threadIdx.x + i * POST_THREADS;
+				if (e < CARRY * 64u)
+					stage[e] = keep[i];
+			}
+			first = CARRY;
 		}
+		{
+			/* a run of consecutive rows per wave: each channel frame is loaded once and stays in a
+			 * register as the next row's predecessor */
+			const unsigned int per = (NEED - first + NROW - 1u) / NROW;
+			const unsigned int beg = first + row * per;
+			const unsigned int end = (beg + per < NEED) ? beg + per : NEED;
+			if (r0 > WR_HIST && r0 + NEED <= (size_t)k1 + WR_HIST) {
+				/* every row is a frame of this block and so is its predecessor (all tiles but a
+				 * block's first and last): the loads of POST_LB rows go out together, nothing to
+				 * decide per row -- the stage phase is a chain of memory round trips, and one per
+				 * row made the post workgroups the last to finish */
+				const float2 *__restrict__ src = chan_iq + (r0 - WR_HIST) * slots + s;
+				for (unsigned int r = beg; r < end; r += POST_LB) {
+					float2 z[POST_LB + 1u];
+					z[0] = src[((size_t)r - 1u) * slots];
+#pragma unroll
+					for (unsigned int i = 0; i < POST_LB; ++i) {
+						const unsigned int ri = (r + i < end) ? r + i : end - 1u;
+						z[i + 1u] = src[(size_t)ri * slots];
+					}
+#pragma unroll
+					for (unsigned int i = 0; i < POST_LB; ++i)
+						if (r + i < end)
+							stage[(r + i) * 64u + lane] = (m >= 0) ? demod_one(m, z[i + 1u].x, z[i + 1u].y, z[i].x, z[i].y) : 0.0f;
+				}
+			} else {
+				float2 zp = make_float2(0.0f, 0.0f);
+				if (m >= 0 && beg < end) {
+					const size_t rr = r0 + beg;
+					if (rr == WR_HIST)
+						zp = prev_iq[s];
+					else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
+						zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
+				}
 #pragma unroll 6
-		for (unsigned int r = beg; r < end; ++r) {
-			const size_t rr = r0 + r;
-			float v = 0.0f;
-			if (m >= 0) {
-				if (rr < WR_HIST) {
-					v = dem_hist[rr * slots + s];
-					if (rr + 1u == WR_HIST)
-						zp = prev_iq[s];                    /* the next row is the block's first frame */
-				} else if (rr - WR_HIST < k1) {
-					const float2 z = chan_iq[(rr - WR_HIST) * slots + s];
-					v = demod_one(m, z.x, z.y, zp.x, zp.y);
-					zp = z;
+				for (unsigned int r = beg; r < end; ++r) {
+					const size_t rr = r0 + r;
+					float v = 0.0f;
+					if (m >= 0) {
+						if (rr < WR_HIST) {
+							v = dem_hist[rr * slots + s];
+							if (rr + 1u == WR_HIST)
+								zp = prev_iq[s];                    /* the next row is the block's first frame */
+						} else if (rr - WR_HIST < k1) {
+							const float2 z = chan_iq[(rr - WR_HIST) * slots + s];
+							v = demod_one(m, z.x, z.y, zp.x, zp.y);
+							zp = z;
+						}
+					}
+					stage[r * 64u + lane] = v;
 				}
 			}
-			stage[r * 64u + lane] = v;
 		}
-	}
-	__syncthreads();
-	if (row < POST_TK / POST_B) {
-		float acc[POST_B];
+		__syncthreads();
+		TLP(1);
+		if (row < POST_TK / POST_B) {
+			float acc[POST_B];
 #pragma unroll
-		for (unsigned int o = 0; o < POST_B; ++o)
-			acc[o] = 0.0f;
-		const float *x = stage + (row * POST_B * D2) * 64u + lane;
-		if (HREGS) {
-			/* rows outermost: each staged row is read from LDS once and meets the tap of every
-			 * frame of the group that uses it (which tap: resolved at compile time) */
+			for (unsigned int o = 0; o < POST_B; ++o)
+				acc[o] = 0.0f;
+			const float *x = stage + (row * POST_B * D2) * 64u + lane;
+			if (HREGS) {
+				/* rows outermost: each staged row is read from LDS once and meets the tap of every
+				 * frame of the group that uses it (which tap: resolved at compile time) */
 #pragma unroll
-			for (unsigned int r = 0; r < (POST_B - 1u) * D2 + WR_FIR_LENGTH; ++r) {
-				const float xv = x[r * 64u];
+				for (unsigned int r = 0; r < (POST_B - 1u) * D2 + WR_FIR_LENGTH; ++r) {
+					const float xv = x[r * 64u];
 #pragma unroll
-				for (unsigned int o = 0; o < POST_B; ++o) {
-					if (r >= o * D2 && r - o * D2 < WR_FIR_LENGTH)
-						acc[o] = acc[o] + h[HREGS ? WR_FIR_LENGTH - 1u - (r - o * D2) : 0] * xv;
+					for (unsigned int o = 0; o < POST_B; ++o) {
+						if (r >= o * D2 && r - o * D2 < WR_FIR_LENGTH)
+							acc[o] = acc[o] + h[HREGS ? WR_FIR_LENGTH - 1u - (r - o * D2) : 0] * xv;
+					}
 				}
-			}
-		} else {
-			/* taps outermost, newest tap last (so that every frame still adds its products
-			 * oldest row first): one memory read per tap, shared by the frames of the group; the
-			 * rows come from LDS once per frame */
+			} else {
+				/* taps outermost, newest tap last (so that every frame still adds its products
+				 * oldest row first): one memory read per tap, shared by the frames of the group; the
+				 * rows come from LDS once per frame */
+				if (g < 64u && ((A.uni2 >> g) & 1ull)) {
+					/* every channel of the lane group has the same audio filter (radio.cxx:78-79: the
+					 * usual case): its taps come through the scalar cache into SGPRs -- no vector
+					 * memory round trips behind the next block's DDC gathers in this phase at all */
+					const WR_CONSTANT float *tu = (const WR_CONSTANT float *)(A.taps2u + (size_t)g * WR_FIR_LENGTH);
+#pragma unroll
+					for (int j = WR_FIR_LENGTH - 1; j >= 0; --j) {
+						const float hj = tu[j];
+#pragma unroll
+						for (unsigned int o = 0; o < POST_B; ++o)
+							acc[o] = acc[o] + hj * x[(o * D2 + (WR_FIR_LENGTH - 1u - (unsigned int)j)) * 64u];
+					}
+				} else {
 #pragma unroll 16
-			for (int j = WR_FIR_LENGTH - 1; j >= 0; --j) {
-				const float hj = taps2[(size_t)j * slots + s];
+					for (int j = WR_FIR_LENGTH - 1; j >= 0; --j) {
+						const float hj = taps2[(size_t)j * slots + s];
 #pragma unroll
-				for (unsigned int o = 0; o < POST_B; ++o)
-					acc[o] = acc[o] + hj * x[(o * D2 + (WR_FIR_LENGTH - 1u - (unsigned int)j)) * 64u];
+						for (unsigned int o = 0; o < POST_B; ++o)
+							acc[o] = acc[o] + hj * x[(o * D2 + (WR_FIR_LENGTH - 1u - (unsigned int)j)) * 64u];
+					}
+				}
 			}
-		}
 #pragma unroll
-		for (unsigned int o = 0; o < POST_B; ++o)
-			tile[(row * POST_B + o) * 65u + lane] = acc[o];
-	}
-	__syncthreads();
-	/* transposed write: POST_TK consecutive frames of one slot per POST_TK threads */
-	for (unsigned int e = threadIdx.x; e < 64u * POST_TK; e += POST_THREADS) {
-		const unsigned int sl = e / POST_TK, kk = e - sl * POST_TK;
-		const unsigned int so = g * 64u + sl;
-		const size_t k = kbase + kk;
-		if (k < A.k2 && A.mode[so] >= 0)
-			A.audio[(size_t)so * A.k2max + k] = audio_out(tile[kk * 65u + sl], A.gain, A.squelch, chan_iq, slots, so, k, D2,
-			                                              A.scale);
+			for (unsigned int o = 0; o < POST_B; ++o)
+				tile[(row * POST_B + o) * 65u + lane] = acc[o];
+		}
+		__syncthreads();
+		TLP(2);
+		/* transposed write: POST_TK consecutive frames of one slot per POST_TK threads */
+		for (unsigned int e = threadIdx.x; e < 64u * POST_TK; e += POST_THREADS) {
+			const unsigned int sl = e / POST_TK, kk = e - sl * POST_TK;
+			const unsigned int so = g * 64u + sl;
+			const size_t k = kbase + kk;
+			if (k < A.k2 && modes[sl] >= 0)
+				A.audio[(size_t)so * A.k2max + k] = audio_out(tile[kk * 65u + sl], A.gain, A.squelch, chan_iq, slots, so, k, D2,
+				                                              A.scale);
+		}
+		TLP(3);
 	}
 }
 
@@ -586,7 +676,8 @@ k_tuner_post(WrPostArgs A)
 	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
 	__shared__ float stage[NEED * 64u];
 	__shared__ float tile[POST_TK * 65u];
-	post_role<D2, true>(A, blockIdx.x, blockIdx.y, stage, tile);
+	__shared__ int modes[64];
+	post_role<D2, true>(A, blockIdx.x, blockIdx.y, stage, tile, modes);
 }
 
 /* LDS plan of k_tuner_ddc: [0, 128 KiB) the two replicated NCO tables (SPLIT only),
@@ -600,6 +691,11 @@ k_tuner_post(WrPostArgs A)
 #define DDC_ROTATE_WGS_PER_CU 4u
 #endif
 #define DDC_LDS_BYTES     (DDC_TABLE_BYTES + DDC_WAVES * 2u * 512u)
+#ifndef DDC_DEAL_WAYS
+#define DDC_DEAL_WAYS 2u                   /* measured at C2, us per block at 1 / 4 blocks per launch: in order (and as
+                                              many workgroups as make the units come out even) 37.6 / 32.8, 2 ways
+                                              36.8 / 32.0, 4 ways 37.0 / 32.0, 8 ways 38.5 / 32.0 */
+#endif
 
 /* PD2 > 0: workgroups n_ddc.. of the grid run the post stage (audio decimation PD2) of the
  * PREVIOUS block -- see post_role and wr_capi.hip: the two have nothing to do with each other
@@ -630,7 +726,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		const unsigned int idx = blockIdx.x - n_ddc;
 		float *stage = (float *)lds;
 		post_role<(PD2 ? PD2 : 1u), false>(post, idx % (post.ntiles + 1u), idx / (post.ntiles + 1u), stage,
-		                                    stage + NEED * 64u);
+		                                    stage + NEED * 64u, (int *)(stage + NEED * 64u + POST_TK * 65u));
 		return;
 	}
 	const unsigned int lane = threadIdx.x & 63u;
@@ -695,8 +791,18 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	const unsigned int gl = LTAPS ? blockIdx.x % groups : wid % groups;
 	const unsigned int g = (unsigned int)(((gl < 8u ? gmap0 : gmap1) >> ((gl & 7u) * 8u)) & 255u);
 	unsigned int k = LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
-	if (k >= wpg)
+	if (k >= wpg) {
 		k = k1u;                                         /* the few waves left over stay idle */
+	} else if (!LTAPS && DDC_DEAL_WAYS > 1u) {
+		/* A wave that starts at k does ceil((k1 - k) / wpg) units: the low starts one more than the
+		 * high ones.  Neighbouring waves take their starts from DDC_DEAL_WAYS different parts of
+		 * [0, wpg) in turn, so that every workgroup -- and with it every SIMD: its waves go round
+		 * the four -- gets its share of the long and of the short ones.  (Dealt in order, the first
+		 * workgroups of the grid had all the long waves, and whole CUs one round more than others.) */
+		const unsigned int r = k % DDC_DEAL_WAYS, q = k / DDC_DEAL_WAYS;
+		const unsigned int fl_ = wpg / DDC_DEAL_WAYS, rem = wpg % DDC_DEAL_WAYS;
+		k = r * fl_ + (r < rem ? r : rem) + q;
+	}
 	const float *ltaps = (const float *)(lds + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N : 0u) + waves_per_wg * 128u * nset);
 	if (LTAPS) {
 		float *lt = (float *)(lds + 2u * WR_SPLIT_N + waves_per_wg * 128u * nset);
@@ -805,6 +911,9 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 				csq[q] = nco<NCO>(P0 + (unsigned int)(q * ROT_SEG + ROT_SEG - 1) * st, table, hi_l, lo_l);
 		}
 #ifdef DDC_PREFETCH2
+		/* (the copy waits for the load issued one unit ago: the second slot buys little more than the
+		 * first.  Alternating two slots in a loop unrolled by two -- no copy -- spills under the
+		 * 64-VGPR bound and was slower, r02) */
 		xnext = xnext2;
 		if (kn + wpg < k1u)
 			xnext2 = window_sample(kn + wpg);
@@ -1404,7 +1513,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		 * post workgroups at priority 3): 1 slot 38.2 us, 2 slots 39.7, 3 slots 49.8 (the DDC
 		 * starves); DDC + post as two launches: 31.3 + 15.2 + gap. */
 		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
-		const size_t post_lds = ((size_t)NEED * 64u + POST_TK * 65u) * sizeof(float);
+		const size_t post_lds = ((size_t)NEED * 64u + POST_TK * 65u + 64u) * sizeof(float);
 		if (post_lds > lds)
 			lds = post_lds;
 		unsigned int fit = (unsigned int)((160u * 1024u) / lds);
@@ -1422,8 +1531,8 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	unsigned int wgs = (unsigned int)((units + W - 1) / W);
 	const unsigned int cap = (unsigned int)num_cus * wgs_per_cu;
 	if (wgs > cap) {
-#ifdef DDC_FILL_ALL_SLOTS
-		wgs = cap;
+#if DDC_DEAL_WAYS > 1u
+		wgs = cap;                                     /* every slot: the kernel evens the units out (DDC_DEAL_WAYS) */
 #else
 		/* as many workgroups as make the units come out EVEN: with every slot filled (6 144 waves for
 		 * C2's 40 000 units: 6.5 units per wave) half the waves take one unit more than the others
@@ -1561,8 +1670,22 @@ WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G)
 	A.dem_hist = G.dem[p];
 	A.dem_hist_next = G.dem[p ^ 1];
 	A.k2 = L.k2;
-	A.ntiles = (unsigned int)((L.k2 + POST_TK - 1) / POST_TK);
+	A.tiles = (unsigned int)((L.k2 + POST_TK - 1) / POST_TK);
+	/* tiles per workgroup: as long a run as still leaves every CU a few workgroups */
+	{
+		const unsigned int all = A.tiles * (L.slots_used / 64u);
+#ifdef POST_RUN
+		A.run = POST_RUN;
+#else
+		/* measured at C2 (500 tiles a block), us per block: 1 block per launch, run 1 / 2 / 4:
+		 * 38.3 / 37.1 / 38.0; 4 blocks per launch: 33.6 / 32.3 / 32.2 */
+		A.run = all >= 1536u ? 4u : all >= 384u ? 2u : 1u;
+#endif
+	}
+	A.ntiles = (A.tiles + A.run - 1u) / A.run;
 	A.taps2 = G.taps2;
+	A.taps2u = G.taps2u;
+	A.uni2 = L.uniform2_mask;
 	A.audio = G.audio;
 	A.k2max = L.k2max;
 	A.scale = L.audio_scale;
