@@ -281,3 +281,35 @@ def test_blocks_per_launch_gives_the_same_bits(dev, oracle, nco):
     keep = np.r_[0:6 * k2, 7 * k2:9 * k2]
     assert cut.shape[1] == 8 * k2
     assert np.array_equal(every[:, keep].view(np.uint32), cut.view(np.uint32))
+
+
+def test_blocks_per_launch_at_c2_size(dev):
+    """bench.py's configuration: 256 receivers, 4 M-frame blocks off 100 Msps, four blocks per launch
+    (ROTATE, the post stage in runs of four tiles riding in the next launch).  Eight consecutive
+    resident blocks through a tuner that launches each on its own and through one that joins four:
+    every audio sample of every receiver is the same bits."""
+    import torch
+    c2 = synth.C2
+    fs, n = c2["input_rate"], c2["block_frames"]
+    ifs = synth.c2_ifs()
+    nblk, B = 8, 4
+    x = synth.fm_stream_torch(n * nblk, fs, ifs[::4], "cuda")
+    torch.cuda.synchronize()
+
+    def run(join):
+        t = Tuner(dev, fs, 256, n * B, capi.WR_NCO_ROTATE)
+        for f in ifs:
+            t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
+        t.blocks_per_launch(B if join else 1)
+        out = []
+        for b in range(nblk):
+            t.submit_device(x[2 * n * b: 2 * n * (b + 1)], n)
+            if not join or b % B == B - 1:
+                out.append(t.fetch_audio_all().copy())
+        t.destroy()
+        return np.concatenate(out, axis=1)
+
+    one, four = run(False), run(True)
+    assert one.shape == four.shape == (256, nblk * n // 400 // 5)
+    assert np.array_equal(one.view(np.uint32), four.view(np.uint32))
+    assert float(np.abs(one[::4]).max()) > 0.0                  # the carrier channels carry audio
