@@ -12,8 +12,8 @@ mkdir -p $O
 cd $R
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${round}_bench_driver_flags.json 2> /dev/null
 timeout 300 python bench.py --workload c5 --steps 30 --warmup 4 > $O/${round}_c5_1gpu.json 2> /dev/null
-( timeout 200 tests/cxx/host_bench 256 30; WEBRADIO_AUDIO_LATE=1 timeout 200 tests/cxx/host_bench 256 30 ) > $O/${round}_host_bench.txt 2>&1
-( echo "== QT_ONE_ODD=1"; QT_ONE_ODD=1 QT_REPS=400 QT_BLOCKS=12 QT_PROFILE=0 timeout 200 bash tools/kstats.sh python $R/tools/quick_time.py 256 rotate
-  echo "== QT_MIXED=1";   QT_MIXED=1 QT_REPS=400 QT_BLOCKS=12 QT_PROFILE=0 timeout 200 bash tools/kstats.sh python $R/tools/quick_time.py 256 rotate ) > $O/${round}_mixed_passbands.txt 2>&1
+( timeout 200 tests/cxx/host_bench 256 30; WEBRADIO_AUDIO_LATE=1 timeout 200 tests/cxx/host_bench 256 30 ) 2>&1 | grep -E "^\{|^process\(\)" > $O/${round}_host_bench.txt
+( echo "== QT_ONE_ODD=1"; QT_ONE_ODD=1 QT_REPS=1600 QT_BLOCKS=12 QT_PROFILE=0 timeout 200 bash tools/kstats.sh python $R/tools/quick_time.py 256 rotate
+  echo "== QT_MIXED=1";   QT_MIXED=1 QT_REPS=1600 QT_BLOCKS=12 QT_PROFILE=0 timeout 200 bash tools/kstats.sh python $R/tools/quick_time.py 256 rotate ) > $O/${round}_mixed_passbands.txt 2>&1
 timeout 300 bash tools/clock_ramp.sh > $O/${round}_clock_ramp.txt 2>&1
 cut -c1-300 $O/${round}_bench_driver_flags.json; cut -c1-300 $O/${round}_c5_1gpu.json; cat $O/${round}_host_bench.txt $O/${round}_mixed_passbands.txt; cat $O/${round}_clock_ramp.txt

@@ -6,11 +6,12 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/ks -o ks -- "$@" > /tmp/ks.
 python3 - <<'PY'
 import csv, glob, collections
 d = collections.defaultdict(list)
-for f in glob.glob('/tmp/ks/*kernel_trace.csv'):
+for f in sorted(glob.glob('/tmp/ks/**/*kernel_trace.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
         d[r['Kernel_Name'].split('(')[0].replace('void ', '')[:40]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     if k.startswith('k_'):
         v2 = sorted(v)
-        print('%-40s n=%3d  median %.1f  min %.1f  max %.1f us' % (k, len(v), v2[len(v2) // 2], v2[0], v2[-1]))
+        last = sorted(v[-200:])                  # in launch order: the steady state of a long run (clock ramp, see bench.py --settle-ms)
+        print('%-40s n=%4d  median %.1f  min %.1f  max %.1f us   last %d launches: median %.1f' % (k, len(v), v2[len(v2) // 2], v2[0], v2[-1], len(last), last[len(last) // 2]))
 PY
