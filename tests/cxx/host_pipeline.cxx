@@ -51,6 +51,22 @@ protected:
 
 Tuner *makeTuner(const string &name) { return new ReplayTuner(name); }
 
+/* a sink that keeps what it is handed (any channel count) */
+class TapSink : public DspBlock {
+public:
+	TapSink() : DspBlock("tap", "TapSink") {}
+	vector<float> got;
+	vector<unsigned int> sizes;
+protected:
+	bool init() { return true; }
+	void deinit() {}
+	bool process(const vector<sample_t> &in, vector<sample_t> &) {
+		got.insert(got.end(), in.begin(), in.end());
+		sizes.push_back((unsigned int)in.size());
+		return true;
+	}
+};
+
 } // namespace
 
 extern "C" {
@@ -481,6 +497,68 @@ int wr_host_run_rerate(const float *iq, size_t nframes, unsigned int rate1, unsi
 	for (size_t n = 0; n < rx.size(); n++)
 		delete rx[n];
 	delete fe;
+	return rc;
+}
+
+/* a second consumer attached INSIDE a fused chain while it runs (here: a tap on receiver
+ * 0's demodulator after `tap_at` blocks, the way a per-receiver scope would be).  The fusion had
+ * elided that block's host output; DspBlock::connect takes the chain out of the tuner batch, it goes
+ * on block by block (filters from empty histories), the other receivers stay fused.
+ * tap_out receives what the tap was handed (tap_cap floats at most), *tap_len its length,
+ * *tap_blocks the number of process() calls it saw. */
+int wr_host_run_tap(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
+                    unsigned int nrx, const int *if_hz, int mode,
+                    unsigned int chan_passband, unsigned int chan_rate,
+                    unsigned int audio_passband, unsigned int audio_rate, unsigned int tap_at,
+                    float *audio_out, size_t audio_cap, size_t *audio_len,
+                    float *tap_out, size_t tap_cap, size_t *tap_len, unsigned int *tap_blocks)
+{
+	g_iq = iq;
+	g_frames = nframes;
+	g_pos = 0;
+	FrontEnd *fe = new FrontEnd(makeTuner);
+	fe->tuner()->setSampleRate(rate);
+	fe->tuner()->setChannels(2);
+	fe->tuner()->setBlockSize(block_frames * 2);
+	std::vector<Receiver *> rx;
+	for (unsigned int n = 0; n < nrx; n++) {
+		Receiver *r = new Receiver();
+		r->downconverter()->setIF(if_hz[n]);
+		r->channelFilter()->setPassband(chan_passband);
+		r->channelFilter()->setOutputSampleRate(chan_rate);
+		r->audioFilter()->setPassband(audio_passband);
+		r->audioFilter()->setOutputSampleRate(audio_rate);
+		r->demodulator()->setMode((Demodulator::Mode)mode);
+		r->stream()->setCapacity(audio_cap);
+		r->setFrontEnd(fe);
+		rx.push_back(r);
+	}
+	TapSink *tap = new TapSink();
+	int rc = fe->tuner()->start() ? 0 : -1;
+	const size_t blocks = nframes / block_frames;
+	for (size_t b = 0; b < blocks && rc == 0; b++) {
+		if (b == tap_at && nrx)
+			rx[0]->demodulator()->connect(tap);
+		if (!fe->tuner()->run())
+			rc = -4;
+	}
+	*audio_len = 0;
+	for (size_t n = 0; n < rx.size() && rc == 0; n++) {
+		const vector<float> &a = rx[n]->stream()->samples();
+		if (a.size() > audio_cap) { rc = -2; break; }
+		memcpy(audio_out + n * audio_cap, a.data(), a.size() * sizeof(float));
+		*audio_len = a.size();
+	}
+	*tap_len = tap->got.size() < tap_cap ? tap->got.size() : tap_cap;
+	memcpy(tap_out, tap->got.data(), *tap_len * sizeof(float));
+	*tap_blocks = (unsigned int)tap->sizes.size();
+	fe->tuner()->stop();
+	if (nrx)
+		rx[0]->demodulator()->disconnect(tap);
+	for (size_t n = 0; n < rx.size(); n++)
+		delete rx[n];
+	delete fe;
+	delete tap;
 	return rc;
 }
 

@@ -495,3 +495,56 @@ def test_two_lowpass_stages_in_a_row_ride_the_tuner_batch(tmp_path, oracle, fuse
     want = np.concatenate(want)
     assert int(r["n"]) == want.size
     assert np.array_equal(r["audio"].view(np.uint32), want.view(np.uint32))
+
+
+TAP_RUNNER = r"""
+import ctypes as C, sys, numpy as np
+lib, npz = sys.argv[1], sys.argv[2]
+import torch
+L = C.CDLL(lib, mode=C.RTLD_GLOBAL)
+d = np.load(npz)
+iq = np.ascontiguousarray(d["iq"], np.float32); ifs = np.ascontiguousarray(d["ifs"], np.int32); p = [int(v) for v in d["params"]]
+nrx = ifs.size; cap = p[8]; tcap = p[9]
+audio = np.zeros((nrx, cap), np.float32); n = C.c_size_t(); tap = np.zeros(tcap, np.float32); tn = C.c_size_t(); tb = C.c_uint()
+fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+L.wr_host_run_tap.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, ip, C.c_int] + [C.c_uint] * 5 + [fp, C.c_size_t, C.POINTER(C.c_size_t), fp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint)]
+rc = L.wr_host_run_tap(iq.ctypes.data_as(fp), iq.size // 2, p[0], p[1], nrx, ifs.ctypes.data_as(ip), p[2], p[3], p[4], p[5], p[6], p[7],
+                       audio.ctypes.data_as(fp), cap, C.byref(n), tap.ctypes.data_as(fp), tcap, C.byref(tn), C.byref(tb))
+np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], tap=tap[:tn.value], tap_blocks=tb.value, left=L.wr_host_registry_sizes())
+"""
+
+
+def test_second_consumer_inside_a_fused_chain(tmp_path, oracle):
+    """attaching a consumer to a block inside a fused Receiver chain used to hand it the
+    empty, elided vector, and the source's run() failed.  Three receivers (USB), six blocks; before
+    block 2 a tap is connected to receiver 0's demodulator.  Receiver 0 leaves the tuner batch there
+    and goes on block by block with its NCO phase and its filters restarted empty: the tap gets every
+    demodulated block from then on, the audio equals the oracle's for a receiver whose two filters
+    are fresh at block 2; receivers 1 and 2 stay fused and are the oracle's bits throughout."""
+    lib = os.path.join(CXXT, "libwr_host_pipeline.so")
+    ifs, mode, rate, block, nblk, tap_at = [50_000, -75_000, 4321], 2, 2_000_000, 40_000, 6, 2
+    iq = synth.fm_stream(nblk * block, rate, ifs, amp=0.2)
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    cap, tcap = 4096, 1 << 16
+    np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
+             params=np.array([rate, block, mode, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], tap_at, cap, tcap], np.int64))
+    subprocess.check_call([sys.executable, "-c", TAP_RUNNER, lib, inp, out],
+                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
+    r = np.load(out)
+    assert int(r["rc"]) == 0 and int(r["left"]) == 0
+    blocks = [iq[2 * b * block: 2 * (b + 1) * block] for b in range(nblk)]
+    for c in (1, 2):
+        rx = oracle.Receiver(rate, ifs[c], CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+        want = np.concatenate([rx.run(x)[0] for x in blocks])
+        assert np.array_equal(r["audio"][c].view(np.uint32), want.view(np.uint32)), c
+    # receiver 0: the oracle's chain up to the tap; then the same NCO phase with fresh filters
+    rx = oracle.Receiver(rate, ifs[0], CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+    before = np.concatenate([rx.run(x)[0] for x in blocks[:tap_at]])
+    nx = oracle.Receiver(rate, ifs[0], CFG["cpb"], CFG["crate"], mode, CFG["apb"], CFG["arate"])
+    nx.s.phase, nx.s.prev_i, nx.s.prev_q = rx.s.phase, rx.s.prev_i, rx.s.prev_q
+    outs = [nx.run(x) for x in blocks[tap_at:]]
+    after = np.concatenate([o[0] for o in outs])
+    assert np.array_equal(r["audio"][0].view(np.uint32), np.concatenate([before, after]).view(np.uint32))
+    assert int(r["tap_blocks"]) == nblk - tap_at
+    demod = np.concatenate([o[2] for o in outs])
+    assert np.array_equal(r["tap"].view(np.uint32), demod.view(np.uint32))

@@ -39,6 +39,7 @@ private:
 	void deinit();
 	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer);
 	bool acceptsDeviceInput() const { return _channel == NULL; }   /* stand-alone: reads the producer's device output */
+	wrhost::Channel *gpuChannel() const { return _channel; }
 
 	Mode			_mode;
 	vector<string>	_modeNames;

@@ -36,6 +36,9 @@ uint64_t cpuNanoseconds()
 }
 }
 
+/* set by the GPU glue when the first chain is fused (a pointer, so that this file links without it) */
+void (*DspBlock::gpuUnfuse)(DspBlock *) = NULL;
+
 DspBlock::DspBlock(const string &name, const string &type)
 	: _outputSampleRate(DEFAULT_SAMPLE_RATE), _outputChannels(DEFAULT_CHANNELS),
 	  _name(name), _type(type),
@@ -64,6 +67,10 @@ void DspBlock::connect(DspBlock *block)
 		          block->name().c_str(), type().c_str(), name().c_str());
 		return;
 	}
+	/* a block inside a fused Receiver chain produces no host output: a second consumer ends the
+	 * fusion of that chain (it goes on block by block, its filters from empty histories) */
+	if (_elide && gpuUnfuse)
+		gpuUnfuse(this);
 	_consumers.push_back(block);
 	block->_producer = this;
 	LOG_DEBUG("Added block %s:%s as consumer of %s:%s\n", block->type().c_str(),

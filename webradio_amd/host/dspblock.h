@@ -33,7 +33,7 @@ using namespace std;	// reference headers do this and its sources rely on it (ra
 typedef float sample_t;
 
 class DspSource;
-namespace wrhost { class TunerBatch; }
+namespace wrhost { class TunerBatch; struct Channel; }
 
 class DspBlock
 {
@@ -88,6 +88,9 @@ protected:
 	 * output in device memory publishes the pointer, a consumer that can read device memory
 	 * says so, and when every consumer can, the host copy of that output is never made. */
 	virtual bool acceptsDeviceInput() const { return false; }
+	/* the tuner-batch channel this block is part of while its Receiver chain is fused (gpubatch.h) */
+	virtual wrhost::Channel *gpuChannel() const { return NULL; }
+	static void (*gpuUnfuse)(DspBlock *block);       /* takes the chain `block` is part of out of its tuner batch */
 	void publishDeviceOutput(const void *devptr) { _devOut = devptr; }
 	const void *upstreamDeviceOutput() const { return _producer ? _producer->_devOut : NULL; }
 	bool hostOutputNeeded() const;

@@ -284,8 +284,10 @@ void TunerBatch::destroyFor(DspSource *src)
 
 /* The shape radio.cxx:68-76 builds, with nothing else attached along the way.  Only
  * then is it safe to skip the intermediate buffers. */
+
 Channel *TunerBatch::enrol(DownConverter *mixer)
 {
+	DspBlock::gpuUnfuse = TunerBatch::unfuseChainOf;
 	if (envUnsigned("WEBRADIO_NO_FUSION", 0))
 		return NULL;
 	DspSource *src = dynamic_cast<DspSource *>(mixer->_producer);
@@ -393,6 +395,12 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	f1->elideOutput(true);
 	dm->elideOutput(true);
 	return ch;
+}
+
+/* DspBlock::connect on a block whose output the fusion had elided */
+void TunerBatch::unfuseChainOf(DspBlock *block)
+{
+	withdraw(block->gpuChannel());
 }
 
 void TunerBatch::withdraw(Channel *ch)

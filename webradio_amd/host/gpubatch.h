@@ -89,6 +89,7 @@ public:
 	 * returns the channel or NULL (-> the blocks run stand-alone) */
 	static Channel *enrol(DownConverter *mixer);
 	static void withdraw(Channel *ch);
+	static void unfuseChainOf(DspBlock *block);
 	/* the root source's batch device, or NULL if the block is not below a batched source */
 	static wr_dev *batchDeviceOf(const DspBlock *block);
 	static DspSource *rootSource(const DspBlock *block);

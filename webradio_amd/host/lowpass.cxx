@@ -118,8 +118,15 @@ bool LowPass::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuf
 	wr_dev *dev = wrhost::deviceFor(this);
 	const size_t inBytes = (size_t)nframes * ch * sizeof(float);
 	const size_t outBytes = (size_t)outframes * outputChannels() * sizeof(float);
-	if (!dev || !_out->reserve(dev, outBytes ? outBytes : sizeof(float)) || !_history->ptr)
+	if (!dev || !_out->reserve(dev, outBytes ? outBytes : sizeof(float)))
 		return false;
+	if (!_history->ptr) {
+		/* started as part of a fused chain that has since been taken apart (a second consumer was
+		 * attached inside it, DspBlock::connect): an empty history, like a fresh LowPass::block */
+		const size_t hbytes = (size_t)(_firLength - 1) * ch * sizeof(float);
+		if (!_history->reserve(dev, hbytes ? hbytes : sizeof(float)))
+			return false;
+	}
 	/* input: the producer's device output if there is one, else an upload (see DownConverter) */
 	const float *din = (const float *)upstreamDeviceOutput();
 	if (!din) {
