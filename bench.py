@@ -148,6 +148,47 @@ def c3_secondary(torch, dev, blocks, n, steps, settle_ms):
     }
 
 
+def c1_secondary(torch, dev, steps, settle_ms):
+    """BASELINE config 1 on the GPU: ONE receiver (DDC + FM) off a 2.048 Msps stream in the RTL-SDR byte
+    format, 131 072-frame blocks resident in HBM (the reference's own CPU-runnable case; parity in
+    tests/test_gpu_tuner.py::test_c1_single_receiver_u8_file).  One small launch sequence per 64 ms
+    block: what it measures is launch latency, not the chip."""
+    from webradio_amd import capi, synth
+    from webradio_amd.device import Tuner
+    c1 = synth.C1
+    n, nb = c1["block_frames"], 16
+    raw = torch.from_numpy(synth.rtl_u8_stream(n * nb, c1["input_rate"], c1["if_hz"])).cuda()
+    blocks = [raw[2 * n * b: 2 * n * (b + 1)] for b in range(nb)]
+    t = Tuner(dev, c1["input_rate"], 1, n, capi.WR_NCO_ROTATE)
+    t.add_receiver(c1["if_hz"], c1["chan_passband"], c1["chan_rate"], capi.WR_FM, c1["audio_passband"], c1["audio_rate"])
+    for i in range(8):
+        t.submit_u8_device(blocks[i % nb], n)
+    torch.cuda.synchronize()
+    t_settle = time.perf_counter()
+    while settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < settle_ms / 3:
+        for i in range(100):
+            t.submit_u8_device(blocks[i % nb], n)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t.submit_u8_device(blocks[i % nb], n)
+    t.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    a = t.fetch(0, capi.WR_STAGE_AUDIO, n)
+    assert a.size == n // 8 // 8 and bool((a == a).all()) and float(abs(a).max()) > 0.0
+    t.destroy()
+    msps = n * steps / dt / 1e6
+    return {
+        "workload": "C1: one receiver (DDC + FM) off a 2.048 Msps RTL-SDR byte stream, %d-frame blocks resident in HBM, "
+                    "D1=8 (256 kHz), D2=8 (32 kHz)" % n,
+        "value": round(msps, 2), "unit": "complex Msamples/s of tuner input",
+        "ms_per_block": round(dt / steps * 1e3, 5), "steps": steps,
+        "times_real_time": round(msps / (c1["input_rate"] / 1e6), 1),
+        "note": "launch-latency bound: three small launches per 64 ms block (DDC; demodulator; audio filter -- D2 = 8 has no fused post stage)",
+    }
+
+
 def run_c5(args, torch, dist, rank, world, device_index):
     """BASELINE config 5: one synthetic 1 Gsps stream, D1 = 4000, sharded IN TIME.
     Chunk c of T frames belongs to rank c mod world; a rank computes [halo | chunk] from the state
@@ -415,11 +456,12 @@ def main():
         tuner.blocks_per_launch(B)
 
     # BASELINE config 3 off the same resident stream, outside the timed region of the headline
-    c3 = None
+    c3 = c1 = None
     if world == 1 and not args.no_secondary:
         tuner.flush()
         torch.cuda.synchronize()
         c3 = c3_secondary(torch, dev, blocks, n, max(nb, min(args.steps, 60)), args.settle_ms)
+        c1 = c1_secondary(torch, dev, 400, args.settle_ms)
 
     if rank == 0:
         total_samples = float(n) * args.steps * world
@@ -512,6 +554,8 @@ def main():
                 out["secondary"]["c2_one_block_per_launch"] = one
             if c3 is not None:
                 out["secondary"]["c3"] = c3
+            if c1 is not None:
+                out["secondary"]["c1"] = c1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ifs, args.cpu_blocks)
     else:

@@ -48,6 +48,8 @@ def test_single_gpu_line():
     c3 = j["secondary"]["c3"]                                        # BASELINE config 3 beside the headline
     assert c3["value"] > 0 and c3["roofline"]["algorithmic_bytes_per_frame"] == 12 * 65536
     assert abs(c3["roofline"]["frac"] - c3["roofline"]["achieved"] / 8000.0) < 1e-4
+    c1 = j["secondary"]["c1"]
+    assert c1["value"] > 2.048 and abs(c1["times_real_time"] - c1["value"] / 2.048) < 0.1
 
 
 def test_two_rank_launch_path():

@@ -204,6 +204,10 @@ class Tuner:
     def submit_device(self, dev_ptr, nframes):
         check(self.lib.wr_tuner_submit(self.h, ptr(dev_ptr), nframes, capi.WR_DEVICE))
 
+    def submit_u8_device(self, dev_ptr, nframes):
+        """A block in the RTL-SDR byte format (io/rtlsdrtuner.cxx:106), already in device memory."""
+        check(self.lib.wr_tuner_submit_u8(self.h, ptr(dev_ptr), nframes, capi.WR_DEVICE))
+
     def fetch(self, ch, stage, capacity):
         out = np.empty(max(capacity, 1), dtype=np.float32)
         n = C.c_size_t()
