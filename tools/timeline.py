@@ -7,7 +7,7 @@ from webradio_amd import capi, synth
 from webradio_amd.device import Device, Tuner
 
 c2 = synth.C2
-fs, n = c2["input_rate"], c2["block_frames"]
+fs, n = c2["input_rate"], c2["block_frames"] * int(os.environ.get("TL_BLOCKS", "1"))      # blocks per launch
 ifs = synth.c2_ifs(256)
 dev = Device(0, torch.cuda.current_stream().cuda_stream)
 x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
