@@ -196,3 +196,106 @@ def test_random_streams_through_the_ring(dev, oracle, seed):
             if not was_fm[c] and want[b][c].size:
                 assert np.abs(audio[c] - want[b][c]).max() <= 2e-6 * gain, (seed, b, c)
     t.destroy()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "12"))))
+def test_random_streams_with_blocks_per_launch(dev, seed):
+    """wr_tuner_set_blocks_per_launch under a random stream of calls: the same sequence of submits
+    (blocks that follow on in device memory and blocks that do not, whole and ragged sizes, host
+    blocks), setters (IF, mode, passband, af_gain), flushes and state reads goes through a tuner that
+    launches every block on its own and one that holds up to 2-5 blocks.  Everything either of them
+    hands out through the audio ring, laid end to end, is the same bits; so are the NCO phases read
+    on the way."""
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    fs, crate, arate = RATES[seed % len(RATES)]
+    d1, d2 = fs // crate, crate // arate
+    q = d1 * d2                                             # frames per audio frame
+    nchan = int(rng.choice([3, 40, 64, 130]))
+    nco = (capi.WR_NCO_ROTATE, capi.WR_NCO_EXACT, capi.WR_NCO_SPLIT)[seed % 3]
+    whole = q * int(rng.integers(2, 9))                     # the usual block
+    if whole > 40_000:
+        whole = q * 2
+    hold = int(rng.integers(2, 6))
+    total = whole * 40
+    ifs = [int(v) for v in rng.integers(-fs // 2 + 1, fs // 2, nchan)]
+    iq = synth.fm_stream(total, fs, ifs[:3], amp=0.15, fm_base=fs / 70_000.0, beta=2.0, seed=seed)
+    x = torch.from_numpy(iq).cuda()
+
+    # the script: a list of operations both tuners replay
+    ops, pos = [], 0
+    while pos + 2 * whole < total and len(ops) < 70:
+        r = rng.random()
+        if r < 0.60:
+            ops.append(("dev", pos, whole)); pos += whole
+        elif r < 0.68:                                      # ragged: not a whole number of audio frames
+            n = whole + int(rng.integers(1, q))
+            ops.append(("dev", pos, n)); pos += n
+        elif r < 0.74:                                      # a block from elsewhere: does not follow on
+            ops.append(("dev_copy", pos, whole)); pos += whole
+        elif r < 0.80:
+            ops.append(("host", pos, whole)); pos += whole
+        elif r < 0.86:
+            ops.append(("set_if", int(rng.integers(0, nchan)), int(rng.integers(-fs // 2 + 1, fs // 2))))
+        elif r < 0.90:
+            ops.append(("set_mode", int(rng.integers(0, nchan)), int(rng.integers(0, 4))))
+        elif r < 0.93:
+            ops.append(("set_filter", int(rng.integers(0, nchan)), int(rng.choice([fs // 40, fs // 16, fs // 8]))))
+        elif r < 0.95:
+            ops.append(("gain", int(rng.integers(0, nchan)), float(rng.choice([-6.0, 0.0, 3.5]))))
+        elif r < 0.98:
+            ops.append(("flush",))
+        else:
+            ops.append(("state", int(rng.integers(0, nchan))))
+
+    def play(join):
+        t = Tuner(dev, fs, nchan, whole * hold + q, nco)
+        chans = [t.add_receiver(f, fs // 16, crate, int(m), crate // 8, arate)
+                 for f, m in zip(ifs, rng2.integers(0, 4, nchan))]
+        t.audio_ring(128)
+        if join:
+            t.blocks_per_launch(hold)
+        rows, states = [], []
+
+        def drain():
+            while t.ring_stats()[0]:
+                a, _ = t.ring_acquire()
+                rows.append(a.copy())
+                t.ring_release()
+        for op in ops:
+            if op[0] == "dev":
+                t.submit_device(x[2 * op[1]: 2 * (op[1] + op[2])], op[2])
+            elif op[0] == "dev_copy":
+                t.submit_device(x[2 * op[1]: 2 * (op[1] + op[2])].clone(), op[2])
+                torch.cuda.synchronize()                    # (the clone must outlive the launch that reads it)
+                t.flush()
+                dev.sync()
+            elif op[0] == "host":
+                t.submit_host(iq[2 * op[1]: 2 * (op[1] + op[2])])
+            elif op[0] == "set_if":
+                t.set_if(chans[op[1]], op[2])
+            elif op[0] == "set_mode":
+                t.set_mode(chans[op[1]], op[2])
+            elif op[0] == "set_filter":
+                t.set_filter(chans[op[1]], 0, op[2], crate)
+            elif op[0] == "gain":
+                t.set_af_gain(chans[op[1]], op[2])
+            elif op[0] == "flush":
+                t.flush()
+            elif op[0] == "state":
+                states.append(t.state(chans[op[1]])[0])
+            drain()
+        t.flush()
+        dev.sync()
+        drain()
+        slots = [t.slot(c) for c in chans]
+        t.destroy()
+        return np.concatenate([r[slots] for r in rows], axis=1) if rows else np.zeros((nchan, 0), np.float32), states
+
+    rng2 = np.random.default_rng(seed)
+    one, st1 = play(False)
+    rng2 = np.random.default_rng(seed)
+    many, st2 = play(True)
+    assert one.shape == many.shape and one.shape[1] > 0
+    assert st1 == st2
+    assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
