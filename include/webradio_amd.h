@@ -309,12 +309,14 @@ int wr_tuner_set_audio_scale(wr_tuner *tuner, float scale);
  * and hold whole audio frames are HELD -- pointer and length, the caller keeps the memory alive --
  * and go out as ONE launch over the joined block when the last one arrives, when a submit does
  * not follow on, or when anything reads results or changes parameters (wr_tuner_flush, every
- * fetch, every staged setter at the next submit).  The outputs are the same bits (a frame does not
+ * fetch and getter, every setter -- which so still takes effect at the boundary after the last
+ * block submitted).  The outputs are the same bits (a frame does not
  * depend on where the stream is cut, DspBlock::run's only block-size effect being the truncation
  * of dspblock.cxx:177-178, which whole audio frames avoid); what changes is that they arrive per
  * group: the audio array, wr_chan_fetch and a ring entry then cover all blocks of the group, and
- * the tuner must have been created with max_block_frames >= nblocks * block.  The fixed cost of a
- * launch (~4.5 us of 37 at BASELINE config 2) is paid once per group.  1 (the default) = off. */
+ * the tuner must have been created with max_block_frames >= nblocks * block.  The fixed costs of a
+ * launch (start-up, the waves that finish early) are paid once per group: 32.8 -> 30.0 us per block
+ * at BASELINE config 2 with nblocks = 4.  1 (the default) = off. */
 int wr_tuner_set_blocks_per_launch(wr_tuner *tuner, unsigned int nblocks);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
