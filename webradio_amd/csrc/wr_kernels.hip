@@ -1710,10 +1710,16 @@ bool wrk_tuner_post_supported(unsigned int d2)
 	return d2 >= 1 && d2 <= 6;
 }
 
-hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A)
+hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A0)
 {
-	if (!A.k1 || !A.groups)
+	if (!A0.k1 || !A0.groups)
 		return hipSuccess;
+	/* on its own the post stage has the chip to itself and is a chain of latencies: one tile per
+	 * workgroup, all of them in flight at once (runs of tiles are for the workgroups that ride in a
+	 * DDC launch, where instructions are what is short); 15.4 against 18.2 us for a C2 block */
+	WrPostArgs A = A0;
+	A.run = 1u;
+	A.ntiles = A.tiles;
 	switch (A.d2) {
 	case 1: return launch_post<1>(st, A);
 	case 2: return launch_post<2>(st, A);
