@@ -634,6 +634,37 @@ def test_few_distinct_channel_filters_share_the_fast_kernel(dev, oracle, nco):
     t.destroy()
 
 
+def test_the_largest_tuner(dev, oracle):
+    """WR_MAX_CHANNELS = 4096 receivers = 64 lane groups, four DDC launches of 16 groups a block (the
+    post stage of all 64 rides in the first).  Receivers of the first, a middle and the last lane group
+    against the oracle over three blocks, the default NCO mode, FM and USB."""
+    fs, n, nch = 2_000_000, 24_000, 4096
+    ifs = [(-nch // 2 + c) * 240 + 31 for c in range(nch)]
+    t = Tuner(dev, fs, nch, n, capi.WR_NCO_ROTATE)
+    mode = lambda c: capi.WR_FM if c % 2 else capi.WR_USB
+    chans = [t.add_receiver(f, 128_000, 5_000, mode(c), 160, 1_000) for c, f in enumerate(ifs)]
+    probe = [0, 1, 63, 1024, 2049, 4032, 4095]
+    rxs = {c: oracle.Receiver(fs, ifs[c], 128_000, 5_000, oracle.FM if c % 2 else oracle.USB, 160, 1_000) for c in probe}
+    t.audio_ring(4)
+    start, want = 0, []
+    for b in range(3):
+        iq = synth.fm_stream(n, fs, [ifs[c] for c in probe], start_frame=start, seed=5, amp=0.1, fm_base=30.0, beta=2.0)
+        start += n
+        t.submit_host(iq)
+        want.append({c: rxs[c].run(iq) for c in probe})
+    t.flush()
+    for b in range(3):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b and audio.shape == (4096, n // 400 // 5)
+        for c in probe:
+            assert np.abs(audio[t.slot(chans[c])] - want[b][c][0]).max() <= AUDIO_ATOL, (b, c)
+    for c in probe:                                           # and the last block's channel IQ
+        gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)
+        assert np.abs(gc - want[2][c][1]).max() <= IQ_ATOL, c
+    t.destroy()
+
+
 @pytest.mark.parametrize("d2,blocks,mode", [(5, [38_400, 39_100, 38_400], capi.WR_USB),
                                             (2, [61_440, 61_440], capi.WR_USB),
                                             (5, [38_400, 38_400], capi.WR_FM)])
