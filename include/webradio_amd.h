@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define WR_ABI_VERSION   1
+#define WR_ABI_VERSION   2       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
+                                    blocks per launch added (nothing of version 1 changed or removed) */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
