@@ -1557,8 +1557,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
 		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
-		const bool defer = !two_kernels && !g->d1b && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE
-		                   && (g->fewsets_mask & ((L.slots_used / 64 >= 64) ? ~0ull : ((1ull << (L.slots_used / 64)) - 1ull))) != 0;
+		const bool defer = !two_kernels && !g->d1b && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, Lp, Gp));
 			HIP_TRY(wrk_tuner_audio(st, Lp, Gp));

@@ -724,6 +724,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		wave_prio(3u);
 		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
 		const unsigned int idx = blockIdx.x - n_ddc;
+		if (threadIdx.x >= POST_THREADS)
+			return;                                     /* (workgroups of the per-lane-taps variant have 16 waves) */
 		float *stage = (float *)lds;
 		post_role<(PD2 ? PD2 : 1u), false>(post, idx % (post.ntiles + 1u), idx / (post.ntiles + 1u), stage,
 		                                    stage + NEED * 64u, (int *)(stage + NEED * 64u + POST_TK * 65u));
@@ -1624,8 +1626,23 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 	if (odd || !uni) {
 		WrTunerLaunch L2 = L;
 		L2.ev_start = L2.ev_stop = nullptr;                 /* the profiling events went to the first launch */
-		return launch_ddc<NCO, false, 0>(st, uni ? L2 : L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr,
-		                                 (odd == all) ? 0ull : odd, whole);
+		const unsigned long long sel = (odd == all) ? 0ull : odd;
+		if (!uni && NCO == WR_NCO_ROTATE && post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
+			/* no lane group left for the fast kernel (every group holds more than WR_TAPSETS channel
+			 * filters): the previous block's post stage rides with this launch instead (its workgroups
+			 * are as large as the per-lane-taps ones, 16 waves, of which the post stage uses eight) */
+			if (post_taken)
+				*post_taken = true;
+			switch (post->d2) {
+			case 1: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 1u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
+			case 2: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 2u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
+			case 3: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 3u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
+			case 4: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 4u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
+			case 5: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 5u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
+			default: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 6u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
+			}
+		}
+		return launch_ddc<NCO, false, 0>(st, uni ? L2 : L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, sel, whole);
 	}
 	return hipSuccess;
 }
