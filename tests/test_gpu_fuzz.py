@@ -299,3 +299,49 @@ def test_random_streams_with_blocks_per_launch(dev, seed):
     assert one.shape == many.shape and one.shape[1] > 0
     assert st1 == st2
     assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "12"))))
+def test_random_post_stage_runs(dev, oracle, seed):
+    """The riding post stage where it takes runs of tiles (16 lane groups, enough audio frames for runs
+    of two or four): random audio decimation 1-6, detector per receiver, mixed and shared audio
+    filters per lane group, ragged block sizes.  EXACT NCO mode: AM/USB/LSB receivers are the
+    oracle's bits, FM ones within tolerance; blocks through the audio ring, so every block but the last
+    went through the riding variant and the last through the kernel of its own."""
+    rng = np.random.default_rng(9000 + seed)
+    fs, crate = 2_400_000, 120_000
+    d2 = int(rng.integers(1, 7))
+    arate = crate // d2
+    nch = 1024
+    tiles = int(rng.choice([24, 30, 96, 100]))                 # x 16 groups: 384.. -> runs of 2, 1536.. -> runs of 4
+    k2 = tiles * 16 - int(rng.integers(0, 16))                # a ragged last tile, mostly
+    base = k2 * d2 * 20
+    blocks = [base, base + int(rng.integers(0, 20 * d2)), max(20 * d2, base - 20 * d2 * int(rng.integers(0, 40)))]
+    ifs = [(-nch // 2 + c) * 1100 + 13 for c in range(nch)]
+    modes = rng.integers(0, 4, nch)
+    mixed_group = int(rng.integers(0, 16))                    # one lane group with two audio filters
+    apb = lambda c: arate // 5 if (c // 64 == mixed_group and c % 2) else arate // 4
+    t = Tuner(dev, fs, nch, max(blocks), capi.WR_NCO_EXACT)
+    chans = [t.add_receiver(f, 50_000, crate, int(modes[c]), apb(c), arate) for c, f in enumerate(ifs)]
+    probe = [int(v) for v in rng.choice(nch, 6, replace=False)] + [mixed_group * 64, mixed_group * 64 + 1]
+    rxs = {c: oracle.Receiver(fs, ifs[c], 50_000, crate, int(modes[c]), apb(c), arate) for c in probe}
+    t.audio_ring(len(blocks))
+    start, want = 0, []
+    for n in blocks:
+        iq = synth.fm_stream(n, fs, [ifs[c] for c in probe[:4]], start_frame=start, seed=seed, amp=0.1, fm_base=300.0, beta=2.0)
+        start += n
+        t.submit_host(iq)
+        want.append({c: rxs[c].run(iq)[0] for c in probe})
+    t.flush()
+    for b, n in enumerate(blocks):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b and audio.shape[1] == n // 20 // d2
+        for c in probe:
+            ga, wa = audio[t.slot(chans[c])], want[b][c]
+            if modes[c] == capi.WR_FM:
+                gain = max(1.0, float(np.abs(oracle.lowpass_design(apb(c), crate)).sum()))
+                assert np.abs(ga - wa).max() <= FM_ATOL * gain * 4, (c, b)
+            else:
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (c, b, int(modes[c]))
+    t.destroy()
