@@ -691,6 +691,9 @@ k_tuner_post(WrPostArgs A)
 #define DDC_ROTATE_WGS_PER_CU 4u
 #endif
 #define DDC_LDS_BYTES     (DDC_TABLE_BYTES + DDC_WAVES * 2u * 512u)
+#ifndef DDC_LTAPS_SMALL
+#define DDC_LTAPS_SMALL 1                  /* the per-lane-taps ROTATE variant in 8-wave workgroups, four per CU, like the fast one */
+#endif
 #ifndef DDC_DEAL_WAYS
 #define DDC_DEAL_WAYS 2u                   /* measured at C2, us per block at 1 / 4 blocks per launch: in order (and as
                                               many workgroups as make the units come out even) 37.6 / 32.8, 2 ways
@@ -702,7 +705,7 @@ k_tuner_post(WrPostArgs A)
  * except that they share the CUs, the post stage's latency-bound phases filling in between the
  * DDC's arithmetic.  Their dependency is the kernel boundary before this launch. */
 template <int NCO, bool UTAPS, unsigned int PD2>
-__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && UTAPS ? DDC_ROTATE_WGS_PER_CU * DDC_ROTATE_WAVES / 4u : DDC_WAVES / 4u)))
+__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL) ? DDC_ROTATE_WGS_PER_CU * DDC_ROTATE_WAVES / 4u : DDC_WAVES / 4u)))
 k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             const float2 *__restrict__ hist,
             float2 *__restrict__ hist_next, size_t nframes, size_t k1,
@@ -1457,8 +1460,8 @@ hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t c
  *   SPLIT                : 16 x 1 -- the replicated tables take 128 KiB
  *   EXACT                : 16 x 2 -- small LDS footprint, two workgroups hide the gather latency */
 template <int NCO, bool UTAPS> struct DdcGeom {
-	static constexpr unsigned int waves = (NCO == WR_NCO_ROTATE && UTAPS) ? DDC_ROTATE_WAVES : DDC_WAVES;
-	static constexpr unsigned int wgs_per_cu = (NCO == WR_NCO_ROTATE && UTAPS) ? DDC_ROTATE_WGS_PER_CU
+	static constexpr unsigned int waves = (NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL)) ? DDC_ROTATE_WAVES : DDC_WAVES;
+	static constexpr unsigned int wgs_per_cu = (NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL)) ? DDC_ROTATE_WGS_PER_CU
 	                                           : (NCO == WR_NCO_EXACT) ? 2u : 1u;
 };
 
