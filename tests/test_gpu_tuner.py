@@ -706,3 +706,33 @@ def test_post_stage_runs_of_tiles(dev, oracle, d2, blocks, mode):
             else:
                 assert np.abs(ga - wa).max() <= AUDIO_ATOL, (c, b)
     t.destroy()
+
+
+def test_every_lane_group_mixed_and_more_than_sixteen_of_them(dev, oracle):
+    """1100 receivers, seven channel passbands dealt round the receivers: every one of the 18 lane
+    groups holds more than WR_TAPSETS filters, so all DDC launches are of the per-lane-taps variant (16
+    groups, then 2), and the previous block's post stage -- all 18 groups -- rides in the first of
+    them.  Probes in the first, the 16th, the 17th and the last group against the oracle, three
+    blocks through the audio ring."""
+    fs, n, nch = 2_000_000, 20_000, 1100
+    ifs = [(-nch // 2 + c) * 900 + 77 for c in range(nch)]
+    pb = lambda c: 70_000 + 31_250 * (c % 7)
+    t = Tuner(dev, fs, nch, n, capi.WR_NCO_ROTATE)
+    chans = [t.add_receiver(f, pb(c), 5_000, capi.WR_USB, 160, 1_000) for c, f in enumerate(ifs)]
+    probe = [0, 5, 63, 1000, 1023, 1024, 1030, 1087, 1088, 1099]
+    rxs = {c: oracle.Receiver(fs, ifs[c], pb(c), 5_000, oracle.USB, 160, 1_000) for c in probe}
+    t.audio_ring(3)
+    start, want = 0, []
+    for _ in range(3):
+        iq = synth.fm_stream(n, fs, [ifs[c] for c in probe[::2]], start_frame=start, seed=3, fm_base=30.0, beta=2.0)
+        start += n
+        t.submit_host(iq)
+        want.append({c: rxs[c].run(iq)[0] for c in probe})
+    t.flush()
+    for b in range(3):
+        audio, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == b
+        for c in probe:
+            assert np.abs(audio[t.slot(chans[c])] - want[b][c]).max() <= AUDIO_ATOL, (b, c)
+    t.destroy()
