@@ -8,7 +8,11 @@
            rank's tuner (BASELINE config 2 / SURVEY C2).
 
   python bench.py --gpus N --steps K --warmup W
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+  bench.py --gpus N ...: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* come from the environment), or plain
+  `python bench.py --gpus N`, which starts the N ranks itself (spawn_ranks below) -- one per GPU,
+  RCCL ("nccl") by default.  N GPUs must be there: with fewer the job exits non-zero instead of
+  quietly measuring one GPU (`--backend gloo` lets ranks share a GPU; that is for the tests).
 
 Prints ONE JSON line on rank 0 (see the contract in the task description) carrying
 `roofline` (dominant kernel, HIP-event timed inside the timed region) and, at N = 1,
@@ -65,9 +69,38 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=8,
                     help="one HIP event pair around every n consecutive launches of the dominant kernel (n = 1: every "
                          "launch stamps its own start and stop, which costs ~2 us of stream time per launch)")
+    ap.add_argument("--halo", choices=["auto", "copy", "ring"], default="auto",
+                    help="c5: where a chunk's halo comes from.  ring: the C ABI's wr_ring_* (RCCL ncclSend/ncclRecv on a side "
+                         "stream, issued a round ahead) -- what N > 1 over nccl uses; at N = 1 the rank is its own neighbour.  "
+                         "copy: a device copy (N = 1 only).  auto: ring for N > 1 over nccl, copy at N = 1; gloo ranks "
+                         "(tests: two ranks on one GPU) exchange host tensors through torch.distributed")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, as the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would
+    (Radio::run pumps its front ends one after the other, radio.cxx:56-59; here every front end has
+    its own process and GPU).  Rank 0's JSON line goes to this process's stdout; the exit code is the
+    launcher's."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and args.backend == "nccl":
+        raise SystemExit("bench.py: --gpus %d but this box has %d GPU(s): refusing to measure fewer GPUs than asked for "
+                         "(--backend gloo lets ranks share a GPU, for tests only)" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(cfg, ifs, blocks):
@@ -204,7 +237,8 @@ def run_c5(args, torch, dist, rank, world, device_index):
     H = timeshard.halo_frames(d1, d2)
     assert H == 260_000 and T % (d1 * d2) == 0 and T >= H
     ifs = synth.c2_ifs(args.channels, cfg)
-    nb = max(2, min(args.resident_blocks, 4))               # (H + T) * 8 B = 162 MB each
+    nb = max(3, min(args.resident_blocks, 4))               # (H + T) * 8 B = 162 MB each; >= 3: a halo posted a round
+                                                            # ahead lands in a buffer no chunk in flight reads
     # every buffer: [halo H | chunk T]; the chunks are consecutive pieces of one stream per rank
     bufs = [torch.empty(2 * (H + T), dtype=torch.float32, device="cuda") for _ in range(nb)]
     for b in range(nb):
@@ -216,16 +250,42 @@ def run_c5(args, torch, dist, rank, world, device_index):
     tuner = Tuner(dev, fs, args.channels, H + T, capi.WR_NCO_ROTATE)
     for f in ifs:
         tuner.add_receiver(f, cfg["chan_passband"], cfg["chan_rate"], capi.WR_FM, cfg["audio_passband"], cfg["audio_rate"])
-    ring = timeshard.RingHalo(dist, rank, world) if world > 1 else None
+    native = args.halo == "ring" or (args.halo == "auto" and world > 1 and args.backend == "nccl")
+    if args.halo == "copy" and world > 1:
+        raise SystemExit("bench.py: --halo copy needs --gpus 1")
+    if native and world > 1 and args.backend != "nccl":
+        raise SystemExit("bench.py: --halo ring between ranks needs one GPU per rank (RCCL): use the nccl backend")
+    ring = None
+    if native:
+        ring = timeshard.RingHalo(dist, rank, world, dev=dev)        # wr_ring_* on RCCL
+    elif world > 1:
+        ring = timeshard.RingHalo(dist, rank, world)                 # torch.distributed (gloo: host tensors)
+    posted = [None]
+
+    def tail_of(i):
+        return bufs[i % nb][2 * T:]                                  # last H frames of round i's [halo | chunk]
+
+    def halo_of(i):
+        # the tail received in round i is the one of chunk i * world + rank - 1: this rank's halo of the same
+        # round -- except on rank 0, whose predecessor chunk is rank world - 1's of the round before
+        return bufs[(i + 1) % nb][:2 * H] if rank == 0 else bufs[i % nb][:2 * H]
 
     def step(i):
         buf = bufs[i % nb]
         c = i * world + rank                                # this rank's chunk of round i
         tail = buf[2 * T:]                                  # last H frames of [halo | chunk]
-        if world == 1:
+        if native:
+            # the halo is input, not a result: round i + 1's pair goes out on the ring's own stream before this
+            # round's chunk is submitted and travels while it computes; nothing here waits on the host
+            if posted[0] is None:
+                ring.post(tail_of(i), halo_of(i))
+            ring.wait()                                     # round i's pair (and rank 0's halo, which came a round earlier)
+            ring.post(tail_of(i + 1), halo_of(i + 1))
+            posted[0] = i + 1
+        elif world == 1:
             bufs[(i + 1) % nb][:2 * H].copy_(tail)          # next chunk's halo: a device copy
         else:
-            # (gloo -- the two-ranks-on-one-GPU test -- moves host tensors only; RCCL takes them from HBM)
+            # (gloo -- the two-ranks-on-one-GPU test -- moves host tensors only)
             got = ring.exchange(tail if args.backend == "nccl" else tail.cpu())   # from rank - 1: the tail of chunk c - 1 ...
             if rank == 0:
                 bufs[(i + 1) % nb][:2 * H].copy_(got, non_blocking=False)    # ... which rank 0 needs one round later
@@ -287,9 +347,12 @@ def run_c5(args, torch, dist, rank, world, device_index):
                 "workload": "C5: ONE synthetic 1 Gsps complex-f32 stream, %d channels, D1=4000 (250 kHz, passband 64 MHz), "
                             "FM, D2=5; chunks of %d frames dealt round-robin to the ranks, halo of %d frames per chunk "
                             "from the ring neighbour (%s)" % (args.channels, T, H,
-                                                              "torch.distributed %s send/recv" % args.backend if world > 1
-                                                              else "device copy at world size 1"),
+                                                              "wr_ring: RCCL ncclSend/ncclRecv on a side stream, issued a round ahead"
+                                                              if native else "torch.distributed %s send/recv" % args.backend
+                                                              if world > 1 else "device copy at world size 1"),
                 "channels": args.channels, "chunk_frames": T, "halo_frames": H, "resident_chunks": nb,
+                "halo": "ring" if native else ("copy" if world == 1 else "torch.distributed"),
+                "ring_exchanges": ring.native.exchanges() if native else None,
                 "nco": "rotate", "parallelism": "time sharding, ring halo exchange (RCCL), no other collective",
             },
             "roofline": {
@@ -305,12 +368,17 @@ def run_c5(args, torch, dist, rank, world, device_index):
                         "the algorithmic figure (every input byte once) can exceed what HBM could deliver",
             },
         }
+    if ring is not None:
+        if native:
+            ring.wait()
+            torch.cuda.synchronize()
+        ring.close()
     tuner.destroy()
     dev.close()
     return out
 
 
-def finish(out, dist):
+def finish(out, dist, gpus):
     """The JSON line is the LAST line the job writes: RCCL prints its version banner through C stdio
     when NCCL_DEBUG=VERSION is set (it is on the GPU boxes); every rank pushes that out, the ranks
     meet, and only then does rank 0 print."""
@@ -323,6 +391,7 @@ def finish(out, dist):
     if dist is not None:
         dist.barrier()
     if out is not None:
+        assert out["n_gpus"] == gpus, "the line says %d GPUs, --gpus asked for %d" % (out["n_gpus"], gpus)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -335,6 +404,10 @@ def finish(out, dist):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                          # does not return
     import torch
     from webradio_amd import capi, synth
     from webradio_amd.device import Device, Tuner
@@ -342,9 +415,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the line would not be an %d-GPU measurement"
+                         % (args.gpus, world, args.gpus))
+    have = torch.cuda.device_count()
+    if have < 1:
+        raise SystemExit("bench.py: no GPU (the HIP path has no CPU fallback)")
+    if world > have and args.backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s): one rank per GPU (--backend gloo lets ranks share a GPU, "
+                         "for tests only)" % (world, have))
+    device_index = local_rank % have
     torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
@@ -356,7 +436,7 @@ def main():
             dist.init_process_group(args.backend)
 
     if args.workload == "c5":
-        finish(run_c5(args, torch, dist, rank, world, device_index), dist)
+        finish(run_c5(args, torch, dist, rank, world, device_index), dist, args.gpus)
         return
 
     cfg = synth.C2
@@ -563,7 +643,7 @@ def main():
 
     tuner.destroy()
     dev.close()
-    finish(out, dist)
+    finish(out, dist, args.gpus)
 
 
 if __name__ == "__main__":

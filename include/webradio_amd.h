@@ -39,8 +39,9 @@
 extern "C" {
 #endif
 
-#define WR_ABI_VERSION   2       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
-                                    blocks per launch added (nothing of version 1 changed or removed) */
+#define WR_ABI_VERSION   3       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
+                                    blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream)
+                                    added.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
@@ -84,6 +85,7 @@ enum wr_where { WR_HOST = 0, WR_DEVICE = 1 };
 typedef struct wr_dev      wr_dev;
 typedef struct wr_tuner    wr_tuner;
 typedef struct wr_spectrum wr_spectrum;
+typedef struct wr_ring     wr_ring;
 
 /* ------------------------------------------------------------------ misc -- */
 int         wr_abi_version(void);
@@ -300,6 +302,30 @@ int wr_chan_reset_history(wr_tuner *tuner, int chan);
  * sequential result for the chunk once the first halo/(D1*D2) audio frames are dropped
  * (webradio_amd/timeshard.py).  One call, no per-channel traffic. */
 int wr_tuner_seek(wr_tuner *tuner, unsigned long long frame);
+/* The halo ring of such a time-sharded stream (chunk c on rank c mod world, the halo of
+ * every chunk -- the last H frames of the one before it, webradio_amd/timeshard.py: halo_frames --
+ * from the ring neighbour).  What a LowPass carries from block to block in a member
+ * (dsp/lowpass.cxx:133-142) here crosses GPUs: ONE ncclSend / ncclRecv pair per chunk in one group,
+ * rank r -> r + 1, on RCCL directly (librccl.so.1 is looked up when the first wr_ring_* call
+ * needs it; WR_ERR_NODEV if it is not there -- nothing else in the library depends on it).
+ *   wr_ring_make_id   rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the host gets the
+ *                     bytes to the other ranks by its own means (a file, MPI, torch.distributed)
+ *   wr_ring_create    every rank, collectively (ncclCommInitRank); one process per GPU
+ *   wr_ring_exchange  enqueue one pair on the ring's own stream: send `nfloats` floats at send_dev
+ *                     to rank + 1, receive as many from rank - 1 into recv_dev.  It is ordered
+ *                     after everything the device's stream (wr_dev_open) holds at this moment and
+ *                     returns at once -- issue it a round ahead: the halo is input, not a result
+ *   wr_ring_wait      the device's stream waits (event to event, no host wait) for the last
+ *                     exchange; then submit [halo | chunk] as usual
+ * At world = 1 the neighbour is the rank itself (a device copy through RCCL). */
+int wr_ring_id_bytes(void);
+int wr_ring_version(int *version);                 /* ncclGetVersion of the RCCL that was loaded */
+int wr_ring_make_id(void *id_host, size_t nbytes);
+int wr_ring_create(wr_ring **ring, wr_dev *dev, const void *id_host, size_t nbytes, int rank, int world);
+int wr_ring_exchange(wr_ring *ring, const float *send_dev, float *recv_dev, size_t nfloats);
+int wr_ring_wait(wr_ring *ring);
+int wr_ring_info(wr_ring *ring, int *rank, int *world, unsigned long long *exchanges);
+int wr_ring_destroy(wr_ring *ring);
 /* scale applied to the audio as it is stored (default 1).  The MP3 encoder behind every
  * Receiver multiplies by 32768 before LAME (web/mp3encoder.cxx:65-72); a sink that wants
  * that format gets it from the audio kernel's store instead of a host loop. */

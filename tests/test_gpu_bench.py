@@ -82,3 +82,72 @@ def test_c5_workload_line_and_two_rank_ring():
     j = _line(out)
     assert j["n_gpus"] == 2
     assert abs(j["value"] - 2 * j["config"]["chunk_frames"] * 3 / (j["ms_per_step"] * 3 / 1e3) / 1e6) / j["value"] < 1e-3
+
+
+def test_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's call style) starts the two
+    ranks itself and reports n_gpus = 2 -- it used to run one GPU and say n_gpus 1.  gloo: the test box
+    has one GPU, which the two ranks share."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    for extra in ([], ["--workload", "c5"]):
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                                       "--warmup", "1", "--backend", "gloo"] + extra, cwd=ROOT, env=env)
+        j = _line(out)
+        assert j["n_gpus"] == 2 and j["steps"] == 3
+
+
+def test_more_gpus_than_the_box_has_is_an_error():
+    """--gpus 8 on a box with fewer GPUs exits non-zero with a message instead of measuring what is there."""
+    import torch
+    want = torch.cuda.device_count() + 7
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    for extra in ([], ["--workload", "c5"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2",
+                            "--warmup", "1"] + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode != 0
+        assert b"refusing to measure fewer GPUs" in p.stderr and not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    # under a launcher that made fewer ranks than --gpus says: an error too
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env2,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr
+
+
+_RCCL_PROBE = r"""
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29733")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+x = torch.arange(1024, dtype=torch.float32, device="cuda")
+dist.all_reduce(x)                                   # RCCL: ncclAllReduce on one rank
+y = torch.empty_like(x)
+ops = [dist.P2POp(dist.isend, x, 0), dist.P2POp(dist.irecv, y, 0)]     # the halo ring's send/recv pair, to itself
+for w in dist.batch_isend_irecv(ops): w.wait()
+torch.cuda.synchronize()
+assert bool((y == torch.arange(1024, device="cuda")).all())
+import ctypes
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps, "RCCL is not mapped"
+print("rccl ok", torch.cuda.nccl.version())
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_loads_and_reduces_at_world_size_one():
+    """The box proves RCCL loads: the nccl backend (= RCCL on ROCm) initialises at world size 1, an
+    all-reduce and a grouped send/recv pair (the C5 halo ring's primitive) run on the device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.check_output([sys.executable, "-c", _RCCL_PROBE], cwd=ROOT, env=env, timeout=300)
+    assert b"rccl ok" in out
+
+
+def test_c5_halo_through_the_native_ring():
+    """bench.py --workload c5 --halo ring at N = 1: the rank is its own ring neighbour, so every chunk's halo goes
+    through wr_ring_* -- ncclSend/ncclRecv on the ring's stream, posted a round ahead -- the branch a multi-GPU
+    node takes over nccl.  One exchange per step plus the one posted ahead."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--halo", "ring",
+                                   "--steps", "3", "--warmup", "1", "--settle-ms", "0"], cwd=ROOT)
+    j = _line(out)
+    assert j["n_gpus"] == 1 and j["config"]["halo"] == "ring" and "wr_ring" in j["config"]["workload"]
+    assert j["config"]["ring_exchanges"] == 3 + 1 + 1

@@ -46,6 +46,42 @@ def test_time_shard_single_rank_bit_identical(dev, nco):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_native_ring_world_one_bit_identical(dev):
+    """The C ABI's halo ring (wr_ring_*: ncclSend / ncclRecv on RCCL, its own stream, events to the device's
+    stream) at world size 1, where the rank is its own neighbour: every chunk's halo really travels through
+    ncclSend/ncclRecv, the chunks live in HBM, and the audio is the sequential pass's, bit for bit."""
+    import torch
+    from webradio_amd.device import Ring
+    assert Ring.rccl_version() > 20000                                   # RCCL loaded and answers (2.x.y -> 2xxyy)
+    iq = torch.from_numpy(_stream()).cuda()
+    shard = timeshard.TunerShard(dev, FS, IFS, 128_000, 5_000, capi.WR_FM, 160, 1_000, T + timeshard.halo_frames(D1, D2),
+                                 capi.WR_NCO_SPLIT)
+    ring = timeshard.RingHalo(None, 0, 1, dev=dev)
+    out = timeshard.run_time_sharded(ring, lambda c: iq[2 * c * T: 2 * (c + 1) * T], N, T, D1, D2, shard,
+                                     lambda a: a.contiguous(), lambda t: t)
+    assert ring.native.exchanges() == N
+    ring.close()
+    shard.close()
+    got = np.concatenate([out[c] for c in range(N)], axis=1)
+    want = _sequential(dev, capi.WR_NCO_SPLIT)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_ring_entry_points_argument_checks(dev):
+    """wr_ring_* fail with WR_ERR_ARG and a message on bad arguments, before RCCL is touched."""
+    import ctypes as C
+    lib = capi.load()
+    assert lib.wr_ring_id_bytes() == 128
+    h = C.c_void_p()
+    ident = (C.c_ubyte * 128)()
+    assert lib.wr_ring_make_id(ident, 64) == capi.WR_ERR_ARG
+    assert lib.wr_ring_create(C.byref(h), dev.h, ident, 128, 2, 2) == capi.WR_ERR_ARG      # rank out of range
+    assert lib.wr_ring_create(C.byref(h), None, ident, 128, 0, 1) == capi.WR_ERR_ARG
+    assert lib.wr_ring_exchange(None, None, None, 0) == capi.WR_ERR_ARG
+    assert lib.wr_ring_wait(None) == capi.WR_ERR_ARG and b"wr_ring_wait" in lib.wr_last_error()
+    assert lib.wr_ring_destroy(None) == capi.WR_OK
+
+
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     import torch

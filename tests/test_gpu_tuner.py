@@ -6,9 +6,12 @@ Tolerances (float32, |x| <= 1):
   WR_NCO_SPLIT  the LO comes from the two-level table: it differs from the reference's
                 table entry by <= 3.5e-7 (the reference table itself carries 2.4e-7 of
                 argument-rounding noise) and the taps are accumulated with FMAs, so
-                channel IQ is within IQ_ATOL = 1e-6 absolute; demod / audio on channels
-                that hold a carrier within AUDIO_ATOL = 1e-5 (FM is
-                ill-conditioned on noise-only channels, which are checked on IQ only).
+                channel IQ is within IQ_ATOL = 1e-6 absolute; FM audio on channels
+                that hold a carrier within AUDIO_ATOL = 1e-5, and on EVERY channel -- noise-only
+                ones too, where FM is ill-conditioned -- within what the channel's
+                own IQ difference allows: per demod frame 1.25 * (|dz[k]|/|z[k]| + |dz[k-1]|/|z[k-1]|)
+                / (2 pi) + 2.4e-7 cycles, through the audio filter's |taps| (tests/fm_bound.py;
+                the bound itself is tested on the CPU in tests/test_fm_bound.py).
   WR_NCO_ROTATE (default) the same table index per frame; each LO value is the anchor's turned
                 by a product of correctly rounded turns (Horner recurrence): same tolerances as
                 SPLIT, measured 1.3e-7 on channel IQ.
@@ -20,6 +23,7 @@ import pytest
 
 from webradio_amd import capi, synth
 from webradio_amd.device import Tuner
+import fm_bound
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +104,16 @@ def test_fast_nco_modes_within_tolerance(dev, oracle, nco):
             if cfg["ifs"][c] in car:                   # carrier present: demod is well conditioned
                 assert np.abs(ga - wa).max() <= AUDIO_ATOL, c
     assert worst_iq <= IQ_ATOL
+    # every FM channel, carrier or not: the audio differs by no more than its IQ difference allows
+    taps2 = oracle.lowpass_design(cfg["audio_pb"], cfg["chan_rate"])
+    d2 = cfg["chan_rate"] // cfg["audio_rate"]
+    checked = 0
+    for c in range(0, len(cfg["ifs"]), 2):              # the FM channels of [FM, AM]
+        cat = lambda which, idx: np.concatenate([blk[c][which][idx] for blk in results])
+        fm_bound.assert_fm_audio_within_iq_bound(cat(0, 1), cat(1, 1), cat(0, 0), cat(1, 0), taps2, d2,
+                                                 want_demod=cat(0, 2), what="channel %d" % c)
+        checked += 1
+    assert checked == len(cfg["ifs"]) // 2
     for (gph, _), (oph, _, _) in states:
         assert gph == oph                               # integer phase is exact in either mode
 
@@ -280,6 +294,16 @@ def test_c2_full_size_properties(dev, oracle, nco):
         assert worst <= 2.5e-7, worst
     for a, b in list(zip(outs[capi.WR_NCO_EXACT], outs[nco]))[::4]:      # carrier channels
         assert np.abs(a[1] - b[1]).max() <= AUDIO_ATOL
+    # ALL 256 channels, the 192 noise-only ones included: FM audio of the fast mode against the bit-exact mode
+    # within what the channel's own IQ difference allows (tests/fm_bound.py)
+    taps2 = oracle.lowpass_design(c2["audio_passband"], c2["chan_rate"])
+    worst_ratio = 0.0
+    for c, (a, b) in enumerate(zip(outs[capi.WR_NCO_EXACT], outs[nco])):
+        dem, _ = oracle.demod(oracle.FM, (0.0, 0.0), a[0])
+        _, ratio = fm_bound.assert_fm_audio_within_iq_bound(a[0], b[0], a[1], b[1], taps2, 5, want_demod=dem,
+                                                            what="channel %d" % c)
+        worst_ratio = max(worst_ratio, ratio)
+    assert worst_ratio <= 1.0
     # oracle on a prefix for three channels
     m = 200_000
     xh = x[: 2 * m].cpu().numpy()

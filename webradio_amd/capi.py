@@ -16,7 +16,7 @@ WR_AM, WR_FM, WR_USB, WR_LSB = range(4)
 WR_STAGE_CHAN_IQ, WR_STAGE_DEMOD, WR_STAGE_AUDIO = 1, 2, 3
 WR_NCO_SPLIT, WR_NCO_EXACT, WR_NCO_ROTATE = 0, 1, 2
 WR_HOST, WR_DEVICE = 0, 1
-WR_ABI_VERSION = 2            # include/webradio_amd.h
+WR_ABI_VERSION = 3            # include/webradio_amd.h
 WR_FIR_LENGTH = 64
 WR_TABLE_SIZE = 65536
 
@@ -84,6 +84,14 @@ SIGNATURES = {
     "wr_chan_slot": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "wr_tuner_fetch_audio_all": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_u32)]),
     "wr_chan_reset_history": (C.c_int, [_vp, C.c_int]),
+    "wr_ring_id_bytes": (C.c_int, []),
+    "wr_ring_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "wr_ring_make_id": (C.c_int, [_vp, _sz]),
+    "wr_ring_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, _sz, C.c_int, C.c_int]),
+    "wr_ring_exchange": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "wr_ring_wait": (C.c_int, [_vp]),
+    "wr_ring_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]),
+    "wr_ring_destroy": (C.c_int, [_vp]),
     "wr_tuner_set_audio_scale": (C.c_int, [_vp, C.c_float]),
     "wr_spectrum_get_waterfall_row": (C.c_int, [_vp, _u32, C.c_int, _vp, _vp]),
     "wr_tuner_profile": (C.c_int, [_vp, C.c_int]),

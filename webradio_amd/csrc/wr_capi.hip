@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -21,6 +23,15 @@
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+int wrc_fail(int code, const char *fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);
@@ -59,7 +70,8 @@ struct wr_dev {
 	 * under an enqueue in progress. */
 	std::mutex *scratch_lock;
 	hipEvent_t upload_done;    /* behind the last wr_dev_upload_async */
-	bool upload_pending;
+	std::atomic<bool> upload_pending;   /* uploads and waits may come from different threads */
+	std::map<void *, size_t> *registered;   /* host ranges THIS library page-locked (wr_dev_host_register), under scratch_lock */
 };
 #define SCRATCH_GUARD(d) std::lock_guard<std::mutex> scratch_guard_(*(d)->scratch_lock)
 
@@ -304,7 +316,7 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	wr_dev *d = new (std::nothrow) wr_dev();
 	if (!d)
 		return fail(WR_ERR_NOMEM, "out of memory");
-	memset(d, 0, sizeof(*d));
+	/* (value-initialised: every member zero) */
 	d->device = device_index;
 	d->num_cus = prop.multiProcessorCount;
 	/* NULL selects HIP's default (null) stream -- which is also what
@@ -319,9 +331,11 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	int rc = WR_OK;
 	d->turn_host = (float *)malloc(WR_TABLE_SIZE * sizeof(float));
 	d->scratch_lock = new (std::nothrow) std::mutex();
-	if (!d->turn_host || !d->scratch_lock) {
+	d->registered = new (std::nothrow) std::map<void *, size_t>();
+	if (!d->turn_host || !d->scratch_lock || !d->registered) {
 		free(d->turn_host);
 		delete d->scratch_lock;
+		delete d->registered;
 		delete d;
 		return fail(WR_ERR_NOMEM, "out of memory");
 	}
@@ -359,6 +373,10 @@ extern "C" int wr_dev_close(wr_dev *d)
 	(void)hipFree(d->coeff);
 	(void)hipFree(d->scratch);
 	free(d->turn_host);
+	if (d->registered)
+		for (auto &r : *d->registered)              /* what the caller forgot to release */
+			(void)hipHostUnregister(r.first);
+	delete d->registered;
 	delete d->scratch_lock;
 	if (d->upload_done)
 		(void)hipEventDestroy(d->upload_done);
@@ -377,6 +395,8 @@ extern "C" int wr_dev_sync(wr_dev *d)
 }
 
 extern "C" void *wr_dev_stream(wr_dev *d) { return d ? (void *)d->stream : nullptr; }
+int wrc_dev_index(const wr_dev *d) { return d->device; }
+hipStream_t wrc_dev_stream(const wr_dev *d) { return d->stream; }
 
 extern "C" int wr_dev_malloc(wr_dev *d, size_t bytes, void **ptr_dev)
 {
@@ -420,17 +440,27 @@ extern "C" int wr_dev_host_register(wr_dev *d, void *host, size_t bytes)
 		return fail(WR_ERR_ARG, "wr_dev_host_register: bad argument");
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	SCRATCH_GUARD(d);
 	hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
 	if (e == hipErrorHostMemoryAlreadyRegistered) {
-		/* a range registered earlier whose memory was freed and handed out again by the allocator */
 		(void)hipGetLastError();
+		auto own = d->registered->find(host);
+		if (own == d->registered->end())
+			/* page-locked by somebody else (the application, torch, another library): that is all
+			 * this call is for -- it is neither undone nor recorded, and wr_dev_host_unregister
+			 * will leave it alone */
+			return WR_OK;
+		/* one of OURS whose memory was freed and handed out again by the allocator, perhaps with
+		 * another length: register the range as it is now */
 		(void)hipHostUnregister(host);
+		d->registered->erase(own);
 		e = hipHostRegister(host, bytes, hipHostRegisterDefault);
 	}
 	if (e != hipSuccess) {
 		(void)hipGetLastError();                    /* not sticky: a later launch check must not trip over it */
 		return fail(WR_ERR_HIP, "wr_dev_host_register: %s", hipGetErrorString(e));
 	}
+	(*d->registered)[host] = bytes;
 	return WR_OK;
 }
 
@@ -440,6 +470,11 @@ extern "C" int wr_dev_host_unregister(wr_dev *d, void *host)
 		return fail(WR_ERR_ARG, "wr_dev_host_unregister: bad argument");
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	SCRATCH_GUARD(d);
+	auto own = d->registered->find(host);
+	if (own == d->registered->end())
+		return WR_OK;                               /* not page-locked by this library: not ours to release */
+	d->registered->erase(own);
 	hipError_t e = hipHostUnregister(host);
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
@@ -753,9 +788,14 @@ static int settle_held(wr_tuner *t)
 	return tuner_launch_held(t);
 }
 
+/* why the last chan_get() of this thread returned no channel: the error of sending the held blocks
+ * out (already in wr_last_error()), or WR_OK when there simply is no such channel */
+static thread_local int g_settle_rc = WR_OK;
+
 static Chan *chan_get(wr_tuner *t, int chan)
 {
-	if (settle_held(t))
+	g_settle_rc = settle_held(t);
+	if (g_settle_rc)
 		return nullptr;
 	if (!t || chan < 0 || (size_t)chan >= t->chans.size() || !t->chans[chan].in_use)
 		return nullptr;
@@ -801,7 +841,7 @@ extern "C" int wr_chan_remove(wr_tuner *t, int chan)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_remove: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_remove: no channel %d", chan);
 	int rc = chan_unseat(t, *c, false);
 	c->in_use = false;
 	return rc;
@@ -904,7 +944,7 @@ extern "C" int wr_chan_set_if(wr_tuner *t, int chan, int if_hz)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_set_if: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_if: no channel %d", chan);
 	c->if_hz = if_hz;
 	c->stepL = (unsigned int)wrd_phase_step(if_hz, t->input_rate) << 1;
 	if (c->group >= 0)
@@ -916,7 +956,7 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "no channel %d", chan);
 	if (stage < 0 || stage > 2)
 		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
 	if (!decim)
@@ -961,7 +1001,7 @@ extern "C" int wr_chan_set_filter_n(wr_tuner *t, int chan, int stage, unsigned i
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_set_filter: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_filter: no channel %d", chan);
 	if (stage < 0 || stage > 2)
 		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
 	if (!fused_fir_length_ok(fir_length))
@@ -998,7 +1038,7 @@ extern "C" int wr_chan_set_mode(wr_tuner *t, int chan, int mode)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_set_mode: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_mode: no channel %d", chan);
 	if (mode < WR_AM || mode > WR_LSB)
 		return fail(WR_ERR_ARG, "wr_chan_set_mode: bad mode %d", mode);
 	c->mode = mode;
@@ -1014,7 +1054,7 @@ extern "C" int wr_chan_set_af_gain(wr_tuner *t, int chan, float gain_db)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_set_af_gain: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_af_gain: no channel %d", chan);
 	if (!(gain_db == gain_db) || gain_db < -200.0f || gain_db > 200.0f)
 		return fail(WR_ERR_ARG, "wr_chan_set_af_gain: %g dB", (double)gain_db);
 	c->gain = (float)pow(10.0, (double)gain_db / 20.0);
@@ -1027,7 +1067,7 @@ extern "C" int wr_chan_set_squelch(wr_tuner *t, int chan, float threshold_dbfs, 
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_set_squelch: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_squelch: no channel %d", chan);
 	if (enable && (!(threshold_dbfs == threshold_dbfs) || threshold_dbfs < -300.0f || threshold_dbfs > 100.0f))
 		return fail(WR_ERR_ARG, "wr_chan_set_squelch: %g dBFS", (double)threshold_dbfs);
 	c->squelch = enable ? (float)pow(10.0, (double)threshold_dbfs / 10.0) : 0.0f;
@@ -1050,7 +1090,7 @@ extern "C" int wr_chan_get_state(wr_tuner *t, int chan, unsigned int *phase, flo
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_get_state: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_get_state: no channel %d", chan);
 	if (phase)
 		*phase = c->phaseL >> 1;
 	if (prev_iq) {
@@ -1077,7 +1117,7 @@ extern "C" int wr_chan_set_state(wr_tuner *t, int chan, unsigned int phase, cons
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_set_state: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_state: no channel %d", chan);
 	c->phaseL = phase << 1;
 	c->phase_dirty = true;
 	if (prev_iq) {
@@ -1094,7 +1134,7 @@ extern "C" int wr_chan_slot(wr_tuner *t, int chan, int *slot)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c || !slot)
-		return fail(WR_ERR_ARG, "wr_chan_slot: bad argument");
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_slot: bad argument");
 	if (c->group < 0)
 		return fail(WR_ERR_STATE, "channel %d has no filters yet", chan);
 	*slot = c->slot;
@@ -1393,10 +1433,28 @@ static bool block_can_be_held(const wr_tuner *t, size_t nframes)
 	return true;
 }
 
+/* what a submit can be refused for before anything is enqueued -- checked before a block is HELD too,
+ * so that a held wr_tuner_submit never returns WR_OK for a block a later call would have to refuse */
+static int submit_precheck(const wr_tuner *t, size_t nframes, int where)
+{
+	if (nframes > t->max_block_frames)
+		return fail(WR_ERR_ARG, "wr_tuner_submit: %zu frames exceeds max_block_frames %zu", nframes,
+		            t->max_block_frames);
+	if (where != WR_HOST && where != WR_DEVICE)
+		return fail(WR_ERR_ARG, "wr_tuner_submit: bad `where`");
+	for (const Chan &c : t->chans)
+		if (c.in_use && c.group < 0)
+			return fail(WR_ERR_STATE, "a channel has no filters (LowPass::init: \"Must specify either "
+			                          "decimation or output rate\")");
+	return WR_OK;
+}
+
 static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8)
 {
 	if (!t || (nframes && !iq))
 		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
+	if (int rc = submit_precheck(t, nframes, where))
+		return rc;
 	if (t->coalesce > 1 && where == WR_DEVICE && !u8 && nframes && block_can_be_held(t, nframes)) {
 		const float *p = (const float *)iq;
 		/* (a setter called since the last submit has sent the held blocks out already: settle_held) */
@@ -1430,15 +1488,8 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 {
 	if (!t || (nframes && !iq))
 		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
-	if (nframes > t->max_block_frames)
-		return fail(WR_ERR_ARG, "wr_tuner_submit: %zu frames exceeds max_block_frames %zu", nframes,
-		            t->max_block_frames);
-	if (where != WR_HOST && where != WR_DEVICE)
-		return fail(WR_ERR_ARG, "wr_tuner_submit: bad `where`");
-	for (const Chan &c : t->chans)
-		if (c.in_use && c.group < 0)
-			return fail(WR_ERR_STATE, "a channel has no filters (LowPass::init: \"Must specify either "
-			                          "decimation or output rate\")");
+	if (int rc = submit_precheck(t, nframes, where))
+		return rc;
 	wr_dev *d = t->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
@@ -1515,6 +1566,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			L.ev_stop = t->ev[t->ev_used + 1];
 		}
 		if (group_first && !(t->ev_used & 1)) {
+			/* (once per submit: the first rate group's launch is the first of the bracket) */
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
 			t->ev_used += 1;
 		}
@@ -1526,12 +1578,6 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		if (prof_now) {
 			t->ev_span.resize(t->ev_used / 2 + 1, 1u);
 			t->ev_used += 2;
-		}
-		if (group_last && (t->ev_used & 1)) {
-			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
-			t->ev_span.resize(t->ev_used / 2 + 1, 1u);
-			t->ev_span[t->ev_used / 2] = t->prof_stride;
-			t->ev_used += 1;
 		}
 		if (g->post_pending) {
 			if (!rode)
@@ -1587,6 +1633,14 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		g->last_k1 = Lp.k1;            /* frames at the demodulator's input */
 		g->last_k2 = Lp.k2;
 	}
+	/* the bracket of a profiling stride closes behind the LAST rate group's launches of its last submit
+	 * (it used to close behind the first group's: the others' launches were credited and not timed) */
+	if (group_last && (t->ev_used & 1)) {
+		HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
+		t->ev_span.resize(t->ev_used / 2 + 1, 1u);
+		t->ev_span[t->ev_used / 2] = t->prof_stride;
+		t->ev_used += 1;
+	}
 	if (!hist_written)
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
 	t->in_par ^= 1;
@@ -1628,7 +1682,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 {
 	Chan *c = chan_get(t, chan);
 	if (!c || !count)
-		return fail(WR_ERR_ARG, "wr_chan_fetch: bad argument");
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_fetch: bad argument");
 	if (c->group < 0 || !t->submitted)
 		return fail(WR_ERR_STATE, "wr_chan_fetch: nothing submitted yet");
 	Group *g = t->groups[c->group];
@@ -1923,7 +1977,7 @@ extern "C" int wr_chan_reset_history(wr_tuner *t, int chan)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
-		return fail(WR_ERR_ARG, "wr_chan_reset_history: no channel %d", chan);
+		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_reset_history: no channel %d", chan);
 	c->cs_hist_reset = true;
 	c->dem_hist_reset = true;
 	if (c->group >= 0)

@@ -19,6 +19,11 @@
                                               receivers of one tuner mostly share a passband (radio.cxx:78-79),
                                               the UI lets each choose its own (receiverhandler.cxx:130-137) */
 
+/* ---- what other translation units need of a wr_dev (wr_capi.hip) ---- */
+int         wrc_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));   /* sets wr_last_error() */
+int         wrc_dev_index(const wr_dev *dev);
+hipStream_t wrc_dev_stream(const wr_dev *dev);
+
 /* ---- host design math (wr_design.cpp) ---- */
 void     wrd_sin_table(float *table);
 void     wrd_sin_table_rounded(float *table);

@@ -289,3 +289,47 @@ class Spectrum:
 
     def batch_db(self, iq_dev, nframes_fft, db_dev):
         check(self.lib.wr_spectrum_batch_db(self.h, ptr(iq_dev), nframes_fft, ptr(db_dev)))
+
+
+class Ring:
+    """wr_ring: the halo ring of a time-sharded stream (BASELINE config 5) on RCCL -- one
+    ncclSend / ncclRecv pair per exchange, on its own stream, handed to the device's stream by
+    events.  `id_bytes`: what rank 0's Ring.make_id() returned, brought to every rank by the host."""
+
+    @staticmethod
+    def make_id():
+        lib = capi.load()
+        buf = (C.c_ubyte * lib.wr_ring_id_bytes())()
+        check(lib.wr_ring_make_id(buf, len(buf)))
+        return bytes(buf)
+
+    @staticmethod
+    def rccl_version():
+        v = C.c_int()
+        check(capi.load().wr_ring_version(C.byref(v)))
+        return v.value
+
+    def __init__(self, dev, id_bytes, rank, world):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        buf = (C.c_ubyte * len(id_bytes)).from_buffer_copy(id_bytes)
+        check(self.lib.wr_ring_create(C.byref(h), dev.h, buf, len(id_bytes), rank, world))
+        self.h, self.rank, self.world = h, rank, world
+
+    def exchange(self, send_dev, recv_dev, nfloats):
+        """enqueue: send_dev -> rank + 1, recv_dev <- rank - 1 (device pointers or torch tensors)"""
+        check(self.lib.wr_ring_exchange(self.h, ptr(send_dev), ptr(recv_dev), nfloats))
+
+    def wait(self):
+        """the device's stream waits for the last exchange (no host wait)"""
+        check(self.lib.wr_ring_wait(self.h))
+
+    def exchanges(self):
+        n = C.c_ulonglong()
+        check(self.lib.wr_ring_info(self.h, None, None, C.byref(n)))
+        return n.value
+
+    def destroy(self):
+        if self.h:
+            self.lib.wr_ring_destroy(self.h)
+            self.h = None

@@ -246,7 +246,7 @@ void DevBuf::release()
 TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
-	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateQueued(false), _silence(false)
+	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateQueued(false), _silence(false), _lateSeq(0)
 {
 }
 
@@ -373,6 +373,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 	ch->batch = batch;
 	ch->id = id;
 	ch->slot = -1;
+	ch->lateSeq = ~0ull;
 	ch->mixer = mixer;
 	ch->chanFilter = f1;
 	ch->chanFilter2 = f1b;
@@ -518,10 +519,16 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
+	++_lateSeq;                            /* blocks submitted so far */
 	if (pushed)                            /* a filter change may have moved a channel to another rate group */
-		for (size_t n = 0; n < _channels.size(); n++)
+		for (size_t n = 0; n < _channels.size(); n++) {
+			const int before = _channels[n]->slot;
 			if (wr_chan_slot(_tuner, _channels[n]->id, &_channels[n]->slot) != WR_OK)
 				_channels[n]->slot = -1;
+			if (_channels[n]->slot != before)
+				_channels[n]->lateSeq = _lateSeq;          /* this block is the first in that slot: the ring entry
+				                                              of the block before it is not this channel's */
+		}
 	/* the graph hands this block's audio on within this very run(): no waiting for the next launch */
 	wr_tuner_flush(_tuner);
 	traceAdd(_source, 'S');
@@ -598,8 +605,9 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 
 bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 {
-	/* no lock: called on the run thread only, after this block's submitOnce() on the same thread
-	 * (the setters on other threads touch Channel::dirty and the blocks' own members, not these) */
+	/* under the batch lock: withdraw() / unfuseChainOf() may run on an HTTP thread (a consumer connected
+	 * inside a fused chain) while the run thread hands audio out; uncontended it costs 256 x ~20 ns a block */
+	std::lock_guard<std::mutex> g(_lock);
 	if (!_submitOk)
 		return false;
 	if (out.empty())
@@ -609,11 +617,20 @@ bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 		return true;
 	}
 	const int slot = ch->slot;
-	if (_audioSlots && slot >= 0 && (unsigned int)slot < _audioSlots && _audioFrames == out.size()) {
+	if (_audioSlots && slot >= 0 && (unsigned int)slot < _audioSlots && _audioFrames == out.size() &&
+	    (!_late || ch->lateSeq < _lateSeq)) {
 		memcpy(out.data(), _audioPtr + (size_t)slot * _audioStride, out.size() * sizeof(float));
 		return true;
 	}
-	std::lock_guard<std::mutex> g(_lock);
+	if (_late && _audioSlots) {
+		/* One block late, and the ring entry is not this channel's previous block: another block length
+		 * (a ragged block, a changed audio rate), or a channel enrolled (or moved to this slot) with the
+		 * block just submitted, whose slot held somebody else's audio a block ago.  Fetching now would hand
+		 * out the CURRENT block -- and the next run() the same block again from the ring.  The sinks get a
+		 * block of silence instead, exactly as at the start of the stream. */
+		memset(out.data(), 0, out.size() * sizeof(float));
+		return true;
+	}
 	size_t got = 0;
 	if (wr_chan_fetch(_tuner, ch->id, WR_STAGE_AUDIO, out.data(), out.size(), &got) != WR_OK) {
 		LOG_ERROR("wr_chan_fetch: %s\n", wr_last_error());

@@ -81,6 +81,8 @@ struct Channel {
 	Demodulator *demod;
 	LowPass *audioFilter;
 	bool dirty;                   /* parameters changed since the last submit */
+	unsigned long long lateSeq;   /* the first block (counted from 1) submitted with the channel in `slot`: an
+	                                 older ring entry's row `slot` is not this channel's (WEBRADIO_AUDIO_LATE) */
 };
 
 class TunerBatch {
@@ -128,6 +130,7 @@ private:
 	bool _late;                       /* WEBRADIO_AUDIO_LATE: hand out the PREVIOUS block's audio (see submitOnce) */
 	bool _lateQueued;                 /* a block has been submitted whose audio has not been handed out yet */
 	bool _silence;                    /* late mode, first block: nothing to hand out yet */
+	unsigned long long _lateSeq;      /* blocks submitted so far */
 	std::mutex _lock;
 };
 

@@ -43,15 +43,40 @@ def phase_at(step, frame):
 
 
 class RingHalo:
-    """Tail-of-chunk exchange between ring neighbours: rank r sends to r+1, receives from r-1."""
+    """Tail-of-chunk exchange between ring neighbours: rank r sends to r+1, receives from r-1.
 
-    def __init__(self, dist, rank, world):
+    A thin caller.  With a wr_dev (`dev`) the pair goes through the C ABI's wr_ring_* -- RCCL's
+    ncclSend / ncclRecv directly, on the ring's own stream, so `post` can be issued a round ahead and
+    `wait` costs the device's stream one event (bench.py --workload c5).  Without one (the CPU
+    tests' gloo ranks, host tensors) it is torch.distributed's batch_isend_irecv, synchronous."""
+
+    def __init__(self, dist, rank, world, dev=None):
         self.dist, self.rank, self.world = dist, rank, world
+        self.native = None
+        if dev is not None:
+            from .device import Ring
+            ident = [Ring.make_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0)        # 128 bytes, once
+            self.native = Ring(dev, ident[0], rank, world)
+
+    def post(self, tail, recv):
+        """native only: enqueue the pair (tail -> rank + 1, recv <- rank - 1) behind what the device's
+        stream holds now; returns at once"""
+        self.native.exchange(tail, recv, tail.numel())
+
+    def wait(self):
+        self.native.wait()
 
     def exchange(self, tail):
         """tail: 1-D float32 torch tensor (2*H floats) on the backend's device.  Returns the
-        tail sent by the previous rank (None for world == 1)."""
+        tail sent by the previous rank (None for world == 1 without a native ring)."""
         import torch
+        if self.native is not None:
+            recv = torch.empty_like(tail)
+            self.post(tail, recv)
+            self.wait()
+            return recv
         if self.world == 1:
             return None
         recv = torch.empty_like(tail)
@@ -60,6 +85,11 @@ class RingHalo:
         for req in self.dist.batch_isend_irecv(ops):
             req.wait()
         return recv
+
+    def close(self):
+        if self.native is not None:
+            self.native.destroy()
+            self.native = None
 
 
 def run_time_sharded(ring, get_chunk, nchunks, chunk_frames, d1, d2, process, to_tensor, from_tensor):
@@ -85,7 +115,7 @@ def run_time_sharded(ring, get_chunk, nchunks, chunk_frames, d1, d2, process, to
         chunk = get_chunk(c) if have else get_chunk(nchunks - 1)     # idle ranks still take part in the ring
         tail = to_tensor(chunk[2 * (chunk_frames - H):])
         received = ring.exchange(tail)
-        if world == 1:
+        if world == 1 and received is None:
             halo, carried = carried, chunk[2 * (chunk_frames - H):]
         elif rank == 0:
             halo, carried = carried, from_tensor(received)           # needed next round
