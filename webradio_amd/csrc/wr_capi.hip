@@ -125,6 +125,7 @@ struct Group {
 	unsigned long long fewsets_mask = 0; /* bit i: lane group i has at most WR_TAPSETS distinct channel filters
 	                                        (the others take the per-lane-taps kernel) */
 	unsigned char nsets[64] = {0};       /* how many */
+	bool one_filter = false;             /* ONE channel filter for every channel of the group */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -1214,6 +1215,8 @@ static int group_upload(wr_tuner *t, Group *g)
 	 * folds the taps into the shared sample window, one copy of the window per distinct filter (up
 	 * to WR_TAPSETS); a lane group with more than that takes the per-lane-taps kernel. */
 	bool uniform = true;
+	int first_rep = -1;                  /* a channel of the first lane group that has any */
+	bool one_filter = true;
 	unsigned long long umask = 0, fmask = 0;
 	std::vector<float> taps1u(S * WR_TAPSETS, 0.0f);
 	std::vector<int> tapsel(S, 0);
@@ -1239,6 +1242,13 @@ static int group_upload(wr_tuner *t, Group *g)
 				reps[nrep++] = ci;
 			}
 			tapsel[s] = (int)q;
+		}
+		if (nrep) {
+			if (first_rep < 0)
+				first_rep = reps[0];
+			if (nrep > 1 || !few ||
+			    memcmp(t->chans[reps[0]].taps[0], t->chans[first_rep].taps[0], sizeof(float) * WR_FIR_LENGTH))
+				one_filter = false;
 		}
 		if (!few || grp >= 64) {
 			for (size_t s = base; s < base + WR_LANES; ++s)
@@ -1282,6 +1292,13 @@ static int group_upload(wr_tuner *t, Group *g)
 	g->uniform_taps = uniform;
 	g->uniform_mask = umask;
 	g->fewsets_mask = fmask;
+	g->one_filter = one_filter && first_rep >= 0;
+	if (g->one_filter)
+		/* two lane groups that share a wave take the window from the first one's entry: an emptied lane
+		 * group in between holds the common filter too */
+		for (size_t grp = 0; grp < S / WR_LANES; ++grp)
+			for (size_t j = 0; j < WR_LANES; ++j)
+				taps1u[(grp * WR_TAPSETS) * WR_LANES + j] = t->chans[first_rep].taps[0][WR_FIR_LENGTH - 1 - j];
 	/* per-slot turns of the ROTATE NCO (see WrGroupDev) */
 	std::vector<float> rot(S * 4, 0.0f);
 	{
@@ -1546,6 +1563,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		L.uniform_mask = g->uniform_mask;
 		L.uniform2_mask = g->uniform2_mask;
 		L.fewsets_mask = g->fewsets_mask;
+		L.one_filter = g->one_filter ? 1 : 0;
 		memcpy(L.nsets, g->nsets, sizeof(L.nsets));
 		L.audio_scale = t->audio_scale;
 		L.use_gain = g->use_gain ? 1 : 0;

@@ -95,6 +95,7 @@ struct WrTunerLaunch {
 	unsigned long long uniform2_mask;  /* bit g: ... and ONE audio filter (WrGroupDev::taps2u) */
 	unsigned long long fewsets_mask;   /* bit g: lane group g has at most WR_TAPSETS distinct channel filters */
 	unsigned char nsets[64];           /* distinct channel filters of lane group g (valid where fewsets_mask says) */
+	int          one_filter;           /* every channel of the rate group uses ONE and the same channel filter */
 	void        *ev_start, *ev_stop;   /* hipEvent_t pair the DDC launch itself stamps (profiling), or NULL */
 };
 

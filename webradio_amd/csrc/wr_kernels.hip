@@ -704,29 +704,49 @@ k_tuner_post(WrPostArgs A)
  * PREVIOUS block -- see post_role and wr_capi.hip: the two have nothing to do with each other
  * except that they share the CUs, the post stage's latency-bound phases filling in between the
  * DDC's arithmetic.  Their dependency is the kernel boundary before this launch. */
+/* r03: with DDC_ROLES the ROTATE kernel with folded taps splits its workgroups into roles:
+ *   [0, n_ddc)               the persistent DDC waves: output frames kslow .. k1-1, whose 64-frame windows lie
+ *                            inside this block -- ONE lean loop in the kernel itself, nothing else in its registers
+ *   [n_ddc, n_ddc + n_bnd)   one wave per (lane group, frame k < kslow): the first ceil(63 / D1) frames of the
+ *                            block, whose windows reach into the previous one (history rows, kept turns)
+ *   [n_ddc + n_bnd, ...)     the previous block's post stage (PD2 != 0)
+ * Everything but the lean loop is ddc_body, which the lean kernel reaches through a real call (its register
+ * allocation is its own).  Kernels without roles (kslow = n_bnd = 0) ARE ddc_body: one generic loop. */
+#ifndef DDC_ROLES
+#define DDC_ROLES 1
+#endif
+#ifndef DDC_NG2
+#define DDC_NG2 1                          /* two lane groups per wave of the lean loop where the launch allows */
+#endif
+#define DDC_PARAMS \
+	const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, const float2 *__restrict__ hist, \
+	float2 *__restrict__ hist_next, size_t nframes, size_t k1, unsigned int d1, unsigned int slots, unsigned int groups, \
+	const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step, \
+	const float2 *__restrict__ hist_cs, const int *__restrict__ flags, \
+	unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next, \
+	const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next, \
+	const float *__restrict__ taps1, const float4 *__restrict__ rot, const float *__restrict__ taps1u, \
+	const int *__restrict__ tapsel, unsigned int kmax, float2 *__restrict__ chan_iq, \
+	const float *__restrict__ table, const float2 *__restrict__ hi_cs, const float2 *__restrict__ lo_cs, \
+	unsigned int n_ddc, const WrPostArgs &post, unsigned long long gmap0, unsigned long long gmap1, int whole, \
+	unsigned int kslow, unsigned int n_bnd
+#define DDC_PASS \
+	cur, cur_u8, hist, hist_next, nframes, k1, d1, slots, groups, phase, step, hist_cs, flags, phase_next, hist_cs_next, \
+	hist_lo, hist_lo_next, taps1, rot, taps1u, tapsel, kmax, chan_iq, table, hi_cs, lo_cs, n_ddc, post, gmap0, gmap1, \
+	whole, kslow, n_bnd
+#define DDC_ROLE_ALL      0                /* no roles: every frame, the state roll, the riding post stage */
+#define DDC_ROLE_BOUNDARY 1                /* one block-boundary unit per wave (or the post stage, by workgroup index) */
+#define DDC_ROLE_ROLL     2                /* the end-of-block state roll only */
+
 template <int NCO, bool UTAPS, unsigned int PD2>
-__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL) ? DDC_ROTATE_WGS_PER_CU * DDC_ROTATE_WAVES / 4u : DDC_WAVES / 4u)))
-k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
-            const float2 *__restrict__ hist,
-            float2 *__restrict__ hist_next, size_t nframes, size_t k1,
-            unsigned int d1, unsigned int slots, unsigned int groups,
-            const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-            const float2 *__restrict__ hist_cs, const int *__restrict__ flags,
-            unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next,
-            const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
-            const float *__restrict__ taps1, const float4 *__restrict__ rot, const float *__restrict__ taps1u,
-            const int *__restrict__ tapsel, unsigned int kmax,
-            float2 *__restrict__ chan_iq,
-            const float *__restrict__ table, const float2 *__restrict__ hi_cs,
-            const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post,
-            unsigned long long gmap0, unsigned long long gmap1, int whole)
+__device__ __forceinline__ void
+ddc_body(DDC_PARAMS, v2f *lds, const int role)
 {
-	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
-	if (PD2 != 0u && blockIdx.x >= n_ddc) {
+	if (PD2 != 0u && role != DDC_ROLE_ROLL && blockIdx.x >= n_ddc + n_bnd) {
 		/* latency-bound tenants: a chain of loads, barriers and short bursts of arithmetic */
 		wave_prio(3u);
 		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
-		const unsigned int idx = blockIdx.x - n_ddc;
+		const unsigned int idx = blockIdx.x - n_ddc - n_bnd;
 		if (threadIdx.x >= POST_THREADS)
 			return;                                     /* (workgroups of the per-lane-taps variant have 16 waves) */
 		float *stage = (float *)lds;
@@ -774,7 +794,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 * so no reader of `hist` in this launch is disturbed. */
 	/* (`whole`: this launch covers every lane group of the rate group, or is the first of the
 	 * two launches that between them do -- it then also rolls the state of ALL channels) */
-	if (whole && blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
+	if (whole && role != DDC_ROLE_ROLL && blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
 		const size_t f = nframes + lane;            /* frame index in [hist | cur] */
 		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
 	}
@@ -791,12 +811,21 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	/* ROTATE with per-lane taps keeps the taps of ONE lane group in LDS (16 KiB) instead of 64
 	 * registers per lane: there a whole workgroup keeps to one group */
 	constexpr bool LTAPS = (NCO == WR_NCO_ROTATE) && !UTAPS;
-	const unsigned int wpg = LTAPS ? (n_ddc / groups) * waves_per_wg : nwaves / groups;   /* >= 1: see the launcher */
+	unsigned int wpg = LTAPS ? (n_ddc / groups) * waves_per_wg : nwaves / groups;   /* >= 1: see the launcher */
+	/* a wave of the block-boundary workgroups: ONE unit, frame k < kslow of one lane group */
+	const bool bnd = role == DDC_ROLE_BOUNDARY;
+	const unsigned int ub = bnd ? (blockIdx.x - n_ddc) * waves_per_wg + wave : 0u;
 	/* `groups` lane groups take part in this launch; which ones: 16 one-byte entries */
-	const unsigned int gl = LTAPS ? blockIdx.x % groups : wid % groups;
+	const unsigned int gl = bnd ? ub % groups : LTAPS ? blockIdx.x % groups : wid % groups;
 	const unsigned int g = (unsigned int)(((gl < 8u ? gmap0 : gmap1) >> ((gl & 7u) * 8u)) & 255u);
-	unsigned int k = LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
-	if (k >= wpg) {
+	unsigned int k = bnd ? ub / groups : LTAPS ? (blockIdx.x / groups) * waves_per_wg + wave : wid / groups;
+	if (role == DDC_ROLE_ROLL) {
+		k = k1u;                                         /* no units: straight to the end-of-block state */
+	} else if (bnd) {
+		if (k >= kslow)
+			k = k1u;
+		wpg = k1u;                                       /* one unit, then out of the loop */
+	} else if (k >= wpg) {
 		k = k1u;                                         /* the few waves left over stay idle */
 	} else if (!LTAPS && DDC_DEAL_WAYS > 1u) {
 		/* A wave that starts at k does ceil((k1 - k) / wpg) units: the low starts one more than the
@@ -1153,7 +1182,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	 * (at the head of the kernel its dependent loads sat in front of the first unit). */
 	const unsigned int roll_wgs = (WR_FIR_LENGTH * slots + blockDim.x - 1u) / blockDim.x;
 	const unsigned int roll_first = n_ddc > roll_wgs ? n_ddc - roll_wgs : 0u;
-	if (whole && blockIdx.x >= roll_first) {
+	if (whole && blockIdx.x >= roll_first && blockIdx.x < n_ddc) {
 		const unsigned int nlo = (unsigned int)nframes;
 		const unsigned int gtid = (blockIdx.x - roll_first) * blockDim.x + threadIdx.x, gsz = (n_ddc - roll_first) * blockDim.x;
 		for (unsigned int s = gtid; s < slots; s += gsz) {
@@ -1196,6 +1225,300 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 		}
 	}
 
+	TL(11);
+}
+
+/* (The roles of the lean kernel that are not its loop are ddc_body INLINED at two places -- ahead of the
+ * loop, for the workgroups that never enter it, and behind it with role = DDC_ROLE_ROLL, which folds
+ * everything but the state roll away.  As a real call (tried) the kernel needs 936 bytes of stack per lane
+ * for the 35 arguments and the call-clobbered registers: half a gigabyte of scratch for a full grid, which
+ * the runtime then allocates and frees around EVERY dispatch -- 61 us per launch instead of 35.) */
+#ifndef DDC_RD
+#define DDC_RD 1                           /* lean loop: 16-byte window reads issued ahead of the taps, per stage */
+#endif
+
+/* NG: lane groups (recurrences) per wave of the lean loop.  The ROTATE tap is a chain -- every Horner step
+ * waits for the one before it, and the carry travels add -> VCC -> select -> FMA -- so ONE recurrence per wave
+ * needs eight waves per SIMD to reach 138 G wave-taps/s, while TWO independent ones per wave, one after the
+ * other tap by tap, reach the issue ceiling (150-152 G, = the rate of plain independent FMAs) with as few as
+ * two waves per SIMD (tools/ubench_tap.hip, profiles/r03_ubench_tap.txt).  The two recurrences are two lane
+ * groups at the same output frame: they share the window and every one of its LDS reads.  NG = 2 takes an even
+ * number of lane groups that all use ONE and the same channel filter (the host says: WrTunerLaunch::one_filter)
+ * and 80 registers (6 waves per SIMD); otherwise NG = 1, as before. */
+#ifndef DDC_NG2_WAVES_PER_EU
+#define DDC_NG2_WAVES_PER_EU 6u
+#endif
+template <int NCO, bool UTAPS, unsigned int NG> struct DdcOcc {
+	static constexpr unsigned int per_eu = (NG == 2u) ? DDC_NG2_WAVES_PER_EU
+	                                       : (NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL)) ? DDC_ROTATE_WGS_PER_CU * DDC_ROTATE_WAVES / 4u
+	                                       : DDC_WAVES / 4u;
+};
+
+template <int NCO, bool UTAPS, unsigned int PD2, unsigned int NG>
+__global__ void __launch_bounds__(DDC_WAVES * 64u) __attribute__((amdgpu_waves_per_eu(DdcOcc<NCO, UTAPS, NG>::per_eu)))
+k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
+            const float2 *__restrict__ hist,
+            float2 *__restrict__ hist_next, size_t nframes, size_t k1,
+            unsigned int d1, unsigned int slots, unsigned int groups,
+            const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+            const float2 *__restrict__ hist_cs, const int *__restrict__ flags,
+            unsigned int *__restrict__ phase_next, float2 *__restrict__ hist_cs_next,
+            const float2 *__restrict__ hist_lo, float2 *__restrict__ hist_lo_next,
+            const float *__restrict__ taps1, const float4 *__restrict__ rot, const float *__restrict__ taps1u,
+            const int *__restrict__ tapsel, unsigned int kmax,
+            float2 *__restrict__ chan_iq,
+            const float *__restrict__ table, const float2 *__restrict__ hi_cs,
+            const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post,
+            unsigned long long gmap0, unsigned long long gmap1, int whole, unsigned int kslow, unsigned int n_bnd)
+{
+	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
+	constexpr bool ROLES = DDC_ROLES && NCO == WR_NCO_ROTATE && UTAPS;
+	static_assert(NG == 1u || (NG == 2u && ROLES), "two recurrences per wave: the lean loop only");
+	if constexpr (!ROLES) {
+		ddc_body<NCO, UTAPS, PD2>(DDC_PASS, lds, DDC_ROLE_ALL);
+		return;
+	}
+	if (blockIdx.x >= n_ddc) {
+		/* a block-boundary unit per wave, or (by workgroup index) the riding post stage */
+		ddc_body<NCO, UTAPS, PD2>(DDC_PASS, lds, DDC_ROLE_BOUNDARY);
+		return;
+	}
+	/* ---- the persistent waves: every window lies inside the block (n0 >= 0).  Nothing of the block-boundary
+	 * path, the post stage or the state roll is live in this loop, so the registers are the tap loop's.
+	 *   - A unit ENDS with the next unit's window going to LDS, then its own store, then the load for the
+	 *     unit after the next: at the only point where the wave waits for vector memory, everything
+	 *     outstanding was issued a whole unit (~3 us) ago -- whatever count the compiler waits for, it waits
+	 *     for nothing.
+	 *   - two window loads are in flight, in two register pairs that take turns (the loop is unrolled by
+	 *     two: no copy of a load in flight), both LDS buffers have constant addresses, and the phase of a
+	 *     unit's first frame advances by addition (wpg * d1 frames per unit). ---- */
+	const unsigned int lane = threadIdx.x & 63u;
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned int waves_per_wg = blockDim.x >> 6;
+	const unsigned int wid = blockIdx.x * waves_per_wg + wave;
+	TL(0);
+	wave_prio(3u);                                           /* the prologue's loads go out at once */
+	for (unsigned int e = threadIdx.x; e < WR_SPLIT_N; e += blockDim.x) {
+		const float2 hv = hi_cs[e], lv = lo_cs[e];
+		lds[e] = (v2f){hv.x, hv.y};
+		lds[WR_SPLIT_N + e] = (v2f){lv.x, lv.y};
+	}
+	__syncthreads();
+	const v2f *hi_l = lds, *lo_l = lds + WR_SPLIT_N;
+	const unsigned int nset = (NG == 2u) ? 1u : kmax;
+	v2f *win = lds + 2u * WR_SPLIT_N + wave * (128u * nset);
+	if (whole && blockIdx.x == 0 && wave == 0 && lane < WR_HIST) {
+		const size_t f = nframes + lane;            /* frame index in [hist | cur]: the tuner's next input history */
+		hist_next[lane] = (f < WR_HIST) ? hist[f] : input_frame(cur, cur_u8, f - WR_HIST);
+	}
+	const unsigned int k1u = (unsigned int)k1;
+	const unsigned int nwaves = n_ddc * waves_per_wg;
+	TL(1);
+	const unsigned int gsets = groups / NG;                 /* sets of NG lane groups that share a wave */
+	const unsigned int wpg = nwaves / gsets;                /* >= 1: see the launcher */
+	const unsigned int gs = wid % gsets;
+	unsigned int k = wid / gsets;
+	if (k >= wpg) {
+		k = k1u;                                         /* the few waves left over stay idle */
+	} else {
+		if (DDC_DEAL_WAYS > 1u) {                        /* long and short waves to every workgroup: see ddc_body */
+			const unsigned int r = k % DDC_DEAL_WAYS, q = k / DDC_DEAL_WAYS;
+			const unsigned int fl_ = wpg / DDC_DEAL_WAYS, rem = wpg % DDC_DEAL_WAYS;
+			k = r * fl_ + (r < rem ? r : rem) + q;
+		}
+		k += kslow;                                      /* behind the block-boundary frames */
+		if (k > k1u)
+			k = k1u;
+	}
+	const unsigned int my_units = (k < k1u) ? (k1u - k + wpg - 1u) / wpg : 0u;
+	unsigned int tl_unit = 0;
+	if (k < k1u) {
+		/* per recurrence: one coalesced load each (WrGroupDev::rot, taps1u), all independent of one another */
+		unsigned int Pk[NG], fstep[NG], dP[NG], stv[NG];
+		int fl[NG];
+		v2f rot0[NG], rot1[NG];                          /* the two possible turns per frame */
+		float2 *out[NG];
+		unsigned int g0 = 0, s0 = 0;
+#pragma unroll
+		for (unsigned int c = 0; c < NG; ++c) {
+			const unsigned int gl = gs * NG + c;
+			const unsigned int g = (unsigned int)(((gl < 8u ? gmap0 : gmap1) >> ((gl & 7u) * 8u)) & 255u);
+			const unsigned int s = g * 64u + lane;
+			if (c == 0) {
+				g0 = g;
+				s0 = s;
+			}
+			const unsigned int p0 = phase[s];
+			stv[c] = step[s];
+			fl[c] = flags[s];
+			const float4 r4 = rot[s];
+			rot0[c] = (v2f){r4.x, r4.y};
+			rot1[c] = (v2f){r4.z, r4.w};
+			fstep[c] = stv[c] << 16;
+			Pk[c] = p0 + (unsigned int)((size_t)k * d1 - WR_HIST) * stv[c];   /* phase of the unit's first window frame */
+			dP[c] = wpg * d1 * stv[c];
+			out[c] = chan_iq + s;
+		}
+		const unsigned int mysel = (NG == 2u) ? 0u : (unsigned int)tapsel[s0];   /* which of the group's tap sets this lane's channel uses */
+		float hlane[WR_TAPSETS];                              /* lane j holds the tap of window sample j, per tap set */
+#pragma unroll
+		for (int q = 0; q < WR_TAPSETS; ++q)
+			hlane[q] = ((unsigned int)q < nset) ? taps1u[((size_t)g0 * WR_TAPSETS + q) * 64u + lane] : 0.0f;
+		const lds_v4f *w4[2];
+		v2f *wst[2];
+#pragma unroll
+		for (int b = 0; b < 2; ++b) {
+			w4[b] = (const lds_v4f *)(win + ((unsigned int)b * nset + mysel) * 64u);
+			wst[b] = win + (unsigned int)b * nset * 64u + lane;
+		}
+		const size_t dn = (size_t)wpg * d1;
+		/* window sample `lane` of unit kk is frame kk * d1 - 63 + lane >= 0, inside the block; past the
+		 * wave's last unit the index stays where it is (a load nobody uses, and no branch around it) */
+		const size_t nlast = (size_t)(k + (my_units - 1u) * wpg) * d1 - WR_HIST + lane;
+		size_t nx = (size_t)k * d1 - WR_HIST + lane;
+		/* (a frame travels as loaded -- two floats, or the two bytes of the RTL-SDR format in .x -- and is
+		 * converted where it is used, (u8 - 128) / 128 as io/rtlsdrtuner.cxx:106: nothing waits at the load) */
+		auto fetch = [&]() __attribute__((always_inline)) -> float2 {
+			float2 v;
+			if (cur_u8) {
+				const uchar2 b2 = cur_u8[nx];
+				v = make_float2(__builtin_bit_cast(float, (unsigned int)b2.x | ((unsigned int)b2.y << 8)), 0.0f);
+			} else {
+				v = cur[nx];
+			}
+			nx = (nx + dn <= nlast) ? nx + dn : nlast;
+			return v;
+		};
+		auto to_lds = [&](const float2 raw, const int b) __attribute__((always_inline)) {
+			float2 xf = raw;
+			if (cur_u8) {
+				const unsigned int bits = __builtin_bit_cast(unsigned int, raw.x);
+				xf = make_float2(((float)(bits & 255u) - 128.0f) / 128.0f, ((float)((bits >> 8) & 255u) - 128.0f) / 128.0f);
+			}
+#pragma unroll
+			for (int q = 0; q < WR_TAPSETS; ++q)
+				if ((unsigned int)q < nset)
+					wst[b][q * 64] = (v2f){hlane[q] * xf.x, hlane[q] * xf.y};
+		};
+		float2 xa = fetch();                              /* unit 0 */
+		float2 xb = fetch();                              /* unit 1 */
+		to_lds(xa, 0);
+		xa = fetch();                                     /* unit 2 */
+		TL(2);
+		/* one unit from LDS buffer b; `xo` holds the NEXT unit's window sample (on its way or landed) */
+		auto unit = [&](float2 &xo, const int b) __attribute__((always_inline)) {
+			{
+				const unsigned int q = (4u * tl_unit) / my_units;   /* 0..3: see wave_prio */
+				wave_prio(q >= 3u ? 0u : 2u - q + 0u);
+			}
+			v2f csq[NG][ROT_Q];
+			unsigned int F[NG];
+			v2f acc[NG], A[NG], Aq[NG][ROT_Q];
+#pragma unroll
+			for (unsigned int c = 0; c < NG; ++c) {
+#pragma unroll
+				for (int q = 0; q < ROT_Q; ++q)
+					csq[c][q] = nco<NCO>(Pk[c] + (unsigned int)(q * ROT_SEG + ROT_SEG - 1) * stv[c], table, hi_l, lo_l);
+				F[c] = Pk[c] << 16;                   /* the 16 fraction bits, left-aligned */
+				acc[c] = (v2f){0.0f, 0.0f};
+				A[c] = (v2f){0.0f, 0.0f};
+			}
+			/* the window comes back DDC_RD x 16 bytes (2 taps each) ahead of the arithmetic */
+			constexpr int RD = DDC_RD, NST = WR_FIR_LENGTH / 2 / RD;
+			v4f xr[2][RD];
+#pragma unroll
+			for (int r = 0; r < RD; ++r)
+				xr[0][r] = w4[b][r];
+#pragma unroll
+			for (int t = 0; t < NST; ++t) {
+#ifndef DDC_ABL_NOLDS
+				if (t + 1 < NST) {
+#pragma unroll
+					for (int r = 0; r < RD; ++r)
+						xr[(t + 1) & 1][r] = w4[b][(t + 1) * RD + r];
+				}
+#endif
+#pragma unroll
+				for (int r = 0; r < RD; ++r) {
+#ifdef DDC_ABL_NOLDS                                           /* (timing experiments only: results are wrong) */
+					const v4f x2 = {xo.x, xo.y, xo.y, xo.x};
+#else
+					const v4f x2 = xr[t & 1][r];
+#endif
+#pragma unroll
+					for (int jj = 0; jj < 2; ++jj) {
+						const int j = 2 * (t * RD + r) + jj;
+						const v2f u = jj ? (v2f){x2.z, x2.w} : (v2f){x2.x, x2.y};
+#pragma unroll
+						for (unsigned int c = 0; c < NG; ++c) {
+							if (j % ROT_SEG == 0) {
+								if (j)
+									F[c] += fstep[c];       /* a segment starts afresh: no turn */
+								A[c] = u;
+							} else {
+#ifdef DDC_ABL_NOSEL
+								horner_step(A[c], rot0[c].x, rot0[c].y, u);
+#else
+								unsigned int F2;
+								const bool carry = __builtin_uadd_overflow(F[c], fstep[c], &F2);
+								F[c] = F2;
+								horner_step(A[c], carry ? rot1[c].x : rot0[c].x, carry ? rot1[c].y : rot0[c].y, u);
+#endif
+							}
+							if (j % ROT_SEG == ROT_SEG - 1)
+								Aq[c][j / ROT_SEG] = A[c];
+						}
+					}
+				}
+				/* nothing crosses a stage: left alone, the scheduler hoists all 32 window reads of a unit to
+				 * its top (128 registers of them) and spills them */
+				__builtin_amdgcn_sched_barrier(0);
+			}
+#pragma unroll
+			for (unsigned int c = 0; c < NG; ++c) {
+#pragma unroll
+				for (int q = 0; q < ROT_Q; ++q)
+					horner_close(acc[c], Aq[c][q], csq[c][q]);
+				/* (the result is needed HERE: its only use is the store under `if (active)` below, and the
+				 * optimiser would sink the whole recurrence into that branch, behind the window writes --
+				 * leaving the unit's 32 window reads on their own at its top, 128 registers wide) */
+				asm volatile("" : "+v"(acc[c].x), "+v"(acc[c].y));
+			}
+			/* the next unit's window (requested two units ago), this unit's result, the request after next */
+			to_lds(xo, b ^ 1);
+#pragma unroll
+			for (unsigned int c = 0; c < NG; ++c) {
+				if (fl[c] & PHASE_FLAG_ACTIVE) {
+#ifdef DDC_PLAIN_STORE
+					out[c][(size_t)k * slots] = make_float2(acc[c].x, acc[c].y);
+#else
+					union { v2f f; unsigned long long u; } cv;
+					cv.f = acc[c];
+					__hip_atomic_store((unsigned long long *)&out[c][(size_t)k * slots], cv.u, __ATOMIC_RELAXED,
+					                   __HIP_MEMORY_SCOPE_AGENT);             /* write-through: see ddc_body */
+#endif
+				}
+				Pk[c] += dP[c];
+			}
+			xo = fetch();
+			k += wpg;
+			TL(3u + tl_unit);
+			++tl_unit;
+		};
+		while (k < k1u) {
+			unit(xb, 0);
+			if (k >= k1u)
+				break;
+			unit(xa, 1);
+		}
+	}
+	wave_prio(0u);
+	/* the end-of-block state of every channel: the LAST workgroups of the grid, after their units (they
+	 * are the ones that get a unit fewer when the units do not divide evenly) */
+	const unsigned int roll_wgs = (WR_FIR_LENGTH * slots + blockDim.x - 1u) / blockDim.x;
+	const unsigned int roll_first = n_ddc > roll_wgs ? n_ddc - roll_wgs : 0u;
+	if (whole && blockIdx.x >= roll_first)
+		ddc_body<NCO, UTAPS, PD2>(DDC_PASS, lds, DDC_ROLE_ROLL);
 	TL(11);
 }
 
@@ -1467,12 +1790,21 @@ template <int NCO, bool UTAPS> struct DdcGeom {
 
 /* `gsel`: bit g set = lane group g takes part in this launch (0 = all of them); `whole`: the launch
  * also rolls the per-channel state of every group (exactly one launch per block does) */
-template <int NCO, bool UTAPS, unsigned int PD2>
+template <int NCO, bool UTAPS, unsigned int PD2, unsigned int NG = 1u>
 static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                              const float *table_dev, const float *hi_dev, const float *lo_dev, int num_cus,
                              const WrPostArgs *post, unsigned long long gsel = 0, bool whole = true)
 {
 	constexpr unsigned int W = DdcGeom<NCO, UTAPS>::waves;
+	if constexpr (NG == 1u && DDC_ROLES && DDC_NG2 && NCO == WR_NCO_ROTATE && UTAPS) {
+		/* two lane groups per wave (see k_tuner_ddc: NG) where the launch allows: an even number of lane groups, at
+		 * most 16, all on one and the same channel filter */
+		unsigned int n = 0;
+		for (unsigned int g = 0; g < L.slots_used / 64; ++g)
+			n += (!gsel || ((gsel >> g) & 1ull)) ? 1u : 0u;
+		if (L.one_filter && n >= 2u && n <= 16u && (n & 1u) == 0u)
+			return launch_ddc<NCO, UTAPS, PD2, 2u>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	}
 	const unsigned int allgroups = L.slots_used / 64;        /* <= 64: wr_tuner_create caps max_channels */
 	unsigned long long gmap[2] = {0, 0};
 	unsigned int ngroups = 0;
@@ -1509,7 +1841,8 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	size_t lds = (NCO == WR_NCO_SPLIT) ? DDC_LDS_BYTES
 	             : (W * 2u * 512u * kmax) + (NCO == WR_NCO_ROTATE ? 2u * WR_SPLIT_N * 8u : 0u)
 	               + (NCO == WR_NCO_ROTATE && !UTAPS ? WR_FIR_LENGTH * 64u * 4u : 0u);
-	unsigned int wgs_per_cu = DdcGeom<NCO, UTAPS>::wgs_per_cu;
+	/* NG = 2: 80 registers, 6 waves per SIMD: three 8-wave workgroups per CU */
+	unsigned int wgs_per_cu = (NG == 2u) ? DDC_NG2_WAVES_PER_EU * 4u / W : DdcGeom<NCO, UTAPS>::wgs_per_cu;
 	unsigned int post_wgs = 0;
 	if (PD2 != 0u) {
 		/* the post workgroups' stage + tile set the LDS size of every workgroup of the launch;
@@ -1532,7 +1865,17 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	}
 	/* launched even for a block too short to yield a channel-rate frame: workgroup 0 still
 	 * advances the NCO (downconverter.cxx:103 runs per input frame) and rolls the histories */
-	const size_t units = L.k1 * ngroups;
+	/* (DDC_ROLES) the first ceil(63 / D1) output frames of the block reach into the previous one: they go to
+	 * n_bnd workgroups of their own, one wave per (lane group, frame), and the persistent waves share the rest */
+	constexpr bool ROLES = DDC_ROLES && NCO == WR_NCO_ROTATE && UTAPS;
+	unsigned int kslow = 0, n_bnd = 0;
+	if (ROLES && L.k1) {
+		kslow = (WR_HIST + L.d1 - 1u) / L.d1;
+		if (kslow > L.k1)
+			kslow = (unsigned int)L.k1;
+		n_bnd = (kslow * ngroups + W - 1u) / W;
+	}
+	const size_t units = (L.k1 - kslow) * (ngroups / NG);        /* per wave and pass of its loop: NG lane groups */
 	unsigned int wgs = (unsigned int)((units + W - 1) / W);
 	const unsigned int cap = (unsigned int)num_cus * wgs_per_cu;
 	if (wgs > cap) {
@@ -1556,13 +1899,13 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 			wgs = ngroups;
 	} else {
 		/* every lane group needs at least one wave of its own (the kernel deals waves to groups) */
-		const unsigned int min_wgs = (ngroups + W - 1) / W;
+		const unsigned int min_wgs = (ngroups / NG + W - 1) / W;
 		if (wgs < min_wgs)
 			wgs = min_wgs;
 	}
 	static bool attr_done[WR_MAX_DEVICES];
 	if (lds > 64 * 1024) {
-		hipError_t e = allow_lds((const void *)k_tuner_ddc<NCO, UTAPS, PD2>, lds, attr_done);
+		hipError_t e = allow_lds((const void *)k_tuner_ddc<NCO, UTAPS, PD2, NG>, lds, attr_done);
 		if (e != hipSuccess)
 			return e;
 	}
@@ -1570,7 +1913,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	if (L.ev_start && L.ev_stop) {
 		/* profiling: the launch stamps the two events with the dispatch's own start and end, as
 		 * rocprof sees them -- events recorded around it would add their own barrier packets */
-		hipExtLaunchKernelGGL((k_tuner_ddc<NCO, UTAPS, PD2>), dim3(wgs + post_wgs), dim3(W * 64u), (uint32_t)lds, st,
+		hipExtLaunchKernelGGL((k_tuner_ddc<NCO, UTAPS, PD2, NG>), dim3(wgs + n_bnd + post_wgs), dim3(W * 64u), (uint32_t)lds, st,
 		                      (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
 		                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next,
 		                      L.nframes, L.k1, L.d1, L.slots, ngroups, (const unsigned int *)G.phase[L.sp],
@@ -1578,16 +1921,16 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		                      G.phase[L.sp ^ 1], (float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp],
 		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (const float4 *)G.rot, (const float *)G.taps1u,
 		                      (const int *)G.tapsel, kmax, (float2 *)G.chan_iq[L.cb], table_dev,
-		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
+		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0, kslow, n_bnd);
 		return hipGetLastError();
 	}
-	k_tuner_ddc<NCO, UTAPS, PD2><<<wgs + post_wgs, W * 64u, lds, st>>>(
+	k_tuner_ddc<NCO, UTAPS, PD2, NG><<<wgs + n_bnd + post_wgs, W * 64u, lds, st>>>(
 		(const float2 *)L.cur, (const uchar2 *)L.cur_u8, (const float2 *)L.hist, (float2 *)L.hist_next, L.nframes,
 		L.k1, L.d1,
 		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
 		(const float4 *)G.rot, G.taps1u, G.tapsel, kmax, (float2 *)G.chan_iq[L.cb], table_dev,
-		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0);
+		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0, kslow, n_bnd);
 	return hipGetLastError();
 }
 
