@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define WR_ABI_VERSION   3       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
-                                    blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream)
+                                    blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream), wr_u8_to_f32_from_host
                                     added.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
@@ -160,6 +160,10 @@ int wr_demod(wr_dev *dev, int mode, const float *in_dev, size_t nframes,
 
 /* RTL-SDR byte format to float, (u8 - 128)/128 (io/rtlsdrtuner.cxx:106) */
 int wr_u8_to_f32(wr_dev *dev, const uint8_t *in_dev, float *out_dev, size_t count);
+/* the same straight out of HOST memory page-locked with wr_dev_host_register: the kernel reads the bytes over
+ * PCIe itself -- one launch instead of a copy and a launch, and a quarter of the float block's bytes.  Counts
+ * as an upload in flight: the host buffer must not be rewritten until wr_dev_wait_uploads (or wr_dev_sync). */
+int wr_u8_to_f32_from_host(wr_dev *dev, const uint8_t *in_host_registered, float *out_dev, size_t count);
 
 /* ------------------------------------------------- fused per-tuner path -- */
 /* One wr_tuner = one FrontEnd's tuner (radio.cxx:120-133) with all the Receivers

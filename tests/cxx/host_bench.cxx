@@ -4,7 +4,10 @@
  * webradio process would see: the tuner block lives in HOST memory (PCIe is inside the
  * timing), every Receiver's AudioStreamManager gets its audio.  TEST/MEASUREMENT DRIVER.
  *
- *   host_bench [receivers=256] [blocks=10] [block_frames=4000000]
+ *   host_bench [receivers=256] [blocks=10] [block_frames=4000000] [f32|u8]
+ *
+ * u8: the source holds its block in the RTL-SDR byte format (RawU8Block, like FileTuner: what an RTL-SDR or a
+ * recording delivers, io/rtlsdrtuner.cxx:86-117) -- 8 MB per 4 M-frame block over PCIe instead of 32 MB.
  */
 #include <math.h>
 #include <stdio.h>
@@ -14,6 +17,7 @@
 
 #include <vector>
 
+#include "filetuner.h"
 #include "radio.h"
 
 namespace {
@@ -44,6 +48,30 @@ protected:
 };
 Tuner *make(const string &n) { return new SynthTuner(n); }
 
+std::vector<uint8_t> g_bytes;
+
+/* the same block quantised to the RTL-SDR byte format; like FileTuner it leaves the float vector unfilled when
+ * every consumer reads the block on the device */
+class SynthU8Tuner : public Tuner, public RawU8Block {
+public:
+	SynthU8Tuner(const string &n) : Tuner(n, "SynthU8Tuner") {}
+	const uint8_t *rawU8(size_t *frames) const { if (frames) *frames = g_bytes.size() / 2; return g_bytes.data(); }
+protected:
+	bool init() { return true; }
+	void deinit() {}
+	bool process(const vector<sample_t> &, vector<sample_t> &out) {
+		if (out.size() != g_bytes.size())
+			return false;
+		const bool skip = consumersReadOnDevice();
+		if (!skip)
+			for (size_t n = 0; n < out.size(); n++)
+				out[n] = ((float)g_bytes[n] - 128.0) / 128.0;
+		setHostBlockValid(!skip);
+		return true;
+	}
+};
+Tuner *make_u8(const string &n) { return new SynthU8Tuner(n); }
+
 double now()
 {
 	timespec ts;
@@ -58,6 +86,7 @@ int main(int argc, char **argv)
 	const unsigned int nrx = argc > 1 ? atoi(argv[1]) : 256;
 	const unsigned int blocks = argc > 2 ? atoi(argv[2]) : 10;
 	const unsigned int frames = argc > 3 ? atoi(argv[3]) : 4000000;
+	const bool u8 = argc > 4 && !strcmp(argv[4], "u8");
 	const unsigned int fs = 100000000;
 
 	g_block.resize((size_t)frames * 2);
@@ -77,7 +106,14 @@ int main(int argc, char **argv)
 			break;                                           /* a few carriers are enough */
 	}
 
-	FrontEnd *fe = new FrontEnd(make);
+	if (u8) {
+		g_bytes.resize(g_block.size());
+		for (size_t n = 0; n < g_block.size(); n++) {
+			double q = floor(127.5 + 127.0 * 16.0 * g_block[n] + 0.5);        /* (x16: the synthetic block is quiet) */
+			g_bytes[n] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+		}
+	}
+	FrontEnd *fe = new FrontEnd(u8 ? make_u8 : make);
 	fe->tuner()->setSampleRate(fs);
 	fe->tuner()->setChannels(2);
 	fe->tuner()->setBlockSize(frames * 2);
@@ -90,7 +126,7 @@ int main(int argc, char **argv)
 		r->audioFilter()->setPassband(8000);
 		r->audioFilter()->setOutputSampleRate(50000);
 		r->demodulator()->setMode(Demodulator::FM);
-		r->stream()->setCapacity(4096);
+		r->stream()->setCapacity(256);          /* the sink stands for the MP3 encoder: keep a tail for the checksum */
 		r->setFrontEnd(fe);
 		rx.push_back(r);
 	}
@@ -112,9 +148,11 @@ int main(int argc, char **argv)
 		for (size_t i = 0; i < a.size(); i++)
 			sum += fabs(a[i]);
 	}
-	printf("{\"audio\": \"%s\", \"receivers\": %u, \"blocks\": %u, \"block_frames\": %u, \"ms_per_block\": %.3f, "
+	printf("{\"source\": \"%s\", \"audio\": \"%s\", \"receivers\": %u, \"blocks\": %u, \"block_frames\": %u, \"ms_per_block\": %.3f, "
 	       "\"msps_tuner_input\": %.1f, \"audio_samples_per_receiver\": %lu, \"audio_abs_sum\": %.3f}\n",
-	       (getenv("WEBRADIO_AUDIO_LATE") && atoi(getenv("WEBRADIO_AUDIO_LATE"))) ? "one block late (WEBRADIO_AUDIO_LATE=1)" : "on time",
+	       u8 ? "u8 (RTL-SDR byte format, 2 B per frame over PCIe)" : "f32 (8 B per frame over PCIe)",
+	       (getenv("WEBRADIO_AUDIO_LATE") && atoi(getenv("WEBRADIO_AUDIO_LATE")) >= 2) ? "two blocks late (WEBRADIO_AUDIO_LATE=2: one launch per block)"
+	       : (getenv("WEBRADIO_AUDIO_LATE") && atoi(getenv("WEBRADIO_AUDIO_LATE"))) ? "one block late (WEBRADIO_AUDIO_LATE=1)" : "on time",
 	       nrx, blocks, frames, dt / blocks * 1e3, (double)frames * blocks / dt / 1e6,
 	       total / (unsigned long)rx.size(), sum);
 	if (getenv("WR_HOST_BENCH_PROFILE")) {

@@ -82,23 +82,27 @@ def test_fir_length_inside_the_fused_path(dev, oracle, nco, lengths):
     t.destroy()
 
 
+@pytest.mark.parametrize("fs,d1,pb1,sizes", [(5_000_000, 20, 160_000, ((200_000, 2), (1_000, 8), (5_000, 4))),
+                                             (100_000_000, 400, 6_400_000, ((400_000, 2), (20_000, 5)))])
 @pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
-def test_two_stage_channel_filter_through_the_tuner(dev, oracle, nco):
-    """a 12.5 kHz channel off a 5 Msps stream.  One 64-tap LowPass cannot do it
-    (64 * 12 500 / 5 M / 2 = bin 0, lowpass.cxx:167: all taps zero); the reference's own means is a
-    second LowPass in a row.  Here: DDC + first stage 5 M -> 250 k (D1 = 20), second channel stage
-    250 k -> 25 k (D = 10, passband 12.5 kHz -> bin 1), AM, audio filter 25 k -> 5 k -- all through
+def test_two_stage_channel_filter_through_the_tuner(dev, oracle, nco, fs, d1, pb1, sizes):
+    """a 12.5 kHz NFM-width channel off a fast stream.  One 64-tap LowPass cannot do it
+    (64 * 12 500 / fs / 2 = bin 0 for 5 Msps and for 100 Msps, lowpass.cxx:167: all taps zero); the
+    reference's own means is a second LowPass in a row.  Here: DDC + first stage fs -> 250 k (off 5 Msps:
+    D1 = 20; off 100 Msps, as H4 words it: D1 = 400, passband 6.4 MHz as in BASELINE config 2), second channel
+    stage 250 k -> 25 k (D = 10, passband 12.5 kHz -> bin 1), AM, audio filter 25 k -> 5 k -- all through
     wr_tuner_submit, 66 receivers, against the oracle's cascade."""
-    fs = 5_000_000
     assert oracle.lowpass_maxbin(12_500, fs) == 0 and oracle.lowpass_maxbin(12_500, 250_000) == 1
-    ifs = [(-33 + c) * 30_000 + 4321 for c in range(66)]
+    assert fs // d1 == 250_000 and oracle.lowpass_maxbin(pb1, fs) >= 1
+    step = 30_000 if fs == 5_000_000 else 700_000
+    ifs = [(-33 + c) * step + 4321 for c in range(66)]
     probe = [0, 31, 63, 64, 65]
     live = 0.0
-    # one block size per stream (Q7, see above).  1 000 frames: 50 first-stage, 5 second-stage, 1 audio frame
-    for n, blocks in ((200_000, 2), (1_000, 8), (5_000, 4)):
+    # one block size per stream (Q7, see above).  Off 5 Msps 1 000 frames: 50 first-stage, 5 second-stage, 1 audio frame
+    for n, blocks in sizes:
         t = Tuner(dev, fs, 66, n, nco)
-        chans = [t.add_receiver(f, 160_000, 250_000, capi.WR_AM, 4_000, 5_000, stage2=(64, 12_500, 25_000)) for f in ifs]
-        rxs = {c: OracleChain(oracle, fs, ifs[c], 64, 160_000, 20, oracle.AM, 64, 4_000, 5, stage2=(64, 12_500, 10))
+        chans = [t.add_receiver(f, pb1, 250_000, capi.WR_AM, 4_000, 5_000, stage2=(64, 12_500, 25_000)) for f in ifs]
+        rxs = {c: OracleChain(oracle, fs, ifs[c], 64, pb1, d1, oracle.AM, 64, 4_000, 5, stage2=(64, 12_500, 10))
                for c in probe}
         pos = 0
         for _ in range(blocks):
@@ -224,3 +228,52 @@ def test_random_f4_configurations(dev, oracle, seed):
                 else:
                     assert differ.sum() <= 2, (seed, b, c)
     t.destroy()
+
+
+@pytest.mark.parametrize("d2", [8, 10])
+def test_fused_post_stage_for_audio_decimations_8_and_10(dev, oracle, d2):
+    """r03: the fused demodulator + audio filter (k_tuner_post / the post role riding in the next block's DDC
+    launch) also for D2 = 8 and 10 -- 256 k -> 32 k is BASELINE config 1, 240 k -> 24 k and 480 k -> 48 k the
+    reference's own defaults (radio.cxx:79-81).  70 receivers (two lane groups, all four detectors) off 2 Msps,
+    D1 = 20, four blocks through the audio ring in the host runtime's mode (ROTATE):
+      - the post stage riding in the next launch = the post stage launched on its own (WR_DEFER_POST=0), bit for bit;
+      - against the oracle: AM/USB/LSB within the ROTATE tolerance through the audio filter, FM on carriers."""
+    import os
+    fs, d1, nch = 2_000_000, 20, 70
+    chan_rate, audio_rate = fs // d1, fs // d1 // d2
+    ifs = [(-nch // 2 + c) * 9_000 + 311 for c in range(nch)]
+    modes_c = [capi.WR_FM, capi.WR_AM, capi.WR_USB, capi.WR_LSB]
+    modes_o = [oracle.FM, oracle.AM, oracle.USB, oracle.LSB]
+    n = d1 * d2 * 16 * 5 + d1 * d2 * 3                        # five tiles of 16 audio frames and a ragged one
+    blocks = [synth.fm_stream(n, fs, ifs[::4], start_frame=b * n, seed=5, amp=0.2, fm_base=200.0, beta=2.0) for b in range(4)]
+    rxs = [oracle.Receiver(fs, f, 250_000, chan_rate, modes_o[c % 4], audio_rate // 2, audio_rate) for c, f in enumerate(ifs)]
+    want = [np.stack([rx.run(iq)[0] for rx in rxs]) for iq in blocks]
+    outs = []
+    for env in ("1", "0"):
+        os.environ["WR_DEFER_POST"] = env
+        try:
+            t = Tuner(dev, fs, nch, n, capi.WR_NCO_ROTATE)
+        finally:
+            del os.environ["WR_DEFER_POST"]
+        chans = [t.add_receiver(f, 250_000, chan_rate, modes_c[c % 4], audio_rate // 2, audio_rate) for c, f in enumerate(ifs)]
+        t.audio_ring(len(blocks))
+        for iq in blocks:
+            t.submit_host(iq)
+        t.flush()
+        got = []
+        for b in range(len(blocks)):
+            a, seq = t.ring_acquire()
+            assert seq == b and a.shape[1] == n // d1 // d2
+            got.append(np.stack([a[t.slot(ch)] for ch in chans]))
+            t.ring_release()
+        outs.append(got)
+        t.destroy()
+    taps2 = oracle.lowpass_design(audio_rate // 2, chan_rate)
+    tol = 2e-6 * max(1.0, float(np.abs(taps2).sum()))
+    for b in range(len(blocks)):
+        assert np.array_equal(outs[0][b].view(np.uint32), outs[1][b].view(np.uint32)), b
+        for c in range(nch):
+            if c % 4 == 0:                                     # the FM receivers: they sit on the carriers (ifs[::4])
+                assert np.abs(outs[0][b][c] - want[b][c]).max() <= 1e-5, (b, c)
+            else:
+                assert np.abs(outs[0][b][c] - want[b][c]).max() <= tol, (b, c)

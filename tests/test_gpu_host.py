@@ -288,7 +288,7 @@ def test_late_audio_keeps_both_front_ends_in_flight(tmp_path, oracle):
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([rate, block, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], mode, nblk, cap], np.int64))
     res = {}
-    for late in ("0", "1"):
+    for late in ("0", "1", "2"):
         subprocess.check_call([sys.executable, "-c", TRACED_RUNNER, lib, inp, out],
                               env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1",
                                        WEBRADIO_AUDIO_LATE=late))
@@ -309,6 +309,14 @@ def test_late_audio_keeps_both_front_ends_in_flight(tmp_path, oracle):
     assert runs[0] == "S0S1"                                     # nothing to hand out yet
     assert all(r == "S0A0S1A1" for r in runs[1:]), runs           # enqueue, take what is there; never wait
     assert all(r.startswith("S0") and "S1" in r for r in res["0"][1].strip("|").split("|"))
+    # WEBRADIO_AUDIO_LATE=2: no flush after the submit -- the demodulator + audio filter of a block ride in the
+    # NEXT block's launch (one launch per block, as bench.py) -- and the sinks get the block before the previous
+    # one: two blocks of silence, then the same bits, and still never a wait
+    late2 = res["2"][0]
+    assert late2.shape == on_time.shape and not late2[:, :2 * k2].any()
+    assert np.array_equal(late2[:, 2 * k2:].view(np.uint32), on_time[:, :-2 * k2].view(np.uint32))
+    runs2 = res["2"][1].strip("|").split("|")
+    assert runs2[0] == runs2[1] == "S0S1" and all(r == "S0A0S1A1" for r in runs2[2:]), runs2
 
 
 FILE_RUNNER = r'''
@@ -330,8 +338,8 @@ np.savez(out, rc=rc, audio=audio[:n.value], left=L.wr_host_registry_sizes())
 def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
     """BASELINE config 1 end to end: FileTuner replays an RTL-SDR format recording (the capture and
     the ORACLE's outputs for it, oracle_selfcheck_c1.npz -- a self-check, not a reference pin), one
-    DownConverter + FM Receiver.  With a FrontEnd the float block is staged
-    once for SpectrumSink and receiver; without it the raw bytes go to the GPU (u8 ingest)."""
+    DownConverter + FM Receiver.  The recording's bytes are staged on the device once per block (2 bytes per
+    frame over PCIe) and converted there for SpectrumSink and receiver alike."""
     lib = os.path.join(CXXT, "libwr_host_pipeline.so")
     g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_selfcheck_c1.npz"))
     c1 = synth.C1
@@ -341,7 +349,10 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
     out = str(tmp_path / "out.npz")
     args = [c1["input_rate"], n, 4, c1["if_hz"], 1, c1["chan_passband"], c1["chan_rate"], c1["audio_passband"],
             c1["audio_rate"], with_frontend]
-    for env, tol in (({"WEBRADIO_NCO_EXACT": "1"}, 4.8e-7), ({}, 1e-5)):
+    # (default: the recording's BYTES are staged and converted on the device, the float vector stays unfilled;
+    #  WEBRADIO_NO_U8_STAGING=1: FileTuner converts on the host and the float block is staged, as r02 did)
+    for env, tol in (({"WEBRADIO_NCO_EXACT": "1"}, 4.8e-7), ({}, 1e-5),
+                     ({"WEBRADIO_NCO_EXACT": "1", "WEBRADIO_NO_U8_STAGING": "1"}, 4.8e-7)):
         subprocess.check_call([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
                               env=dict(os.environ, WEBRADIO_QUIET="1", **env))
         r = np.load(out)

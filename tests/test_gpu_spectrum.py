@@ -68,6 +68,33 @@ def test_streaming_partial_frames(dev, oracle):
     s.destroy()
 
 
+@pytest.mark.parametrize("n,hop", [(1024, 0), (4096, 2048), (512, 0)])
+def test_device_pushes_in_place(dev, oracle, n, hop):
+    """Blocks that already lie in device memory (the staged tuner block): with nothing carried over the most
+    recent frame is transformed where it lies and only the tail is kept (r03); blocks that are not a
+    multiple of the hop leave a tail, the next push takes the staged path and carries it on.  Against the
+    oracle fed the same stream (spectrumsink.cxx:101-121), push after push."""
+    h = hop or n
+    sizes = [4 * n, 3 * n + 77, 5 * h - 77, 2 * n, n + 1, 6 * n]          # exact, ragged, back to exact, ...
+    iq = synth.fm_stream(sum(sizes), 2_400_000, [250_000, -400_000], amp=0.3)
+    s = Spectrum(dev, n, hop)
+    pos, done = 0, 0
+    for sz in sizes:
+        part = np.ascontiguousarray(iq[2 * pos: 2 * (pos + sz)])
+        p = dev.upload(part)
+        s.push_device(p, sz)
+        dev.sync()
+        dev.free(p)
+        pos += sz
+        nfr = (pos - n) // h + 1 if pos >= n else 0                            # frames complete so far
+        assert s.frames_done() == nfr
+        if nfr:
+            o = oracle.Spectrum(n)
+            o.process(iq[2 * (nfr - 1) * h: 2 * ((nfr - 1) * h + n)])          # the most recent frame's samples
+            _check(s.get_db(), s.get_bins(), o.get(), o.bins())
+    s.destroy()
+
+
 def test_overlap_hop(dev, oracle):
     """50 % overlap (BASELINE config 3): each frame is an ordinary reference frame fed the
     overlapped samples explicitly."""

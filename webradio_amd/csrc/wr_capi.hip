@@ -217,6 +217,9 @@ static int dev_alloc_zero(T **p, size_t count)
 {
 	HIP_TRY(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
 	HIP_TRY(hipMemset(*p, 0, (count ? count : 1) * sizeof(T)));
+	/* (the fill is ordered on the null stream; a context on a non-blocking stream of its own -- WR_STREAM_PRIVATE --
+	 * is not ordered behind it: wait here, this is set-up code) */
+	HIP_TRY(hipStreamSynchronize(nullptr));
 	return WR_OK;
 }
 
@@ -324,6 +327,7 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	 * torch.cuda.current_stream().cuda_stream is unless the caller switched streams */
 	d->stream = (hipStream_t)hip_stream;
 	d->own_stream = false;
+
 
 	std::vector<float> table(WR_TABLE_SIZE), turn(WR_TABLE_SIZE), hi(2 * WR_SPLIT_N), lo(2 * WR_SPLIT_N);
 	wrd_sin_table(table.data());
@@ -588,6 +592,27 @@ extern "C" int wr_u8_to_f32(wr_dev *d, const uint8_t *in_dev, float *out_dev, si
 	if (!d || (count && (!in_dev || !out_dev)))
 		return fail(WR_ERR_ARG, "wr_u8_to_f32: bad argument");
 	HIP_TRY(wrk_u8_to_f32(d->stream, in_dev, out_dev, count));
+	return WR_OK;
+}
+
+extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *out_dev, size_t count)
+{
+	if (!d || (count && (!in_host || !out_dev)))
+		return fail(WR_ERR_ARG, "wr_u8_to_f32_from_host: bad argument");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	void *mapped = nullptr;
+	hipError_t e = hipHostGetDevicePointer(&mapped, const_cast<uint8_t *>(in_host), 0);
+	if (e != hipSuccess || !mapped) {
+		(void)hipGetLastError();
+		return fail(WR_ERR_ARG, "wr_u8_to_f32_from_host: the buffer is not page-locked (wr_dev_host_register): %s",
+		            hipGetErrorString(e));
+	}
+	if (!d->upload_done)
+		HIP_TRY(hipEventCreateWithFlags(&d->upload_done, hipEventDisableTiming));
+	HIP_TRY(wrk_u8_to_f32(d->stream, (const uint8_t *)mapped, out_dev, count));
+	HIP_TRY(hipEventRecord(d->upload_done, d->stream));
+	d->upload_pending = true;
 	return WR_OK;
 }
 
@@ -2147,6 +2172,31 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 	if (dev_bind(d))
 		return WR_ERR_HIP;
 	hipStream_t st = d->stream;
+	if (where == WR_DEVICE && s->pending == 0 && nframes >= s->n) {
+		/* A block that already lies in device memory and nothing carried over (the tuner block of a source
+		 * whose size is a multiple of the hop, block after block): the most recent frame is transformed where
+		 * it lies and only the tail that belongs to the NEXT frame is kept -- not the whole block copied into
+		 * the stage first (32 MB device to device per 4 M-frame block, and three more enqueues on the host). */
+		const size_t nfft = (nframes - s->n) / s->hop + 1;
+		HIP_TRY(wrk_fft_frames(st, s->plan, iq + 2 * (nfft - 1) * s->hop, s->hop, 1, s->bins, nullptr));
+		s->frames_done += nfft;
+		const size_t rest = nframes - nfft * s->hop;
+		if (rest) {
+			if (rest > s->stage_cap) {
+				float *nb = nullptr;
+				const size_t cap = rest + s->n;
+				HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
+				HIP_TRY(hipStreamSynchronize(st));
+				if (s->stage)
+					HIP_TRY(hipFree(s->stage));
+				s->stage = nb;
+				s->stage_cap = cap;
+			}
+			HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * nfft * s->hop, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+		}
+		s->pending = rest;
+		return WR_OK;
+	}
 	const size_t have = s->pending + nframes;
 	if (have > s->stage_cap) {
 		float *nb = nullptr;

@@ -214,6 +214,17 @@ __device__ __forceinline__ float2 w256(const float2 *__restrict__ tw, unsigned i
 	return (m & 128u) ? make_float2(-w.x, -w.y) : w;
 }
 
+typedef float nt_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 nt_load2(const float2 *p)
+{
+	const nt_v2f v = __builtin_nontemporal_load((const nt_v2f *)p);
+	return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_store2(float2 *p, float2 v)
+{
+	__builtin_nontemporal_store((nt_v2f){v.x, v.y}, (nt_v2f *)p);
+}
+
 #define F256_S 272        /* LDS row stride (float2): 16 x 16 plus 16 -> conflict-free exchanges */
 
 /* pass 1: 16 adjacent columns n2 of one frame; thread (t = tid >> 4, c = tid & 15).
@@ -237,7 +248,11 @@ k_fft64k_pass1(const float2 *__restrict__ iq, size_t hop, const float *__restric
 #pragma unroll
 	for (int a = 0; a < 16; ++a) {
 		const unsigned int idx = (a * 16u + t) * 256u + col;
+#ifdef FFT_P1_NT_LOAD
+		const float2 s = nt_load2(&x[idx]);
+#else
 		const float2 s = x[idx];
+#endif
 		const float w = window[idx];
 		v[a] = make_float2(s.x * w, s.y * w);          /* spectrumsink.cxx:109-112 */
 	}
@@ -261,7 +276,11 @@ k_fft64k_pass1(const float2 *__restrict__ iq, size_t hop, const float *__restric
 		const float2 w = cmul(thi[m >> 8], tlo[m & 255u]);
 		/* intermediate laid out [column tile][k1][16]: this workgroup's 32 KiB are one contiguous run,
 		 * and a pass-2 workgroup (16 rows k1) reads 2 KiB runs from each of the 16 tiles */
+#ifdef FFT_P1_NT_STORE
+		nt_store2(&wout[(blockIdx.x * 256u + k1) * 16u + c], cmul(v[kh], w));
+#else
 		wout[(blockIdx.x * 256u + k1) * 16u + c] = cmul(v[kh], w);
+#endif
 	}
 }
 
@@ -282,7 +301,11 @@ k_fft64k_pass2(const float2 *__restrict__ work, const float2 *__restrict__ tw256
 		const unsigned int t = threadIdx.x & 15u, r = threadIdx.x >> 4;
 #pragma unroll
 		for (int a = 0; a < 16; ++a)
+#ifdef FFT_P2_NT
+			v[a] = nt_load2(&win[(a * 256u + row0 + r) * 16u + t]);
+#else
 			v[a] = win[(a * 256u + row0 + r) * 16u + t];   /* column a*16 + t of row row0 + r (tiled, see pass 1) */
+#endif
 		fft16(v);
 		__syncthreads();                               /* the table */
 #pragma unroll
@@ -304,8 +327,13 @@ k_fft64k_pass2(const float2 *__restrict__ work, const float2 *__restrict__ tw256
 			const unsigned int k = row0 + r + 256u * (t + 16u * kh);
 			if (bins)
 				bins[fbase + k] = v[kh];
-			if (db)
+			if (db) {
+#ifdef FFT_P2_NT
+				__builtin_nontemporal_store(to_db(v[kh], scaledb), &db[fbase + ((k + 32768u) & 65535u)]);
+#else
 				db[fbase + ((k + 32768u) & 65535u)] = to_db(v[kh], scaledb);
+#endif
+			}
 		}
 	}
 }

@@ -1934,6 +1934,27 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 	return hipGetLastError();
 }
 
+/* the launch with the previous block's post stage riding: the audio decimation is a template parameter of the
+ * post role (which tap meets which staged row is resolved at compile time) */
+template <int NCO, bool UTAPS>
+static hipError_t launch_ddc_riding(unsigned int d2, hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
+                                    const float *table_dev, const float *hi_dev, const float *lo_dev, int num_cus,
+                                    const WrPostArgs *post, unsigned long long gsel, bool whole)
+{
+	constexpr bool R = NCO == WR_NCO_ROTATE;
+	switch (d2) {
+	case 1: return launch_ddc<NCO, UTAPS, (R ? 1u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 2: return launch_ddc<NCO, UTAPS, (R ? 2u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 3: return launch_ddc<NCO, UTAPS, (R ? 3u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 4: return launch_ddc<NCO, UTAPS, (R ? 4u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 5: return launch_ddc<NCO, UTAPS, (R ? 5u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 6: return launch_ddc<NCO, UTAPS, (R ? 6u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 8: return launch_ddc<NCO, UTAPS, (R ? 8u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	case 10: return launch_ddc<NCO, UTAPS, (R ? 10u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
+	default: return hipErrorInvalidValue;      /* (wrk_tuner_post_supported keeps other decimations away) */
+	}
+}
+
 template <int NCO>
 static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, const float *table_dev,
                                   const float *hi_dev, const float *lo_dev, int num_cus, const WrPostArgs *post,
@@ -1954,14 +1975,7 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 		if (NCO == WR_NCO_ROTATE && post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
 			if (post_taken)
 				*post_taken = true;
-			switch (post->d2) {
-			case 1: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 1u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
-			case 2: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 2u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
-			case 3: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 3u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
-			case 4: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 4u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
-			case 5: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 5u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
-			default: e = launch_ddc<NCO, true, (NCO == WR_NCO_ROTATE ? 6u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true); break;
-			}
+			e = launch_ddc_riding<NCO, true>(post->d2, st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true);
 		} else {
 			e = launch_ddc<NCO, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, sel, true);
 		}
@@ -1979,14 +1993,7 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 			 * are as large as the per-lane-taps ones, 16 waves, of which the post stage uses eight) */
 			if (post_taken)
 				*post_taken = true;
-			switch (post->d2) {
-			case 1: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 1u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
-			case 2: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 2u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
-			case 3: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 3u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
-			case 4: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 4u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
-			case 5: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 5u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
-			default: return launch_ddc<NCO, false, (NCO == WR_NCO_ROTATE ? 6u : 0u)>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
-			}
+			return launch_ddc_riding<NCO, false>(post->d2, st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, whole);
 		}
 		return launch_ddc<NCO, false, 0>(st, uni ? L2 : L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, sel, whole);
 	}
@@ -2067,10 +2074,11 @@ static hipError_t launch_post(hipStream_t st, const WrPostArgs &A)
 	return hipGetLastError();
 }
 
-/* audio decimations k_tuner_post is instantiated for (anything else takes the two-kernel path) */
+/* audio decimations k_tuner_post is instantiated for (anything else takes the two-kernel path): 1..6, and 8 and 10
+ * -- 256 k -> 32 k (BASELINE config 1), 240 k -> 24 k, 480 k -> 48 k */
 bool wrk_tuner_post_supported(unsigned int d2)
 {
-	return d2 >= 1 && d2 <= 6;
+	return (d2 >= 1 && d2 <= 6) || d2 == 8 || d2 == 10;
 }
 
 hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A0)
@@ -2090,6 +2098,8 @@ hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A0)
 	case 4: return launch_post<4>(st, A);
 	case 5: return launch_post<5>(st, A);
 	case 6: return launch_post<6>(st, A);
+	case 8: return launch_post<8>(st, A);
+	case 10: return launch_post<10>(st, A);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -37,6 +37,10 @@ protected:
 	void deinit() {}
 	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer) {
 		_total += inBuffer.size();
+		if (inBuffer.size() >= _keep) {                 /* a block longer than what is kept: its tail is all there is to keep */
+			_samples.assign(inBuffer.end() - _keep, inBuffer.end());
+			return true;
+		}
 		_samples.insert(_samples.end(), inBuffer.begin(), inBuffer.end());
 		/* trim in large steps: dropping the front of a vector moves everything behind it, and
 		 * doing that for every block of a long stream would cost more than the DSP */

@@ -88,6 +88,10 @@ bool DownConverter::process(const vector<sample_t> &inBuffer, vector<sample_t> &
 			din = NULL;
 	}
 	if (!din) {
+		if (!wrhost::hostBlockValid(this)) {
+			LOG_ERROR("DownConverter: the source left its block on the device and the device copy is not there\n");
+			return false;
+		}
 		if (!_in->reserve(dev, bytes) || wr_dev_upload(dev, _in->ptr, inBuffer.data(), bytes) != WR_OK) {
 			LOG_ERROR("DownConverter: %s\n", wr_last_error());
 			return false;

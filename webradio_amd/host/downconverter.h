@@ -37,7 +37,8 @@ private:
 	bool init();
 	void deinit();
 	bool process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer);
-	bool acceptsDeviceInput() const { return _channel == NULL; }   /* stand-alone: reads the producer's device output */
+	bool acceptsDeviceInput() const { return _channel == NULL; }
+	bool readsSourceOnDevice() const { return true; }            /* fused: the tuner batch; stand-alone: stagedBlock */   /* stand-alone: reads the producer's device output */
 	wrhost::Channel *gpuChannel() const { return _channel; }
 
 	LowPass*		_unusedFilter;

@@ -204,6 +204,17 @@ bool DspBlock::runFrames(const vector<sample_t> &inBuffer, unsigned int inframes
 	return true;
 }
 
+/* do all consumers of this (source) block take its output from the staged device copy? */
+bool DspBlock::consumersReadOnDevice() const
+{
+	if (_consumers.empty())
+		return false;
+	for (size_t n = 0; n < _consumers.size(); n++)
+		if (!_consumers[n]->readsSourceOnDevice())
+			return false;
+	return true;
+}
+
 /* does anybody read this block's output on the host? */
 bool DspBlock::hostOutputNeeded() const
 {
@@ -230,7 +241,7 @@ void DspBlock::setChannels(unsigned int channels)
 }
 
 DspSource::DspSource(const string &name, const string &type)
-	: DspBlock(name, type), _blockSize(DEFAULT_BLOCK_SIZE), _epoch(0), _batch(NULL), _gpuStage(NULL),
+	: DspBlock(name, type), _blockSize(DEFAULT_BLOCK_SIZE), _hostBlockValid(true), _epoch(0), _batch(NULL), _gpuStage(NULL),
 	  _gpuIndex(-1), _gpuCleanup(NULL), _gpuBeforeRun(NULL), _gpuBeforeStop(NULL)
 {
 }

@@ -88,6 +88,11 @@ protected:
 	 * output in device memory publishes the pointer, a consumer that can read device memory
 	 * says so, and when every consumer can, the host copy of that output is never made. */
 	virtual bool acceptsDeviceInput() const { return false; }
+	/* a consumer of a DspSource that takes the source's block from the device copy the GPU glue stages once per
+	 * block (wrhost::stagedBlock) and never looks at the host vector: when all of a source's consumers do, a
+	 * source that holds the block in another form (FileTuner: the RTL-SDR bytes) need not fill the vector */
+	virtual bool readsSourceOnDevice() const { return false; }
+	bool consumersReadOnDevice() const;
 	/* the tuner-batch channel this block is part of while its Receiver chain is fused (gpubatch.h) */
 	virtual wrhost::Channel *gpuChannel() const { return NULL; }
 	static void (*gpuUnfuse)(DspBlock *block);       /* takes the chain `block` is part of out of its tuner batch */
@@ -162,9 +167,15 @@ public:
 	void setGpuBeforeStop(void (*fn)(DspSource*)) { _gpuBeforeStop = fn; }
 	/* the vector the source's process() filled for the current block */
 	const vector<sample_t>& currentBlock() const { return _out; }
+	/* false while the source left the vector unfilled for this block because every consumer reads the block on
+	 * the device (consumersReadOnDevice): a consumer whose device path fails must then fail, not read it */
+	bool hostBlockValid() const { return _hostBlockValid; }
+protected:
+	void setHostBlockValid(bool v) { _hostBlockValid = v; }
 
 private:
 	unsigned int		_blockSize;
+	bool				_hostBlockValid;
 	unsigned long		_epoch;
 	vector<sample_t>	_pump;		/* the (zeroed) input vector handed to the source's own process() */
 	wrhost::TunerBatch*	_batch;

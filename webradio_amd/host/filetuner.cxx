@@ -4,6 +4,8 @@
  */
 #include "filetuner.h"
 
+#include <stdlib.h>
+
 #include "debug.h"
 
 FileTuner::FileTuner(const string &name)
@@ -66,8 +68,15 @@ bool FileTuner::process(const vector<sample_t> &inBuffer, vector<sample_t> &outB
 		}
 		rewind(_file);
 	}
-	for (size_t n = 0; n < want; n++)
-		outBuffer[n] = ((float)_raw[n] - 128.0) / 128.0;   /* rtlsdrtuner.cxx:106 */
+	/* Every consumer takes the block from the device copy (staged from the BYTES and converted there with the
+	 * same rule): nobody reads the float vector, and at 100 Msps filling it costs more host time than the whole
+	 * GPU path.  WEBRADIO_NO_U8_STAGING=1 (the float block is what gets staged then) keeps it filled. */
+	const char *nostage = getenv("WEBRADIO_NO_U8_STAGING");
+	const bool skip = consumersReadOnDevice() && !(nostage && atoi(nostage));
+	if (!skip)
+		for (size_t n = 0; n < want; n++)
+			outBuffer[n] = ((float)_raw[n] - 128.0) / 128.0;   /* rtlsdrtuner.cxx:106 */
+	setHostBlockValid(!skip);
 	_rawFrames = want / 2;
 	_played += _rawFrames;
 	return true;

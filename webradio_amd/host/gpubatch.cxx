@@ -85,6 +85,7 @@ wr_dev *device(int index)
  * rtlsdrtuner.cxx:280), so they are page-locked once and the copy is a DMA nobody waits for */
 struct SourceStage {
 	DevBuf buf;
+	DevBuf raw;                 /* the block as the source holds it in the RTL-SDR byte format (RawU8Block), on the device */
 	unsigned long epoch;
 	const void *host;
 	size_t floats;
@@ -199,10 +200,38 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 		if (only_if_present)
 			return NULL;
 		const size_t bytes = host.size() * sizeof(float);
+		st->dev = dev;
+		/* A source that still holds the block in the RTL-SDR byte format (FileTuner; what RtlSdrTuner::dataReady
+		 * receives, rtlsdrtuner.cxx:86-117): ship the BYTES -- a quarter of the float block over PCIe -- and
+		 * convert on the device with the reference's rule (u8 - 128) / 128 (rtlsdrtuner.cxx:106: exact in
+		 * float, so the staged block is the float block bit for bit).  Such a source need not even fill its
+		 * float vector when every consumer reads the block on the device (DspBlock::readsSourceOnDevice). */
+		const RawU8Block *rawsrc = dynamic_cast<const RawU8Block *>(src);
+		size_t rawFrames = 0;
+		const uint8_t *rawBytes = rawsrc ? rawsrc->rawU8(&rawFrames) : NULL;
+		if (rawBytes && rawFrames * 2 == host.size() && !envUnsigned("WEBRADIO_NO_U8_STAGING", 0)) {
+			const bool pinned = st->pin(dev, rawBytes, host.size());
+			/* page-locked: the conversion kernel reads the bytes over PCIe itself (one launch, nothing the host
+			 * waits for); else a staged copy and the kernel on the device copy */
+			if (!st->buf.reserve(dev, bytes) ||
+			    (pinned ? wr_u8_to_f32_from_host(dev, rawBytes, (float *)st->buf.ptr, host.size())
+			            : (!st->raw.reserve(dev, host.size()) ||
+			               wr_dev_upload(dev, st->raw.ptr, rawBytes, host.size()) != WR_OK)
+			                  ? WR_ERR_HIP
+			                  : wr_u8_to_f32(dev, (const uint8_t *)st->raw.ptr, (float *)st->buf.ptr, host.size())) != WR_OK) {
+				LOG_ERROR("staging the source block (byte format) failed: %s\n", wr_last_error());
+				return NULL;
+			}
+			st->epoch = src->epoch();
+			st->host = host.data();
+			st->floats = host.size();
+			if (dev_out)
+				*dev_out = dev;
+			return (const float *)st->buf.ptr;
+		}
 		/* out of page-locked memory the copy is enqueued and the graph walk goes on beside it; the
 		 * source's next run() waits for it before it touches the vector again (beforeSourceRun) */
 		const bool pinned = st->pin(dev, host.data(), bytes);
-		st->dev = dev;
 		if (!st->buf.reserve(dev, bytes) ||
 		    (pinned ? wr_dev_upload_async(dev, st->buf.ptr, host.data(), bytes)
 		            : wr_dev_upload(dev, st->buf.ptr, host.data(), bytes)) != WR_OK) {
@@ -216,6 +245,12 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 	if (dev_out)
 		*dev_out = dev;
 	return (const float *)st->buf.ptr;
+}
+
+bool hostBlockValid(const DspBlock *block)
+{
+	DspSource *src = TunerBatch::rootSource(block);
+	return !src || src->hostBlockValid();
 }
 
 bool DevBuf::reserve(wr_dev *d, size_t nbytes)
@@ -246,7 +281,8 @@ void DevBuf::release()
 TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
-	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateQueued(false), _silence(false), _lateSeq(0)
+	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateDepth(envUnsigned("WEBRADIO_AUDIO_LATE", 0) >= 2 ? 2u : 1u),
+	  _lateQueued(false), _silence(false), _lateSeq(0)
 {
 }
 
@@ -361,8 +397,9 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 			batch->_tuner = NULL;
 			return NULL;
 		}
-		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 3 : 2);
+		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 2 + batch->_lateDepth : 2);
 		batch->_lateQueued = false;
+		batch->_lateSeq = 0;
 	}
 	int id = -1;
 	if (wr_chan_add(batch->_tuner, &id) != WR_OK) {
@@ -508,10 +545,14 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 	const uint8_t *bytes = (raw && !staged) ? raw->rawU8(&rawFrames) : NULL;
 	if (staged && sdev == _dev) {
 		rc = wr_tuner_submit(_tuner, staged, nframes, WR_DEVICE);
-	} else if (bytes && rawFrames == nframes) {
+	} else if (bytes && rawFrames == nframes && envUnsigned("WEBRADIO_NO_U8_STAGING", 0)) {
 		rc = wr_tuner_submit_u8(_tuner, bytes, nframes, WR_HOST);
 	} else {
 		staged = _channels.empty() ? NULL : stagedBlock(_channels[0]->mixer, tunerBuffer, &sdev, false);
+		if (!(staged && sdev == _dev) && !_source->hostBlockValid()) {
+			LOG_ERROR("the source left its block on the device and the device copy is not there\n");
+			return false;
+		}
 		rc = (staged && sdev == _dev) ? wr_tuner_submit(_tuner, staged, nframes, WR_DEVICE)
 		                              : wr_tuner_submit(_tuner, tunerBuffer.data(), nframes, WR_HOST);
 	}
@@ -529,23 +570,26 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 				_channels[n]->lateSeq = _lateSeq;          /* this block is the first in that slot: the ring entry
 				                                              of the block before it is not this channel's */
 		}
-	/* the graph hands this block's audio on within this very run(): no waiting for the next launch */
-	wr_tuner_flush(_tuner);
+	/* the graph hands this block's audio on within this very run(): no waiting for the next launch.
+	 * (WEBRADIO_AUDIO_LATE=2 hands out the audio of the block before the previous one: the demodulator and
+	 * audio filter of a block then ride in the NEXT block's launch, as in bench.py -- one launch per block.) */
+	if (!(_late && _lateDepth >= 2))
+		wr_tuner_flush(_tuner);
 	traceAdd(_source, 'S');
 	{
 		int ready = 0;
-		if (traceOn() && (!_late || _lateQueued) && wr_tuner_audio_ring_ready(_tuner, &ready) == WR_OK)
+		if (traceOn() && (!_late || _lateSeq > _lateDepth) && wr_tuner_audio_ring_ready(_tuner, &ready) == WR_OK)
 			traceAdd(_source, ready ? 'A' : 'W');
 	}
 	if (_late) {
-		/* WEBRADIO_AUDIO_LATE=1: the sinks get every block's audio ONE run() later (a block's worth
+		/* WEBRADIO_AUDIO_LATE=1 (2): the sinks get every block's audio ONE run() (TWO) later (a block's worth
 		 * of latency, 40 ms at C2).  Nothing in run() then waits for the GPU: this block's copy,
 		 * kernels and audio transfer are merely enqueued, what is handed out is the previous
 		 * block's audio, which arrived in the pinned ring while the host was busy elsewhere -- and
 		 * the front ends of a Radio (radio.cxx:56-59 pumps them one after the other) keep all their
 		 * GPUs busy at once.  The first block's run() hands out silence, the last block's audio is
 		 * dropped at stop(). */
-		_silence = !_lateQueued;
+		_silence = _lateSeq <= _lateDepth;          /* (blocks submitted so far, this one included) */
 		_lateQueued = true;
 		_audioSlots = 0;
 		if (!_silence) {
@@ -618,7 +662,7 @@ bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 	}
 	const int slot = ch->slot;
 	if (_audioSlots && slot >= 0 && (unsigned int)slot < _audioSlots && _audioFrames == out.size() &&
-	    (!_late || ch->lateSeq < _lateSeq)) {
+	    (!_late || ch->lateSeq + (_lateDepth - 1u) < _lateSeq)) {
 		memcpy(out.data(), _audioPtr + (size_t)slot * _audioStride, out.size() * sizeof(float));
 		return true;
 	}

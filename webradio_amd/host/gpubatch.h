@@ -49,6 +49,10 @@ wr_dev *deviceFor(const DspBlock *block);
  * output vector or the upload failed. */
 const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out,
                          bool only_if_present = false);
+/* false while the root source of `block` left its host vector unfilled for the current block (a byte-format
+ * source all of whose consumers read on the device): a device path that fails must then fail loudly */
+bool hostBlockValid(const DspBlock *block);
+
 
 /* WEBRADIO_TRACE=1: what the tuner batches did, in order -- 'S' a block submitted (enqueued, nothing
  * waited for), 'A' audio taken from the pinned ring that was already there, 'W' audio that had to
@@ -128,6 +132,7 @@ private:
 	size_t _audioStride, _audioFrames;
 	unsigned int _audioSlots;
 	bool _late;                       /* WEBRADIO_AUDIO_LATE: hand out the PREVIOUS block's audio (see submitOnce) */
+	unsigned int _lateDepth;          /* 1: the previous block's audio; 2: the one before (no flush: one launch per block) */
 	bool _lateQueued;                 /* a block has been submitted whose audio has not been handed out yet */
 	bool _silence;                    /* late mode, first block: nothing to hand out yet */
 	unsigned long long _lateSeq;      /* blocks submitted so far */

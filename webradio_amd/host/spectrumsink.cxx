@@ -68,6 +68,10 @@ bool SpectrumSink::process(const vector<sample_t> &inBuffer, vector<sample_t> &o
 	/* fed straight from the tuner: use the device copy every GPU consumer of it shares */
 	wr_dev *sdev = NULL;
 	const float *staged = wrhost::stagedBlock(this, inBuffer, &sdev);
+	if (!(staged && sdev == _dev) && !wrhost::hostBlockValid(this)) {
+		LOG_ERROR("SpectrumSink: the source left its block on the device and the device copy is not there\n");
+		return false;
+	}
 	int rc = (staged && sdev == _dev) ? wr_spectrum_push(_spec, staged, inBuffer.size() / 2, WR_DEVICE)
 	                                  : wr_spectrum_push(_spec, inBuffer.data(), inBuffer.size() / 2, WR_HOST);
 	if (rc != WR_OK) {

@@ -30,6 +30,8 @@ public:
 
 	void getSpectrum(float *magnitudes);
 
+	bool readsSourceOnDevice() const { return true; }           /* the staged device copy of the tuner block */
+
 private:
 	bool init();
 	void deinit();
