@@ -136,6 +136,15 @@ def cpu_baseline(cfg, ifs, blocks):
     }
 
 
+def committed_traffic():
+    """HBM bytes of the dominant kernels from the PMC passes of tools/profile_round.sh (profiles/traffic.json): they
+    cannot be collected from inside this process."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return {}
+
+
 def c3_secondary(torch, dev, blocks, n, steps, settle_ms):
     """BASELINE config 3: SpectrumSink (io/spectrumsink.cxx:88-142) as a waterfall -- 65536-point
     Hamming-windowed FFT every 32768 frames, dB with fft-shift -- over the same resident stream:
@@ -177,7 +186,12 @@ def c3_secondary(torch, dev, blocks, n, steps, settle_ms):
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5),
                      "algorithmic_bytes_per_frame": C3_BYTES_PER_FRAME,
-                     "traffic": None},
+                     "algorithmic_bytes_per_launch": rows * C3_BYTES_PER_FRAME,
+                     # PMC FETCH_SIZE + WRITE_SIZE of pass 1 + pass 2 per launch pair of `rows` frames, FETCH_SIZE
+                     # doubled as MI355X_MICROARCH.md (HBM) prescribes for wide coalesced loads on gfx950
+                     "traffic": (committed_traffic().get("c3") or {}).get("hbm_bytes_per_launch")
+                     if (committed_traffic().get("c3") or {}).get("frames_per_launch") == rows else None,
+                     "traffic_unit": "bytes per launch pair (k_fft64k_pass1 + pass2), profiles/traffic.json"},
     }
 
 
@@ -218,7 +232,8 @@ def c1_secondary(torch, dev, steps, settle_ms):
         "value": round(msps, 2), "unit": "complex Msamples/s of tuner input",
         "ms_per_block": round(dt / steps * 1e3, 5), "steps": steps,
         "times_real_time": round(msps / (c1["input_rate"] / 1e6), 1),
-        "note": "launch-latency bound: three small launches per 64 ms block (DDC; demodulator; audio filter -- D2 = 8 has no fused post stage)",
+        "note": "launch-latency bound: ONE small launch per 64 ms block (r03: the fused demodulator + audio filter also for "
+                "D2 = 8, riding in the next block's DDC launch; r02: three launches, 28.6-30.8 us)",
     }
 
 
@@ -593,9 +608,11 @@ def main():
                 "nco": args.nco,
                 "tuners_per_gpu": 1,
                 "parallelism": "one tuner per GPU, no collective",
-                "parity": "this mode (ROTATE) against the oracle in tests/: channel IQ <= 1e-6 on every channel; FM audio "
-                          "<= 1e-5 on the channels that hold a carrier (64 of the 256 here) -- on a noise-only channel the "
-                          "discriminator is ill-conditioned (SURVEY H3) and only the IQ is compared",
+                "parity": "this mode (ROTATE) against the oracle in tests/: channel IQ <= 1e-6 on every channel (measured "
+                          "<= 2.5e-7 at this size); FM audio <= 1e-5 on the channels that hold a carrier (64 of the 256 here) "
+                          "and, on ALL 256 channels, within what the channel's own IQ difference allows: per demodulator "
+                          "frame 1.25 * (|dz[k]|/|z[k]| + |dz[k-1]|/|z[k-1]|) / (2 pi) + 2.4e-7 cycles, through the audio "
+                          "filter's |taps| (tests/fm_bound.py; test_c2_full_size_properties asserts it at this size)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -612,15 +629,20 @@ def main():
                           "launches: the mean per launch includes the gaps between launches" % max(1, args.profile_stride),
                 "algorithmic_bytes_per_launch": nl * ALGO_BYTES_PER_SAMPLE,
                 "frames_per_launch": nl,
-                "note": "the path is fp32-VALU bound at 256 channels (DESIGN.md): "
-                        "HBM fraction is reported as the contract asks, not as the binding roof",
+                "note": "the path is VALU-bound at 256 channels, not HBM-bound (DESIGN.md 3.1): a channel-tap of the "
+                        "index-exact NCO is 7 VALU instructions, and at the issue ceiling this mix reaches on gfx950 "
+                        "(150 G wave-taps/s = 1.05 T wave-instructions/s with two recurrences per wave, "
+                        "profiles/r03_ubench_tap.txt) the 2.56 M wave-taps of a block alone take 17.1 us: the "
+                        "algorithmic 34.05 MB per block then are 1.99 TB/s = 24.9 % of the 8 TB/s roof -- the ceiling of "
+                        "this formulation (29 % at the nominal 1.22 T/s); `frac` is to be read against that",
+                "valu_ceiling_frac_of_hbm_roof": 0.249,
                 # the binding resource, for context: VALU wave-instructions the DDC taps need (7 per
                 # channel-tap in the ROTATE mode, 64 lanes per wave) against the rate the same
-                # instruction mix reaches in isolation (profiles/r01_ubench_rot.txt, 32 waves per CU)
+                # instruction mix reaches in isolation (profiles/r03_ubench_tap.txt: two recurrences per wave)
                 "valu": {
                     "tap_wave_instr_per_launch": tap_instr,
-                    "isolated_rate_wave_instr_per_s": 0.954e12,
-                    "frac": round(tap_instr / 0.954e12 / (ddc_ms / 1e3), 4) if ddc_ms > 0 else None,
+                    "isolated_rate_wave_instr_per_s": 1.05e12,
+                    "frac": round(tap_instr / 1.05e12 / (ddc_ms / 1e3), 4) if ddc_ms > 0 else None,
                     # SURVEY 8d's algorithmic flop count against the fp32 vector peak
                     "fp32_tflops": round(nl * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12, 2) if ddc_ms > 0 else None,
                     "fp32_frac_of_vector_peak": round(nl * ALGO_FLOP_PER_SAMPLE * args.channels / 256 / (ddc_ms / 1e3) / 1e12
@@ -628,6 +650,10 @@ def main():
                 },
             },
         }
+        if one is not None:
+            # the same job with every 40 ms block a launch of its own (no added audio latency): the like-for-like
+            # successor of the r01 figure
+            out["value_one_block_per_launch"] = one["value"]
         if world == 1 and (c3 is not None or one is not None):
             out["secondary"] = {}
             if one is not None:

@@ -49,6 +49,18 @@ if nA:
     stat("wave life, the others", (tl[:, 11] - tl[:, 0])[nA:])
     stat("prologue, post-tile workgroups", (tl[:, 1] - tl[:, 0])[:nA])
 print("kernel span (ticks): %d" % (tl[:, 11].max() - t0))
+try:
+    rb = np.zeros(NW * 2, dtype=np.uint64)
+    lib.wr_debug_timeline_rt(rb.ctypes.data_as(C.c_void_p), C.c_size_t(rb.size))
+    rt = rb.reshape(NW, 2).astype(np.int64)[used][: tl.shape[0]]
+    life_rt = (rt[:, 1] - rt[:, 0]).astype(np.float64)
+    ok = life_rt > 500                                  # waves that lived > 5 us
+    clk = (tl[:, 11] - tl[:, 0])[ok] / life_rt[ok] * 100e6 / 1e9
+    stat("shader clock per wave (MHz)", (clk * 1000).astype(np.int64))
+    stat("wave life (ns, constant clock)", (life_rt[ok] * 10).astype(np.int64))
+    print("first start to last end, constant clock: %.2f us" % ((rt[:, 1].max() - rt[:, 0][rt[:, 0] > 0].min()) / 100.0))
+except AttributeError:
+    pass
 t.destroy()
 
 # the post-stage tenants (previous block's demod + audio filter in extra workgroups of the launch)

@@ -43,7 +43,15 @@ extern "C" int wr_debug_timeline(unsigned long long *out, size_t n)
 {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_tl), n * sizeof(unsigned long long));
 }
-#define TL(slot) do { if (lane == 0 && wid < 16384u && (slot) < TL_SLOTS) g_ddc_tl[wid * TL_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+/* (slot 0 and 11 also take the constant 100 MHz clock: the shader clock the wave really ran at is
+ * (memtime[11] - memtime[0]) / (realtime[11] - realtime[0]) x 100 MHz) */
+__device__ unsigned long long g_ddc_rt[16384 * 2];
+extern "C" int wr_debug_timeline_rt(unsigned long long *out, size_t n)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_rt), n * sizeof(unsigned long long));
+}
+#define TL(slot) do { if (lane == 0 && wid < 16384u && (slot) < TL_SLOTS) { g_ddc_tl[wid * TL_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); \
+	if ((slot) == 0 || (slot) == 11) g_ddc_rt[wid * 2u + ((slot) ? 1u : 0u)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 /* the post-stage tenants of the same launch: wave start, stage phase done, filter done, wave end (of
  * the last tile of a run) */
 __device__ unsigned long long g_post_tl[8192 * 4];
