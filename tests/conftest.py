@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# The lean DDC loop runs two lane groups per wave (k_tuner_ddc: NG = 2) only for streams long enough to fill the
+# grid four times over; the tests' streams are short, so they ask for it whenever the launch allows -- an even number
+# of lane groups on one channel filter -- and cover NG = 1 through odd group counts and mixed passbands.
+os.environ.setdefault("WR_DDC_NG2_MIN_PASSES", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The built libraries are git-ignored; if this checkout has none (fresh clone), build them

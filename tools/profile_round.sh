@@ -5,7 +5,7 @@
 #                                            clock settling and the timed steps)
 #   gpurun_out/<round>_kernel_stats_timed.csv   the same trace, the timed region's launches only
 #   gpurun_out/<round>_pmc_fetch_size.txt / _pmc_write_size.txt   FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
-round=${1:-r02}
+round=${1:-r03}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R && python bench.py > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err

@@ -23,6 +23,8 @@
  */
 #include "wr_internal.h"
 
+#include <cstdlib>
+
 #include <hip/hip_ext.h>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1810,7 +1812,15 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		unsigned int n = 0;
 		for (unsigned int g = 0; g < L.slots_used / 64; ++g)
 			n += (!gsel || ((gsel >> g) & 1ull)) ? 1u : 0u;
-		if (L.one_filter && n >= 2u && n <= 16u && (n & 1u) == 0u)
+		/* ... and enough output frames: a wave of the NG = 2 kernel does twice the work per pass of its loop, so
+		 * with few passes per wave the grid ends ragged (BASELINE config 5: 5 065 frames per chunk, 2.5 passes per
+		 * wave -- 48 us against 43 with one lane group per wave); from four passes on the shared reads win */
+		const size_t waves2 = (size_t)num_cus * (DDC_NG2_WAVES_PER_EU * 4u / W - (PD2 ? 1u : 0u)) * W;
+		static const size_t min_passes = [] {                /* WR_DDC_NG2_MIN_PASSES=0: always (the tests' small streams) */
+			const char *e = getenv("WR_DDC_NG2_MIN_PASSES");
+			return (size_t)((e && *e) ? strtoul(e, nullptr, 0) : 4ul);
+		}();
+		if (L.one_filter && n >= 2u && n <= 16u && (n & 1u) == 0u && L.k1 * (n / 2u) >= min_passes * waves2)
 			return launch_ddc<NCO, UTAPS, PD2, 2u>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
 	}
 	const unsigned int allgroups = L.slots_used / 64;        /* <= 64: wr_tuner_create caps max_channels */
