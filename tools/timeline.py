@@ -18,6 +18,16 @@ for _ in range(int(os.environ.get('TL_WARM', '6'))):
     t.submit_device(x, n)
 torch.cuda.synchronize()
 lib = C.CDLL(capi.LIB_PATH)
+try:
+    # only the LAST launch's stamps: clear what the warm-up launches left, then two more launches (the first of
+    # them without a riding post stage if the warm-up ended on a flush)
+    t.submit_device(x, n)
+    torch.cuda.synchronize()
+    lib.wr_debug_timeline_reset()
+    t.submit_device(x, n)
+    torch.cuda.synchronize()
+except AttributeError:
+    pass
 SL, NW = 12, 16384
 buf = np.zeros(NW * SL, dtype=np.uint64)
 rc = lib.wr_debug_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
@@ -59,6 +69,47 @@ try:
     stat("shader clock per wave (MHz)", (clk * 1000).astype(np.int64))
     stat("wave life (ns, constant clock)", (life_rt[ok] * 10).astype(np.int64))
     print("first start to last end, constant clock: %.2f us" % ((rt[:, 1].max() - rt[:, 0][rt[:, 0] > 0].min()) / 100.0))
+    # by XCD (workgroup b runs on XCD b % 8; 8-wave workgroups): when do an XCD's DDC waves end, on the constant clock?
+    wpw = int(os.environ.get("TL_WAVES_PER_WG", "8"))
+    wids = np.nonzero(used)[0][: tl.shape[0]]
+    xcd = (wids // wpw) % 8
+    t00 = rt[:, 0][rt[:, 0] > 0].min()
+    for x in range(8):
+        m = (xcd == x) & ok
+        if m.sum():
+            e = (rt[m, 1] - t00) / 100.0
+            print("XCD %d: %4d waves  end of wave (us after the first start): median %.1f  p90 %.1f  max %.1f   clock median %.0f MHz  life median %.1f us" % (
+                x, m.sum(), np.median(e), np.percentile(e, 90), e.max(), np.median(clk[m[ok]]) * 1000, np.median(life_rt[m]) / 100.0))
+    try:
+        hb = np.zeros(NW * 2, dtype=np.uint32)
+        lib.wr_debug_timeline_hw(hb.ctypes.data_as(C.c_void_p), C.c_size_t(hb.size))
+        hw = hb.reshape(NW, 2)[used][: tl.shape[0]]
+        # HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]...; XCC_ID[3:0]
+        cu = ((hw[:, 1] & 15).astype(np.int64) << 12) | (((hw[:, 0] >> 13) & 7).astype(np.int64) << 8) | (((hw[:, 0] >> 12) & 1).astype(np.int64) << 4) | ((hw[:, 0] >> 8) & 15)
+        simd = (hw[:, 0] >> 4) & 3
+        per_cu = {}
+        for c_, w_ in zip(cu[ok], wg[ok] if False else (wids // wpw)[ok]):
+            per_cu.setdefault(int(c_), set()).add(int(w_))
+        counts = np.array([len(v) for v in per_cu.values()])
+        print("DDC workgroups per CU: %d CUs seen; %s" % (counts.size, dict(zip(*np.unique(counts, return_counts=True)))))
+        lifeus = life_rt / 100.0
+        for n_ in sorted(set(counts)):
+            cus = {c_ for c_, v in per_cu.items() if len(v) == n_}
+            m = ok & np.array([int(c_) in cus for c_ in cu])
+            print("  CUs with %d DDC workgroup(s): wave life median %.1f us  p90 %.1f  (%d waves)" % (n_, np.median(lifeus[m]), np.percentile(lifeus[m], 90), m.sum()))
+        for sd in range(4):
+            m = ok & (simd == sd)
+            print("  SIMD %d: %d waves, life median %.1f us" % (sd, m.sum(), np.median(lifeus[m])))
+    except AttributeError:
+        pass
+    # by CU-sized neighbourhoods: the spread of last-wave end times over workgroups
+    wg = wids // wpw
+    ends = {}
+    for w, e in zip(wg[ok], (rt[ok, 1] - t00) / 100.0):
+        ends[w] = max(ends.get(w, 0.0), e)
+    ev = np.array(sorted(ends.values()))
+    print("last wave of each DDC workgroup ends (us): p10 %.1f  median %.1f  p90 %.1f  max %.1f  (%d workgroups)" % (
+        np.percentile(ev, 10), np.median(ev), np.percentile(ev, 90), ev.max(), ev.size))
 except AttributeError:
     pass
 t.destroy()

@@ -1481,7 +1481,12 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 					}
 				}
 				/* nothing crosses a stage: left alone, the scheduler hoists all 32 window reads of a unit to
-				 * its top (128 registers of them) and spills them */
+				 * its top (128 registers of them) and spills them -- and the optimiser, for which the carries and
+				 * selects of ALL taps depend on nothing but the phase, may compute them first and sink the
+				 * multiply-adds to where the result is used: the recurrence is pinned stage by stage */
+#pragma unroll
+				for (unsigned int c = 0; c < NG; ++c)
+					asm volatile("" : "+v"(A[c].x), "+v"(A[c].y), "+v"(F[c]));
 				__builtin_amdgcn_sched_barrier(0);
 			}
 #pragma unroll
