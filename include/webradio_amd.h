@@ -108,6 +108,7 @@ int wr_lowpass_design(unsigned int passband, unsigned int input_rate,
  * expression of init()/recalculate() is already written in terms of _firLength.  A power of
  * two (the mask logic of lowpass.cxx:172,184) in [2, WR_FIR_MAX]. */
 #define WR_FIR_MAX 1024
+#define WR_FIR_FUSED_MAX 256     /* longest channel filter the fused per-tuner path takes (wr_chan_set_taps_n, stage 0) */
 int wr_lowpass_design_n(unsigned int fir_length, unsigned int passband, unsigned int input_rate,
                         float *coeff_host /* [fir_length] */, unsigned int *maxbin_out);
 /* SpectrumSink::init window (io/spectrumsink.cxx:71-74); window[fft_size] */
@@ -201,7 +202,12 @@ int wr_chan_set_taps(wr_tuner *tuner, int chan, int stage, const float *coeff_ho
 /* LowPass::_firLength as a run-time value (dsp/lowpass.cxx:38-39 FIXME, :102-110, :167-189 are
  * written in terms of it) INSIDE the fused path: fir_length a power of two in [2, 64].  A shorter
  * filter is the 64-tap filter with its oldest taps zero, bit for bit (the sum runs oldest sample
- * first, lowpass.cxx:150-158).  Longer filters: wr_fir_decimate_n, block by block. */
+ * first, lowpass.cxx:150-158).  The CHANNEL filter (stage 0) may also have 128 or 256 taps
+ * (WR_FIR_FUSED_MAX): receivers with such a filter form rate groups of their own, evaluated by a plain kernel
+ * with the reference's own arithmetic -- table lookups, unfused products, oldest sample first, the last L - 1
+ * MIXED frames kept per channel as LowPass::block does (lowpass.cxx:138-142) -- bit-identical to the reference
+ * chain in every nco mode, at a fraction of the fast kernels' speed (still without a full-rate mixer output).
+ * Longer filters and long audio filters: wr_fir_decimate_n, block by block. */
 int wr_chan_set_filter_n(wr_tuner *tuner, int chan, int stage, unsigned int fir_length,
                          unsigned int passband, unsigned int out_rate);
 int wr_chan_set_taps_n(wr_tuner *tuner, int chan, int stage, const float *coeff_host /* [fir_length] */,

@@ -113,6 +113,8 @@ int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int
 			rx[n]->channelFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH")));
 			rx[n]->audioFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH")));
 		}
+		if (getenv("WR_TEST_FIR_LENGTH_CHAN"))       /* the channel filter alone: such a Receiver stays in the tuner batch */
+			rx[n]->channelFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH_CHAN")));
 		rx[n]->setFrontEnd(fe);
 	}
 	int rc = 0;

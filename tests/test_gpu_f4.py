@@ -77,9 +77,60 @@ def test_fir_length_inside_the_fused_path(dev, oracle, nco, lengths):
     t = Tuner(dev, fs, 1, 1000, nco)
     c = C.c_int()
     capi.check(t.lib.wr_chan_add(t.h, C.byref(c)))
-    assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 128, 128_000, 5_000) == capi.WR_ERR_ARG
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 512, 128_000, 5_000) == capi.WR_ERR_ARG     # channel filter: up to 256
     assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 48, 128_000, 5_000) == capi.WR_ERR_ARG
+    capi.check(t.lib.wr_chan_set_filter_n(t.h, 0, 0, 128, 128_000, 5_000))
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 1, 128, 800, 1_000) == capi.WR_ERR_ARG         # audio filter: up to 64
     t.destroy()
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+@pytest.mark.parametrize("l1,d1,sizes", [(128, 400, ((40_000, 3), (2_000, 5))), (256, 400, ((48_000, 2), (2_000, 4))),
+                                         (256, 40, ((200, 12), (4_000, 3))), (128, 20, ((100, 9),))])
+def test_channel_filter_of_128_and_256_taps_inside_the_tuner(dev, oracle, nco, l1, d1, sizes):
+    """r03, SURVEY 8f-4: LowPass::_firLength 128 and 256 for the channel filter INSIDE the tuner's launch sequence
+    (k_tuner_ddc_long: the reference's own arithmetic, the last L - 1 mixed frames kept per channel as LowPass::block
+    does) -- bit-identical to the oracle's mixer -> `_n` filter -> AM -> audio filter cascade in EVERY nco mode.
+    70 receivers (two lane groups), blocks shorter than the filter's history (200 frames against 255), a retune
+    in mid-stream (the history keeps the frames as they were mixed, downconverter.cxx:59-67), and a receiver with
+    the usual 64 taps beside them in the same tuner (another rate group, the fast kernels)."""
+    fs, d2 = 2_000_000, 5
+    ifs = [(-35 + c) * 6250 + 321 for c in range(70)]
+    probe = [0, 1, 33, 63, 64, 69]
+    pb1 = 128_000
+    assert oracle.lowpass_maxbin_n(l1, pb1, fs) >= 1
+    for n, blocks in sizes:
+        t = Tuner(dev, fs, 71, n, nco)
+        chans = [t.add_receiver(f, pb1, fs // d1, capi.WR_AM, fs // d1 // 8, fs // d1 // d2, fir_lengths=(l1, 64)) for f in ifs]
+        plain = t.add_receiver(4321, pb1, fs // d1, capi.WR_USB, fs // d1 // 8, fs // d1 // d2)
+        rxs = {c: OracleChain(oracle, fs, ifs[c], l1, pb1, d1, oracle.AM, 64, fs // d1 // 8, d2) for c in probe}
+        rxp = OracleChain(oracle, fs, 4321, 64, pb1, d1, oracle.USB, 64, fs // d1 // 8, d2)
+        t.profile(True)                                    # both rate groups' launches stamp their events
+        pos = 0
+        for b in range(blocks):
+            if b == 1:                                     # retune one of them between two blocks
+                t.set_if(chans[33], ifs[33] + 7777)
+                rxs[33].step = oracle.phase_step(ifs[33] + 7777, fs)
+            iq = synth.fm_stream(n, fs, [ifs[c] for c in probe[::2]] + [4321], start_frame=pos, amp=0.12, fm_base=30.0, beta=2.0)
+            pos += n
+            t.submit_host(iq)
+            for c in probe:
+                wa, wc, _ = rxs[c].run(iq)
+                gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)
+                ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
+                assert gc.size == wc.size and ga.size == wa.size
+                assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, b, c)
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, b, c)
+            wa, wc, _ = rxp.run(iq)
+            gc = t.fetch(plain, capi.WR_STAGE_CHAN_IQ, 2 * n)
+            if nco == capi.WR_NCO_EXACT:
+                assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, b)
+            else:
+                assert np.abs(gc - wc).max() <= 1e-6, (n, b)
+        assert float(np.abs(t.fetch(chans[0], capi.WR_STAGE_AUDIO, n)).max()) > 1e-3 or n < d1 * d2     # a live channel
+        launches, ms = t.profile_read()
+        assert launches == 2 * blocks and 0.0 < ms < 50.0, (launches, ms)
+        t.destroy()
 
 
 @pytest.mark.parametrize("fs,d1,pb1,sizes", [(5_000_000, 20, 160_000, ((200_000, 2), (1_000, 8), (5_000, 4))),

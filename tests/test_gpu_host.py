@@ -37,7 +37,8 @@ L.wr_host_run.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, ip, ip, 
 rc = L.wr_host_run(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), nrx, ifs.ctypes.data_as(ip),
                    modes.ctypes.data_as(ip), int(p[2]), int(p[3]), int(p[4]), int(p[5]), int(p[6]), int(p[7]),
                    audio.ctypes.data_as(fp), cap, C.byref(n), fft, spec.ctypes.data_as(fp))
-np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], spec=spec, left=L.wr_host_registry_sizes())
+np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], spec=spec, left=L.wr_host_registry_sizes(),
+         traced=L.wr_host_trace_count())
 '''
 
 
@@ -118,6 +119,34 @@ def test_runtime_fir_length_through_the_host_classes(tmp_path, oracle):
     base, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
                    env={"WEBRADIO_NO_FUSION": "1"})
     assert np.abs(base - got).max() > 1e-4
+
+
+@pytest.mark.parametrize("L", [128, 256])
+def test_long_channel_filter_stays_in_the_tuner_batch(tmp_path, oracle, L):
+    """r03: channelFilter()->setFirLength(128 | 256) with the audio filter at its 64 taps: the Receiver stays in the
+    source's tuner batch (WEBRADIO_TRACE shows it submitting) -- k_tuner_ddc_long runs the channel filter in the
+    reference's own arithmetic, so the linear detectors are the oracle's bits in the DEFAULT (ROTATE) nco mode too.
+    A retune between blocks 1 and 2."""
+    ifs, modes = [50_000, -75_000, 10, 33_333], [0, 2, 3, 0]
+    rate, block, cpb, crate, apb, arate = CFG["rate"], CFG["block"], CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"]
+    iq = synth.fm_stream(4 * block, rate, ifs[:2], amp=0.3)
+    got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(2, 61_000),
+                  env={"WR_TEST_FIR_LENGTH_CHAN": str(L), "WEBRADIO_TRACE": "1"})
+    assert int(np.load(str(tmp_path / "out.npz"))["traced"]) > 0
+    table = oracle.sin_table()
+    for c, (f, m) in enumerate(zip(ifs, modes)):
+        f1 = oracle.Fir(2, rate // crate, oracle.lowpass_design(cpb, rate, L))
+        f2 = oracle.Fir(1, crate // arate, oracle.lowpass_design(apb, crate))
+        phase, prev, want = 0, (0.0, 0.0), []
+        for b in range(4):
+            if c == 0 and b == 2:
+                f = 61_000
+            mixed, phase = oracle.mix(table, phase, oracle.phase_step(f, rate), iq[2 * b * block: 2 * (b + 1) * block])
+            d, prev = oracle.demod(m, prev, f1.process(mixed))
+            want.append(f2.process(d))
+        want = np.concatenate(want)
+        assert got[c].size == want.size
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
 
 
 def test_unfused_blocks_are_bit_exact(tmp_path, oracle):

@@ -83,6 +83,8 @@ struct Chan {
 	int mode;
 	bool have[3];              /* [0] channel filter, [1] audio filter, [2] optional second channel filter */
 	float taps[3][WR_FIR_LENGTH];
+	unsigned int len1;         /* taps of the channel filter: 64 (shorter ones are zero-extended to it) or 128 / 256 */
+	float taps_long[WR_FIR_FUSED_MAX];   /* ... and, when len1 > 64, the taps themselves (taps[0] is not used then) */
 	unsigned int decim[3];
 	float gain;                /* af_gain as a factor (1 = 0 dB) */
 	float squelch;             /* squelch threshold as a power (0 = open) */
@@ -98,6 +100,7 @@ struct Chan {
 struct Group {
 	unsigned int d1, d2;
 	unsigned int d1b = 0;      /* decimation of the second channel-filter stage, 0 = there is none */
+	unsigned int l1 = WR_FIR_LENGTH;   /* taps of the group's channel filters: 64, or 128 / 256 (k_tuner_ddc_long) */
 	int p2 = 0;                /* which iq2_hist set the next block reads */
 	bool use_gain = false, use_squelch = false;
 	unsigned int slots;
@@ -652,6 +655,9 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.iq2_hist[1]);
 	(void)hipFree(g->dev.chan_iq2[0]);
 	(void)hipFree(g->dev.chan_iq2[1]);
+	(void)hipFree(g->dev.taps1L);
+	(void)hipFree(g->dev.mixhist[0]);
+	(void)hipFree(g->dev.mixhist[1]);
 	(void)hipFree(g->dev.gain);
 	(void)hipFree(g->dev.squelch);
 	(void)hipFree(g->dev.prev_iq[0]);
@@ -664,7 +670,7 @@ static void group_free(Group *g)
 	delete g;
 }
 
-static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned int d2, Group **out)
+static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned int d2, unsigned int l1, Group **out)
 {
 	Group *g = new (std::nothrow) Group();
 	if (!g)
@@ -675,6 +681,7 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	g->d1 = d1;
 	g->d1b = d1b;
 	g->d2 = d2;
+	g->l1 = l1;
 	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
 	g->k1max = t->max_block_frames / d1;       /* first-stage frames; the later stages need no more */
 	g->k2max = g->k1max / (d1b ? d1b : 1u) / d2;
@@ -702,6 +709,11 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S * WR_TAPSETS);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps2u, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.tapsel, S);
+	if (l1 > WR_FIR_LENGTH) {
+		if (!rc) rc = dev_alloc_zero(&g->dev.taps1L, S * l1);
+		if (!rc) rc = dev_alloc_zero(&g->dev.mixhist[0], (size_t)(l1 - 1) * S * 2);
+		if (!rc) rc = dev_alloc_zero(&g->dev.mixhist[1], (size_t)(l1 - 1) * S * 2);
+	}
 	if (!rc) rc = dev_alloc_zero(&g->dev.gain, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.squelch, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[0], (size_t)WR_HIST * S * 2);      /* wr_tuner_seek clears it */
@@ -852,6 +864,7 @@ extern "C" int wr_chan_add(wr_tuner *t, int *chan)
 	Chan &c = t->chans[idx];
 	memset(&c, 0, sizeof(c));
 	c.in_use = true;
+	c.len1 = WR_FIR_LENGTH;
 	c.mode = WR_AM;                /* Demodulator ctor, demodulator.cxx:34 */
 	c.gain = 1.0f;                 /* what the reference reports: af_gain 0, squelch_threshold 0 (receiverhandler.cxx:118-119) */
 	c.squelch = 0.0f;
@@ -920,7 +933,8 @@ static int chan_seat(wr_tuner *t, int idx)
 		return WR_OK;
 	if (c.group >= 0) {
 		Group *g = t->groups[c.group];
-		if (g->d1 == c.decim[0] && g->d2 == c.decim[1] && g->d1b == (c.have[2] ? c.decim[2] : 0u)) {
+		if (g->d1 == c.decim[0] && g->d2 == c.decim[1] && g->d1b == (c.have[2] ? c.decim[2] : 0u) &&
+		    g->l1 == (c.len1 > WR_FIR_LENGTH ? c.len1 : (unsigned int)WR_FIR_LENGTH)) {
 			g->dirty = true;
 			return WR_OK;
 		}
@@ -931,7 +945,8 @@ static int chan_seat(wr_tuner *t, int idx)
 	int gi = -1;
 	for (size_t i = 0; i < t->groups.size(); ++i)
 		if (t->groups[i]->d1 == c.decim[0] && t->groups[i]->d2 == c.decim[1] &&
-		    t->groups[i]->d1b == (c.have[2] ? c.decim[2] : 0u)) {
+		    t->groups[i]->d1b == (c.have[2] ? c.decim[2] : 0u) &&
+		    t->groups[i]->l1 == (c.len1 > WR_FIR_LENGTH ? c.len1 : (unsigned int)WR_FIR_LENGTH)) {
 			gi = (int)i;
 			break;
 		}
@@ -939,7 +954,8 @@ static int chan_seat(wr_tuner *t, int idx)
 		if (dev_bind(t->dev))
 			return WR_ERR_HIP;
 		Group *g = nullptr;
-		int rc = group_create(t, c.decim[0], c.have[2] ? c.decim[2] : 0u, c.decim[1], &g);
+		int rc = group_create(t, c.decim[0], c.have[2] ? c.decim[2] : 0u, c.decim[1],
+		                      c.len1 > WR_FIR_LENGTH ? c.len1 : (unsigned int)WR_FIR_LENGTH, &g);
 		if (rc)
 			return rc;
 		t->groups.push_back(g);
@@ -978,7 +994,9 @@ extern "C" int wr_chan_set_if(wr_tuner *t, int chan, int if_hz)
 	return WR_OK;
 }
 
-static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff, unsigned int decim)
+/* `coeff`: 64 taps (a shorter filter zero-extended), or -- stage 0 only -- `len` = 128 or 256 of them */
+static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff, unsigned int decim,
+                           unsigned int len = WR_FIR_LENGTH)
 {
 	Chan *c = chan_get(t, chan);
 	if (!c)
@@ -987,7 +1005,13 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
 		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
 	if (!decim)
 		return fail(WR_ERR_ARG, "decimation must be >= 1");
-	memcpy(c->taps[stage], coeff, sizeof(float) * WR_FIR_LENGTH);
+	if (stage == 0) {
+		c->len1 = len;
+		if (len > WR_FIR_LENGTH)
+			memcpy(c->taps_long, coeff, sizeof(float) * len);
+	}
+	if (len <= WR_FIR_LENGTH)
+		memcpy(c->taps[stage], coeff, sizeof(float) * WR_FIR_LENGTH);
 	c->decim[stage] = decim;
 	c->have[stage] = true;
 	return chan_seat(t, chan);
@@ -998,9 +1022,10 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
  * the oldest samples -- are zero.  lowpass.cxx:150-158 adds the products oldest sample first, so the
  * padded filter starts with 64 - L products that are +-0 and then runs through exactly the additions
  * of the short one: the same bits (finite input). */
-static bool fused_fir_length_ok(unsigned int n)
+static bool fused_fir_length_ok(unsigned int n, int stage = 1)
 {
-	return n >= 2 && n <= WR_FIR_LENGTH && (n & (n - 1)) == 0;
+	/* the channel filter (stage 0) may also have 128 or 256 taps: k_tuner_ddc_long */
+	return n >= 2 && n <= (stage == 0 ? (unsigned int)WR_FIR_FUSED_MAX : (unsigned int)WR_FIR_LENGTH) && (n & (n - 1)) == 0;
 }
 
 extern "C" int wr_chan_set_taps_n(wr_tuner *t, int chan, int stage, const float *coeff_host,
@@ -1008,12 +1033,13 @@ extern "C" int wr_chan_set_taps_n(wr_tuner *t, int chan, int stage, const float 
 {
 	if (!t || !coeff_host)
 		return fail(WR_ERR_ARG, "wr_chan_set_taps: bad argument");
-	if (!fused_fir_length_ok(fir_length))
-		return fail(WR_ERR_ARG, "wr_chan_set_taps_n: fir_length %u is not a power of two in [2, %d] (longer filters "
-		                        "run block by block: wr_fir_decimate_n)", fir_length, WR_FIR_LENGTH);
-	float coeff[WR_FIR_LENGTH] = {0.0f};
+	if (!fused_fir_length_ok(fir_length, stage))
+		return fail(WR_ERR_ARG, "wr_chan_set_taps_n: fir_length %u is not a power of two in [2, %d] (%d for the channel "
+		                        "filter; longer filters run block by block: wr_fir_decimate_n)", fir_length, WR_FIR_LENGTH,
+		            WR_FIR_FUSED_MAX);
+	float coeff[WR_FIR_FUSED_MAX] = {0.0f};
 	memcpy(coeff, coeff_host, sizeof(float) * fir_length);
-	return set_taps_common(t, chan, stage, coeff, decimation);
+	return set_taps_common(t, chan, stage, coeff, decimation, fir_length > WR_FIR_LENGTH ? fir_length : (unsigned int)WR_FIR_LENGTH);
 }
 
 extern "C" int wr_chan_set_taps(wr_tuner *t, int chan, int stage, const float *coeff_host,
@@ -1030,9 +1056,9 @@ extern "C" int wr_chan_set_filter_n(wr_tuner *t, int chan, int stage, unsigned i
 		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_filter: no channel %d", chan);
 	if (stage < 0 || stage > 2)
 		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
-	if (!fused_fir_length_ok(fir_length))
-		return fail(WR_ERR_ARG, "wr_chan_set_filter_n: fir_length %u is not a power of two in [2, %d]", fir_length,
-		            WR_FIR_LENGTH);
+	if (!fused_fir_length_ok(fir_length, stage))
+		return fail(WR_ERR_ARG, "wr_chan_set_filter_n: fir_length %u is not a power of two in [2, %d] (%d for the channel filter)",
+		            fir_length, WR_FIR_LENGTH, WR_FIR_FUSED_MAX);
 	unsigned int in_rate;
 	if (stage == 0) {
 		in_rate = t->input_rate;
@@ -1049,9 +1075,9 @@ extern "C" int wr_chan_set_filter_n(wr_tuner *t, int chan, int stage, unsigned i
 	unsigned int decim = in_rate / out_rate;           /* dspblock.cxx:119-121 */
 	if (in_rate / decim != out_rate || in_rate % out_rate)
 		return fail(WR_ERR_RATE, "Sample rates must be integer related (%u -> %u)", in_rate, out_rate);
-	float coeff[WR_FIR_LENGTH] = {0.0f};
+	float coeff[WR_FIR_FUSED_MAX] = {0.0f};
 	wrd_lowpass_design(fir_length, passband, in_rate, coeff);
-	return set_taps_common(t, chan, stage, coeff, decim);
+	return set_taps_common(t, chan, stage, coeff, decim, fir_length > WR_FIR_LENGTH ? fir_length : (unsigned int)WR_FIR_LENGTH);
 }
 
 extern "C" int wr_chan_set_filter(wr_tuner *t, int chan, int stage, unsigned int passband,
@@ -1214,6 +1240,7 @@ static int group_upload(wr_tuner *t, Group *g)
 	std::vector<int> flags(S, 0), mode(S, -1);      /* mode < 0 marks an idle slot */
 	std::vector<float> taps1(S * WR_FIR_LENGTH, 0.0f), taps2(S * WR_FIR_LENGTH, 0.0f);
 	std::vector<float> taps1b(g->d1b ? S * WR_FIR_LENGTH : 0, 0.0f), gain(S, 1.0f), squelch(S, 0.0f);
+	std::vector<float> taps1L(g->l1 > WR_FIR_LENGTH ? S * g->l1 : 0, 0.0f);
 	g->use_gain = g->use_squelch = false;
 	for (size_t s = 0; s < S; ++s) {
 		int ci = g->owner[s];
@@ -1229,6 +1256,9 @@ static int group_upload(wr_tuner *t, Group *g)
 			if (g->d1b)
 				taps1b[(size_t)j * S + s] = c.taps[2][j];
 		}
+		if (g->l1 > WR_FIR_LENGTH)
+			for (unsigned int j = 0; j < g->l1; ++j)
+				taps1L[(size_t)j * S + s] = c.taps_long[j];
 		gain[s] = c.gain;
 		squelch[s] = c.squelch;
 		g->use_gain = g->use_gain || c.gain != 1.0f;
@@ -1341,6 +1371,8 @@ static int group_upload(wr_tuner *t, Group *g)
 	HIP_TRY(hipMemcpyAsync(g->dev.flags, flags.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.mode, mode.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1, taps1.data(), taps1.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	if (g->l1 > WR_FIR_LENGTH)
+		HIP_TRY(hipMemcpyAsync(g->dev.taps1L, taps1L.data(), taps1L.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps2, taps2.data(), taps2.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g->dev.taps1u, taps1u.data(), taps1u.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1375,6 +1407,9 @@ static int group_upload(wr_tuner *t, Group *g)
 			                         WR_HIST, st));
 			HIP_TRY(hipMemset2DAsync(g->dev.iq2_hist[g->p2] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
 			                         WR_HIST, st));
+			if (g->l1 > WR_FIR_LENGTH)        /* the L - 1 mixed frames of this slot */
+				HIP_TRY(hipMemset2DAsync(g->dev.mixhist[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
+				                         g->l1 - 1, st));
 			c.cs_hist_reset = false;
 		}
 		if (c.dem_hist_reset) {
@@ -1616,8 +1651,13 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		/* The previous block's post stage rides along with this block's DDC where the kernel
 		 * variant can take it (wrk_tuner_ddc says); otherwise it goes out on its own first. */
 		bool rode = false;
-		HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
-		                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
+		if (g->l1 > WR_FIR_LENGTH)
+			/* a channel filter of 128 or 256 taps: the plain kernel with the reference's arithmetic (wr_kernels.hip:
+			 * k_tuner_ddc_long), which also rolls phase and mixed history; such a group never defers its post stage */
+			HIP_TRY(wrk_tuner_ddc_long(st, L, g->dev, g->l1, d->table, d->num_cus));
+		else
+			HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
+			                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
 		if (prof_now) {
 			t->ev_span.resize(t->ev_used / 2 + 1, 1u);
 			t->ev_used += 2;
@@ -1646,7 +1686,8 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
 		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
-		const bool defer = !two_kernels && !g->d1b && L.k1 && t->defer_post && t->nco_mode == WR_NCO_ROTATE;
+		const bool defer = !two_kernels && !g->d1b && g->l1 <= WR_FIR_LENGTH && L.k1 && t->defer_post &&
+		                   t->nco_mode == WR_NCO_ROTATE;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, Lp, Gp));
 			HIP_TRY(wrk_tuner_audio(st, Lp, Gp));
@@ -1668,7 +1709,8 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		g->last_parity = g->parity;
 		g->last_cb = g->cb;
 		g->sp ^= 1;                    /* the kernels wrote the other state set */
-		hist_written = true;           /* k_tuner_ddc stored the next input history */
+		if (g->l1 <= WR_FIR_LENGTH)
+			hist_written = true;       /* k_tuner_ddc stored the next input history (k_tuner_ddc_long keeps its own) */
 		if (Lp.k1)
 			g->parity ^= 1;            /* k_tuner_demod filled the other prev_iq / dem history */
 		if (L.k1)
@@ -2063,6 +2105,8 @@ extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
 		}
 		/* on the device from the step array itself: no host data in flight, nothing to wait for */
 		HIP_TRY(wrk_seek(st, g->dev, (unsigned int)S, g->sp, g->parity, g->p2, frame));
+		if (g->l1 > WR_FIR_LENGTH)
+			HIP_TRY(hipMemsetAsync(g->dev.mixhist[g->sp], 0, (size_t)(g->l1 - 1) * S * 2 * sizeof(float), st));
 	}
 	for (Chan &c : t->chans)
 		if (c.in_use && c.group < 0) {

@@ -65,6 +65,10 @@ struct WrGroupDev {
 	float        *iq2_hist[2];  /* [63][slots][2] its history: the last 63 first-stage frames; ping-pong */
 	float        *chan_iq2[2];  /* [k1max / d1b][slots][2] its output = the demodulator's input */
 	/* receiver controls the reference only stubs (receiverhandler.cxx:112,118-119,127) */
+	/* a channel filter of MORE than 64 taps (128 or 256; the rate group is keyed by the length too): its taps
+	 * and, as LowPass::block does (lowpass.cxx:138-142), the last L - 1 MIXED frames of every channel */
+	float        *taps1L;       /* [L][slots] */
+	float        *mixhist[2];   /* [L - 1][slots][2], ping-pong with the state set */
 	float        *gain;         /* [slots] af_gain as a factor (1 = 0 dB) */
 	float        *squelch;      /* [slots] squelch threshold as a power (0 = open) */
 	float        *prev_iq[2];   /* [slots][2] Demodulator::prev_i/prev_q, ping-pong by block parity */
@@ -142,6 +146,10 @@ struct WrPostArgs {
 hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
                          int num_cus, const WrPostArgs *post = nullptr, bool *post_taken = nullptr);
+/* the same for a channel filter of `len` = 128 or 256 taps (k_tuner_ddc_long: the reference's arithmetic in every
+ * nco mode); also rolls the group's state (phase, mixed history) into the other set */
+hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
+                              const float *table_dev, int num_cus);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 /* second channel-filter stage: k1a first-stage frames of chan_iq[cb] -> k1a / d1b frames of chan_iq2[cb];
  * history from iq2_hist[p2], next history into iq2_hist[p2 ^ 1] */

@@ -1537,6 +1537,138 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 	TL(11);
 }
 
+/*
+ * k_tuner_ddc_long: DownConverter::process + a channel LowPass of MORE than 64 taps (LowPass::_firLength 128 or
+ * 256: dsp/lowpass.cxx:38-39 "FIXME: Make runtime variable", :102-110, :131-162) inside the tuner's launch
+ * sequence -- SURVEY 8f-4.  The fused kernels above are built around a 64-frame window; a longer filter is rare
+ * and takes this plain kernel instead, which still never materialises the full-rate mixer output and still mixes
+ * only the frames a tap reaches (L of every D1):
+ *
+ *   unit (k, lane group), one wave: y[k] = sum_{j < L} coeff[L-1-j] * block[k*D1 + j] in the reference's order
+ *   (oldest first, unfused), where block = [the last L-1 MIXED frames of the previous block | this block's
+ *   mixed frames] exactly as LowPass::block holds them (lowpass.cxx:138-142): frames of this block are mixed
+ *   on the fly with the reference's table and operations (downconverter.cxx:100-110), the older ones come from
+ *   `mixhist`, per channel -- so the result is bit-identical to the oracle's cascade in EVERY nco mode (the
+ *   fast recurrences are not used here), whatever setIF did in between.
+ *   The 64-frame pieces of the window go through LDS like the fused kernel's (lane j loads frame j).
+ * k_ddc_long_roll: the end-of-block state -- phase advanced by nframes steps, the last L-1 mixed frames.
+ */
+__global__ void __launch_bounds__(256)
+k_tuner_ddc_long(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes, size_t k1,
+                 unsigned int d1, unsigned int len, unsigned int slots, unsigned int groups,
+                 const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+                 const int *__restrict__ flags, const float *__restrict__ taps, const float2 *__restrict__ mixhist,
+                 const float *__restrict__ table, float2 *__restrict__ chan_iq)
+{
+	__shared__ v2f winl[4][64];
+	const unsigned int lane = threadIdx.x & 63u;
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const size_t units = k1 * groups;
+	const unsigned int hl = len - 1u;                    /* history frames per channel */
+	for (size_t u = (size_t)blockIdx.x * 4u + wave; u < units; u += (size_t)gridDim.x * 4u) {
+		const unsigned int g = (unsigned int)(u % groups);
+		const size_t k = u / groups;
+		const unsigned int s = g * 64u + lane;
+		const unsigned int p0 = phase[s], st = step[s];
+		const bool active = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
+		v2f acc = {0.0f, 0.0f};
+		for (unsigned int seg = 0; seg < len / 64u; ++seg) {
+			const long long n0 = (long long)k * d1 - (long long)hl + 64ll * seg;    /* frame of this piece's first tap */
+			const long long nl = n0 + lane;
+			float2 xf = make_float2(0.0f, 0.0f);
+			if (nl >= 0)
+				xf = input_frame(cur, cur_u8, (size_t)nl);
+			winl[wave][lane] = (v2f){xf.x, xf.y};            /* (one wave reads what it wrote: LDS is in order) */
+			for (unsigned int j = 0; j < 64u; ++j) {
+				const long long n = n0 + j;
+				const float hj = taps[(size_t)(len - 1u - (64u * seg + j)) * slots + s];
+				if (n >= 0) {
+					const v2f xs = winl[wave][j];
+					const v2f cs = nco<WR_NCO_EXACT>(p0 + (unsigned int)n * st, table, nullptr, nullptr);
+					mac<WR_NCO_EXACT>(xs, cs, hj, acc);
+				} else {
+					const float2 m = mixhist[(size_t)(hl + n) * slots + s];   /* the frame as it was mixed back then */
+					float ti, tq;
+					asm("v_mul_f32 %0, %1, %2" : "=v"(ti) : "v"(hj), "v"(m.x));
+					asm("v_mul_f32 %0, %1, %2" : "=v"(tq) : "v"(hj), "v"(m.y));
+					acc.x = acc.x + ti;
+					acc.y = acc.y + tq;
+				}
+			}
+		}
+		if (active)
+			chan_iq[k * slots + s] = make_float2(acc.x, acc.y);
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_ddc_long_roll(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes, unsigned int len,
+                unsigned int slots, const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+                const int *__restrict__ flags, unsigned int *__restrict__ phase_next,
+                const float2 *__restrict__ mixhist, float2 *__restrict__ mixhist_next, const float *__restrict__ table)
+{
+	const unsigned int hl = len - 1u;
+	const size_t total = (size_t)hl * slots;
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+		const unsigned int r = (unsigned int)(e / slots), s = (unsigned int)(e - (size_t)r * slots);
+		const bool active = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
+		const long long f = (long long)nframes - (long long)hl + r;         /* frame of this block, or of an earlier one */
+		float2 m = make_float2(0.0f, 0.0f);
+		if (active) {
+			if (f >= 0) {
+				const float2 x = input_frame(cur, cur_u8, (size_t)f);
+				const v2f cs = nco<WR_NCO_EXACT>(phase[s] + (unsigned int)f * step[s], table, nullptr, nullptr);
+				m = make_float2(x.x * cs.x + x.y * cs.y, x.y * cs.x - x.x * cs.y);  /* downconverter.cxx:109-110 */
+			} else {
+				m = mixhist[(size_t)(hl + f) * slots + s];                        /* a block shorter than the history */
+			}
+		}
+		mixhist_next[e] = m;
+		if (r == 0)
+			phase_next[s] = active ? phase[s] + (unsigned int)nframes * step[s] : phase[s];
+	}
+}
+
+hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
+                              const float *table_dev, int num_cus)
+{
+	if (!L.slots_used)
+		return hipSuccess;
+	const unsigned int groups = L.slots_used / 64u;
+	const size_t units = L.k1 * groups;
+	if (units) {
+		unsigned int wgs = (unsigned int)((units + 3) / 4);
+		const unsigned int cap = (unsigned int)num_cus * 8u;
+		if (wgs > cap)
+			wgs = cap;
+		if (L.ev_start && L.ev_stop)
+			/* profiling: the filter kernel's own start and end (the roll behind it is not in the bracket) */
+			hipExtLaunchKernelGGL(k_tuner_ddc_long, dim3(wgs), dim3(256), 0, st, (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
+			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, L.k1, L.d1, len, L.slots, groups,
+			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
+			                      (const float *)G.taps1L, (const float2 *)G.mixhist[L.sp], table_dev, (float2 *)G.chan_iq[L.cb]);
+		else
+			k_tuner_ddc_long<<<wgs, 256, 0, st>>>((const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, L.k1, L.d1, len,
+			                                      L.slots, groups, G.phase[L.sp], G.step, G.flags, G.taps1L,
+			                                      (const float2 *)G.mixhist[L.sp], table_dev, (float2 *)G.chan_iq[L.cb]);
+	}
+	const size_t total = (size_t)(len - 1u) * L.slots;
+	const unsigned int rwgs = (unsigned int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+	if (L.ev_start && L.ev_stop && !units) {
+		/* profiling a block too short for an output frame: the roll is all there is */
+		hipExtLaunchKernelGGL(k_ddc_long_roll, dim3(rwgs), dim3(256), 0, st, (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
+		                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, len, L.slots,
+		                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
+		                      G.phase[L.sp ^ 1], (const float2 *)G.mixhist[L.sp], (float2 *)G.mixhist[L.sp ^ 1], table_dev);
+		return hipGetLastError();
+	}
+	k_ddc_long_roll<<<rwgs, 256, 0, st>>>((const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes,
+	                                                            len, L.slots, G.phase[L.sp], G.step, G.flags, G.phase[L.sp ^ 1],
+	                                                            (const float2 *)G.mixhist[L.sp], (float2 *)G.mixhist[L.sp ^ 1],
+	                                                            table_dev);
+	return hipGetLastError();
+}
+
 /* Demodulator::process for every channel (dsp/demodulator.cxx:77-115): thread (k, s);
  * the previous channel-rate frame is row k-1, or prev_iq for k = 0.  The same launch
  * also finishes the block for every channel (what DspBlock::run leaves behind in the

@@ -109,7 +109,9 @@ class Tuner:
     def add_receiver(self, if_hz, chan_passband, chan_rate, mode, audio_passband, audio_rate, fir_lengths=None,
                      stage2=None):
         """Receiver() + setFrontEnd(): the wiring of radio.cxx:62-90 with explicit parameters.
-        fir_lengths: (channel, audio) LowPass::_firLength, powers of two up to 64 (default 64, 64).
+        fir_lengths: (channel, audio) LowPass::_firLength, powers of two: the channel filter up to 256
+        (WR_FIR_FUSED_MAX; above 64 the tuner runs it in the reference's own arithmetic whatever the nco mode),
+        the audio filter up to 64 (default 64, 64).
         stage2: (fir_length, passband, out_rate) of a second channel LowPass in front of the demodulator."""
         c = C.c_int()
         check(self.lib.wr_chan_add(self.h, C.byref(c)))
