@@ -225,6 +225,28 @@ __device__ __forceinline__ void nt_store2(float2 *p, float2 v)
 	__builtin_nontemporal_store((nt_v2f){v.x, v.y}, (nt_v2f *)p);
 }
 
+/* write-through (sc1) stores: data that the NEXT launch reads (pass 1's intermediate) or nothing on the chip reads again
+ * (the dB rows) leave the L2 as they are written, not at the end-of-kernel release.  r03, 121 frames on one box: pass 1
+ * 25.6 -> 23.8 us, pass 2 16.9 -> 16.5 us (profiles/r03_fft_pass1_ablation.txt, section 4; FFT_PLAIN_STORE restores the old) */
+__device__ __forceinline__ void wt_store2(float2 *p, float2 v)
+{
+#ifdef FFT_PLAIN_STORE
+	*p = v;
+#else
+	union { float2 f; unsigned long long u; } cv;
+	cv.f = v;
+	__hip_atomic_store((unsigned long long *)p, cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void wt_store1(float *p, float v)
+{
+#ifdef FFT_PLAIN_STORE
+	*p = v;
+#else
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 #define F256_S 272        /* LDS row stride (float2): 16 x 16 plus 16 -> conflict-free exchanges */
 
 /* pass 1: 16 adjacent columns n2 of one frame; thread (t = tid >> 4, c = tid & 15).
@@ -279,7 +301,7 @@ k_fft64k_pass1(const float2 *__restrict__ iq, size_t hop, const float *__restric
 #ifdef FFT_P1_NT_STORE
 		nt_store2(&wout[(blockIdx.x * 256u + k1) * 16u + c], cmul(v[kh], w));
 #else
-		wout[(blockIdx.x * 256u + k1) * 16u + c] = cmul(v[kh], w);
+		wt_store2(&wout[(blockIdx.x * 256u + k1) * 16u + c], cmul(v[kh], w));
 #endif
 	}
 }
@@ -331,7 +353,7 @@ k_fft64k_pass2(const float2 *__restrict__ work, const float2 *__restrict__ tw256
 #ifdef FFT_P2_NT
 				__builtin_nontemporal_store(to_db(v[kh], scaledb), &db[fbase + ((k + 32768u) & 65535u)]);
 #else
-				db[fbase + ((k + 32768u) & 65535u)] = to_db(v[kh], scaledb);
+				wt_store1(&db[fbase + ((k + 32768u) & 65535u)], to_db(v[kh], scaledb));
 #endif
 			}
 		}
