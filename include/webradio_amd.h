@@ -134,6 +134,10 @@ int wr_dev_host_register(wr_dev *dev, void *host, size_t bytes);
 int wr_dev_host_unregister(wr_dev *dev, void *host);
 int wr_dev_upload_async(wr_dev *dev, void *dst_dev, const void *src_host, size_t bytes);
 int wr_dev_wait_uploads(wr_dev *dev);  /* sync */
+/* The same, leaving the `newest` (0..3) most recent uploads in flight: for a source that alternates between two (or more)
+ * buffers -- it may refill buffer A as soon as everything but the upload out of buffer B has completed, and the host
+ * then runs a block ahead of the GPU instead of in step with it. */
+int wr_dev_wait_uploads_but(wr_dev *dev, unsigned int newest);
 
 /* ------------------------------------------- one kernel per reference block -- */
 /* DownConverter::process (dsp/downconverter.cxx:91-114).  Frame n uses phase
@@ -163,7 +167,12 @@ int wr_demod(wr_dev *dev, int mode, const float *in_dev, size_t nframes,
 int wr_u8_to_f32(wr_dev *dev, const uint8_t *in_dev, float *out_dev, size_t count);
 /* the same straight out of HOST memory page-locked with wr_dev_host_register: the kernel reads the bytes over
  * PCIe itself -- one launch instead of a copy and a launch, and a quarter of the float block's bytes.  Counts
- * as an upload in flight: the host buffer must not be rewritten until wr_dev_wait_uploads (or wr_dev_sync). */
+ * as an upload in flight: the host buffer must not be rewritten until wr_dev_wait_uploads (or wr_dev_sync).
+ * The conversion runs on a stream of the library's own and the device's stream waits for it, so work enqueued after
+ * the call sees `out_dev` filled -- and a caller that ALTERNATES between two `out_dev` buffers gets the transfer of
+ * block b + 1 beside the kernels of block b: the conversion waits only for the work that was enqueued before the call
+ * after the last one that wrote the same `out_dev` (rule for the caller: once the next block has been converted into
+ * the other buffer, enqueue no more readers of this one). */
 int wr_u8_to_f32_from_host(wr_dev *dev, const uint8_t *in_host_registered, float *out_dev, size_t count);
 
 /* ------------------------------------------------- fused per-tuner path -- */

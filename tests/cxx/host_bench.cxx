@@ -55,13 +55,15 @@ std::vector<uint8_t> g_bytes;
 class SynthU8Tuner : public Tuner, public RawU8Block {
 public:
 	SynthU8Tuner(const string &n) : Tuner(n, "SynthU8Tuner") {}
-	const uint8_t *rawU8(size_t *frames) const { if (frames) *frames = g_bytes.size() / 2; return g_bytes.data(); }
+	const uint8_t *rawU8(size_t *frames) const { if (frames) *frames = g_bytes.size() / 2; return buf[cur].data(); }
+	unsigned int rawU8Buffers() const { return 2; }        /* like FileTuner: blocks alternate between two buffers */
 protected:
-	bool init() { return true; }
+	bool init() { buf[0] = g_bytes; buf[1] = g_bytes; cur = 0; return true; }
 	void deinit() {}
 	bool process(const vector<sample_t> &, vector<sample_t> &out) {
 		if (out.size() != g_bytes.size())
 			return false;
+		cur ^= 1u;
 		const bool skip = consumersReadOnDevice();
 		if (!skip)
 			for (size_t n = 0; n < out.size(); n++)
@@ -69,6 +71,8 @@ protected:
 		setHostBlockValid(!skip);
 		return true;
 	}
+	std::vector<uint8_t> buf[2];
+	unsigned int cur;
 };
 Tuner *make_u8(const string &n) { return new SynthU8Tuner(n); }
 
@@ -134,8 +138,8 @@ int main(int argc, char **argv)
 		fprintf(stderr, "start failed\n");
 		return 1;
 	}
-	Radio::run();                                            /* warm-up (allocations, uploads) */
-	Radio::run();
+	for (int w = 0; w < 8; w++)                              /* warm-up (allocations, page locks, the clocks' ramp) */
+		Radio::run();
 	const double t0 = now();
 	for (unsigned int b = 0; b < blocks; b++)
 		Radio::run();

@@ -147,6 +147,40 @@ def test_u8_ingest(dev, oracle):
     dev.free(dout)
 
 
+def test_u8_ingest_from_page_locked_host_memory(dev, oracle):
+    """wr_u8_to_f32_from_host: the bytes cross PCIe on the library's own stream (DMA + conversion kernel) and the
+    device's stream waits for them.  Blocks alternate between two device buffers and two host buffers the way the host
+    runtime stages a RawU8Block source (gpubatch.cxx), one size that is not a multiple of 16, the same buffer twice in a
+    row; wr_dev_wait_uploads_but(1) lets the host refill one buffer while the other is in flight.  Every block is the
+    reference's (u8 - 128) / 128 bit for bit (rtlsdrtuner.cxx:106)."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 1_000_003
+    hosts = [np.zeros(n, np.uint8), np.zeros(n, np.uint8)]
+    for h in hosts:
+        capi.check(dev.lib.wr_dev_host_register(dev.h, capi.ptr(h), h.size))
+    douts = [dev.malloc(n * 4), dev.malloc(n * 4)]
+    try:
+        for b in range(7):
+            which = b & 1 if b != 4 else 1                       # block 4 reuses the buffers of block 3
+            capi.check(dev.lib.wr_dev_wait_uploads_but(dev.h, 0 if b == 4 else 1))
+            hosts[which][:] = rng.integers(0, 256, n, dtype=np.uint8)
+            count = n if b != 2 else 4096 + 48
+            capi.check(dev.lib.wr_u8_to_f32_from_host(dev.h, capi.ptr(hosts[which]), C.c_void_p(douts[which]), count))
+            got = dev.download(douts[which], count)             # on the device's stream: waits for the conversion
+            assert np.array_equal(got, oracle.u8_to_float(hosts[which][:count])), b
+        capi.check(dev.lib.wr_dev_wait_uploads(dev.h))
+        assert dev.lib.wr_dev_wait_uploads_but(dev.h, 4) == capi.WR_ERR_ARG
+        other = np.zeros(64, np.uint8)                           # not page-locked: refused, nothing enqueued
+        assert dev.lib.wr_u8_to_f32_from_host(dev.h, capi.ptr(other), C.c_void_p(douts[0]), 64) == capi.WR_ERR_ARG
+    finally:
+        dev.sync()
+        for h in hosts:
+            dev.lib.wr_dev_host_unregister(dev.h, capi.ptr(h))
+        for d in douts:
+            dev.free(d)
+
+
 def test_reference_blocks_chain_equals_oracle_receiver(dev, oracle):
     """mix -> fir -> demod -> fir with the per-block kernels == the oracle's Receiver."""
     from webradio_amd import synth

@@ -50,6 +50,8 @@ int wrc_fail(int code, const char *fmt, ...)
 
 /* ------------------------------------------------------------------ structs -- */
 
+#define WR_UPLOAD_RING 4
+
 struct wr_dev {
 	int device;
 	hipStream_t stream;
@@ -69,8 +71,20 @@ struct wr_dev {
 	 * else's kernel can land between a producer and its consumer, and nobody frees the buffer
 	 * under an enqueue in progress. */
 	std::mutex *scratch_lock;
-	hipEvent_t upload_done;    /* behind the last wr_dev_upload_async */
-	std::atomic<bool> upload_pending;   /* uploads and waits may come from different threads */
+	/* behind each of the last WR_UPLOAD_RING async uploads (wr_dev_upload_async, wr_u8_to_f32_from_host): upload number n
+	 * (from 1) owns event n % WR_UPLOAD_RING.  `uploads_issued` - `uploads_done` are possibly still in flight. */
+	hipEvent_t upload_ev[WR_UPLOAD_RING];
+	std::atomic<unsigned long long> uploads_issued, uploads_done;   /* uploads and waits may come from different threads */
+	std::mutex *upload_lock;
+	/* wr_u8_to_f32_from_host runs on a stream of its own so that a block's bytes cross PCIe while the block before it
+	 * is being worked on: up_tail[i] marks what the device's stream held when call i was made (the last readers of the
+	 * buffer the call AFTER it may overwrite), up_out[i] is the buffer call i wrote */
+	hipStream_t up_stream;
+	hipEvent_t up_tail[WR_UPLOAD_RING], up_done;
+	void *up_out[WR_UPLOAD_RING];
+	unsigned long long up_calls;
+	uint8_t *up_raw[2];         /* where the DMA engine puts the bytes of a block (alternating) before the conversion kernel */
+	size_t up_raw_cap[2];
 	std::map<void *, size_t> *registered;   /* host ranges THIS library page-locked (wr_dev_host_register), under scratch_lock */
 };
 #define SCRATCH_GUARD(d) std::lock_guard<std::mutex> scratch_guard_(*(d)->scratch_lock)
@@ -340,10 +354,12 @@ extern "C" int wr_dev_open(wr_dev **dev, int device_index, void *hip_stream)
 	d->turn_host = (float *)malloc(WR_TABLE_SIZE * sizeof(float));
 	d->scratch_lock = new (std::nothrow) std::mutex();
 	d->registered = new (std::nothrow) std::map<void *, size_t>();
-	if (!d->turn_host || !d->scratch_lock || !d->registered) {
+	d->upload_lock = new (std::nothrow) std::mutex();
+	if (!d->turn_host || !d->scratch_lock || !d->registered || !d->upload_lock) {
 		free(d->turn_host);
 		delete d->scratch_lock;
 		delete d->registered;
+		delete d->upload_lock;
 		delete d;
 		return fail(WR_ERR_NOMEM, "out of memory");
 	}
@@ -386,8 +402,21 @@ extern "C" int wr_dev_close(wr_dev *d)
 			(void)hipHostUnregister(r.first);
 	delete d->registered;
 	delete d->scratch_lock;
-	if (d->upload_done)
-		(void)hipEventDestroy(d->upload_done);
+	for (int i = 0; i < WR_UPLOAD_RING; ++i)
+		if (d->upload_ev[i])
+			(void)hipEventDestroy(d->upload_ev[i]);
+	delete d->upload_lock;
+	if (d->up_stream) {
+		(void)hipStreamSynchronize(d->up_stream);
+		(void)hipStreamDestroy(d->up_stream);
+	}
+	for (int i = 0; i < WR_UPLOAD_RING; ++i)
+		if (d->up_tail[i])
+			(void)hipEventDestroy(d->up_tail[i]);
+	if (d->up_done)
+		(void)hipEventDestroy(d->up_done);
+	(void)hipFree(d->up_raw[0]);
+	(void)hipFree(d->up_raw[1]);
 	if (d->own_stream)
 		(void)hipStreamDestroy(d->stream);
 	delete d;
@@ -493,32 +522,58 @@ extern "C" int wr_dev_host_unregister(wr_dev *d, void *host)
 
 /* Enqueue a host-to-device copy on the device's stream and return; the host buffer must stay
  * untouched until wr_dev_wait_uploads (or wr_dev_sync) returns. */
+/* marks "the upload just enqueued on the stream ends here"; the event it reuses belonged to the upload WR_UPLOAD_RING
+ * before it, which is waited for first if nobody has yet */
+static int upload_mark(wr_dev *d, hipStream_t st)
+{
+	std::lock_guard<std::mutex> g(*d->upload_lock);
+	const unsigned long long n = d->uploads_issued + 1;
+	hipEvent_t &ev = d->upload_ev[n % WR_UPLOAD_RING];
+	if (!ev)
+		HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	else if (n > WR_UPLOAD_RING && d->uploads_done < n - WR_UPLOAD_RING) {
+		HIP_TRY(hipEventSynchronize(ev));
+		d->uploads_done = n - WR_UPLOAD_RING;
+	}
+	HIP_TRY(hipEventRecord(ev, st));
+	d->uploads_issued = n;
+	return WR_OK;
+}
+
 extern "C" int wr_dev_upload_async(wr_dev *d, void *dst_dev, const void *src_host, size_t bytes)
 {
 	if (!d || (bytes && (!dst_dev || !src_host)))
 		return fail(WR_ERR_ARG, "wr_dev_upload_async: bad argument");
 	if (dev_bind(d))
 		return WR_ERR_HIP;
-	if (!d->upload_done)
-		HIP_TRY(hipEventCreateWithFlags(&d->upload_done, hipEventDisableTiming));
 	if (bytes)
 		HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, d->stream));
-	HIP_TRY(hipEventRecord(d->upload_done, d->stream));
-	d->upload_pending = true;
+	return upload_mark(d, d->stream);
+}
+
+extern "C" int wr_dev_wait_uploads_but(wr_dev *d, unsigned int newest)
+{
+	if (!d)
+		return fail(WR_ERR_ARG, "dev is NULL");
+	if (newest >= WR_UPLOAD_RING)
+		return fail(WR_ERR_ARG, "wr_dev_wait_uploads_but: at most %d uploads can be left in flight", WR_UPLOAD_RING - 1);
+	if (d->uploads_issued <= d->uploads_done + newest)
+		return WR_OK;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	std::lock_guard<std::mutex> g(*d->upload_lock);
+	const unsigned long long issued = d->uploads_issued;
+	if (issued <= d->uploads_done + newest)
+		return WR_OK;
+	const unsigned long long upto = issued - newest;       /* uploads 1..upto must have completed (stream order) */
+	HIP_TRY(hipEventSynchronize(d->upload_ev[upto % WR_UPLOAD_RING]));
+	d->uploads_done = upto;
 	return WR_OK;
 }
 
 extern "C" int wr_dev_wait_uploads(wr_dev *d)
 {
-	if (!d)
-		return fail(WR_ERR_ARG, "dev is NULL");
-	if (!d->upload_pending)
-		return WR_OK;
-	if (dev_bind(d))
-		return WR_ERR_HIP;
-	HIP_TRY(hipEventSynchronize(d->upload_done));
-	d->upload_pending = false;
-	return WR_OK;
+	return wr_dev_wait_uploads_but(d, 0);
 }
 
 extern "C" int wr_dev_download(wr_dev *d, void *dst_host, const void *src_dev, size_t bytes)
@@ -611,12 +666,53 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 		return fail(WR_ERR_ARG, "wr_u8_to_f32_from_host: the buffer is not page-locked (wr_dev_host_register): %s",
 		            hipGetErrorString(e));
 	}
-	if (!d->upload_done)
-		HIP_TRY(hipEventCreateWithFlags(&d->upload_done, hipEventDisableTiming));
-	HIP_TRY(wrk_u8_to_f32(d->stream, (const uint8_t *)mapped, out_dev, count));
-	HIP_TRY(hipEventRecord(d->upload_done, d->stream));
-	d->upload_pending = true;
-	return WR_OK;
+	/* On the upload stream, so that these bytes cross PCIe beside whatever the device's stream is doing with the block
+	 * before (8 MB take 170 us at 47 GB/s -- more than all the kernels of a C2 block together).  It may start as soon
+	 * as the last readers of `out_dev` are done: those were enqueued before the call that followed the last one to
+	 * write `out_dev` (a caller alternating between two buffers: before the previous call), or -- the same buffer
+	 * twice in a row, or one not seen lately -- by now.  The device's stream then waits for the conversion. */
+	if (!d->up_stream) {
+		int prio_low = 0, prio_high = 0;                     /* lowest priority: the kernels of the block before go first */
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+		HIP_TRY(hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_low));
+		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming));
+		for (int i = 0; i < WR_UPLOAD_RING; ++i)
+			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming));
+	}
+	const unsigned long long n = d->up_calls;
+	HIP_TRY(hipEventRecord(d->up_tail[n % WR_UPLOAD_RING], d->stream));
+	unsigned long long after = n;                      /* wait for the tail recorded by call `after` */
+	for (unsigned long long back = 1; back < WR_UPLOAD_RING && back <= n; ++back)
+		if (d->up_out[(n - back) % WR_UPLOAD_RING] == (void *)out_dev) {
+			after = n - back + 1;
+			break;
+		}
+	HIP_TRY(hipStreamWaitEvent(d->up_stream, d->up_tail[after % WR_UPLOAD_RING], 0));
+	d->up_out[n % WR_UPLOAD_RING] = (void *)out_dev;
+	d->up_calls = n + 1;
+	/* The bytes come over with the DMA engine and are converted out of device memory.  (r03 tried the kernel reading
+	 * host memory itself, WR_U8_ZEROCOPY=1: one launch and 47 GB/s -- but kernels running beside it take up to ten times
+	 * as long, k_tuner_post 14 -> 107 us, a 32 MB device copy 13 -> 146 us: its reads, microseconds each, sit in the
+	 * same L2 / fabric queues as everybody's HBM traffic.  A DMA copy does not go through them.) */
+	static const bool zerocopy = getenv("WR_U8_ZEROCOPY") && atoi(getenv("WR_U8_ZEROCOPY")) != 0;
+	if (zerocopy) {
+		HIP_TRY(wrk_u8_to_f32(d->up_stream, (const uint8_t *)mapped, out_dev, count));
+	} else {
+		const unsigned int rb = (unsigned int)(n & 1u);
+		if (d->up_raw_cap[rb] < count) {
+			HIP_TRY(hipStreamSynchronize(d->up_stream));
+			(void)hipFree(d->up_raw[rb]);
+			d->up_raw[rb] = nullptr;
+			d->up_raw_cap[rb] = 0;
+			HIP_TRY(hipMalloc((void **)&d->up_raw[rb], count));
+			d->up_raw_cap[rb] = count;
+		}
+		HIP_TRY(hipMemcpyAsync(d->up_raw[rb], in_host, count, hipMemcpyHostToDevice, d->up_stream));
+		HIP_TRY(wrk_u8_to_f32(d->up_stream, d->up_raw[rb], out_dev, count));
+	}
+	HIP_TRY(hipEventRecord(d->up_done, d->up_stream));
+	HIP_TRY(hipStreamWaitEvent(d->stream, d->up_done, 0));
+	return upload_mark(d, d->up_stream);
 }
 
 /* ------------------------------------------------------------------ tuner -- */

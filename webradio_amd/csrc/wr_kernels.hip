@@ -216,6 +216,42 @@ __global__ void k_u8_to_f32(const uint8_t *__restrict__ in, float *__restrict__ 
 		out[i] = ((float)in[i] - 128.0f) / 128.0f;
 }
 
+/* The same, 16 bytes per lane and four such loads in flight per lane: a wave asks for 1 KiB at a time.  `in` may be
+ * page-locked HOST memory read over PCIe (wr_u8_to_f32_from_host): with one byte per lane every wave-load was a 64-byte read
+ * request and the link ran at 29 GB/s (279 us for the 8 MB of a 4 M-frame block, r03 rocprofv3; 170 us = 47 GB/s now).
+ * PCIe-bound work needs few waves: the launch is kept to U8_X16_WGS workgroups (2 MB in flight), because a grid that fills
+ * the chip with waves parked on PCIe reads leaves no wave slots to the kernels of the block before, which run beside it on
+ * the device's own stream (a 32 MB device-to-device copy beside the full grid: 164 us instead of 13).
+ * `n16` = count / 16, both pointers 16-byte aligned. */
+#define U8_X16_WGS 128u
+__global__ void __launch_bounds__(256) k_u8_to_f32_x16(const uint4 *__restrict__ in, float4 *__restrict__ out, size_t n16)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n16; i0 += 4 * stride) {
+		uint4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (i0 + u * stride < n16)
+				v[u] = in[i0 + u * stride];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const size_t i = i0 + u * stride;
+			if (i >= n16)
+				break;
+			const unsigned int w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				float4 o;
+				o.x = ((float)(w[q] & 255u) - 128.0f) / 128.0f;
+				o.y = ((float)((w[q] >> 8) & 255u) - 128.0f) / 128.0f;
+				o.z = ((float)((w[q] >> 16) & 255u) - 128.0f) / 128.0f;
+				o.w = ((float)(w[q] >> 24) - 128.0f) / 128.0f;
+				out[4 * i + q] = o;
+			}
+		}
+	}
+}
+
 /* ------------------------------------------------------------------------- */
 /* tier 2: fused per-tuner path                                               */
 /* ------------------------------------------------------------------------- */
@@ -1919,7 +1955,16 @@ hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t c
 {
 	if (!count)
 		return hipSuccess;
-	k_u8_to_f32<<<grid_for(count, 256, 2048), 256, 0, st>>>(in, out, count);
+	size_t head = 0;
+	hipPointerAttribute_t pa;                           /* host memory read over PCIe: few workgroups (see k_u8_to_f32_x16) */
+	const bool zc = hipPointerGetAttributes(&pa, in) == hipSuccess && pa.type == hipMemoryTypeHost;
+	(void)hipGetLastError();
+	if ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0 && count >= 16) {
+		head = count & ~(size_t)15;
+		k_u8_to_f32_x16<<<grid_for(head / 16, 256, zc ? U8_X16_WGS : 2048u), 256, 0, st>>>((const uint4 *)in, (float4 *)out, head / 16);
+	}
+	if (head < count)
+		k_u8_to_f32<<<grid_for(count - head, 256, 2048), 256, 0, st>>>(in + head, out + head, count - head);
 	return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@
 #include "debug.h"
 
 FileTuner::FileTuner(const string &name)
-	: Tuner(name, "FileTuner"), _file(NULL), _loop(false), _played(0), _rawFrames(0)
+	: Tuner(name, "FileTuner"), _file(NULL), _loop(false), _played(0), _cur(0), _rawFrames(0)
 {
 	_name = "file";
 	_manufacturer = "webradio_amd";
@@ -48,17 +48,20 @@ void FileTuner::deinit()
 	if (_file)
 		fclose(_file);
 	_file = NULL;
-	vector<uint8_t>().swap(_raw);
+	vector<uint8_t>().swap(_raw[0]);
+	vector<uint8_t>().swap(_raw[1]);
 	_rawFrames = 0;
 }
 
 bool FileTuner::process(const vector<sample_t> &inBuffer, vector<sample_t> &outBuffer)
 {
 	const size_t want = outBuffer.size();           /* blockSize counts floats == bytes here */
-	_raw.resize(want);
+	_cur ^= 1u;                                      /* the other buffer: the last block's bytes may still be on their way */
+	vector<uint8_t> &raw = _raw[_cur];
+	raw.resize(want);
 	size_t got = 0;
 	while (got < want) {
-		size_t n = fread(_raw.data() + got, 1, want - got, _file);
+		size_t n = fread(raw.data() + got, 1, want - got, _file);
 		got += n;
 		if (got == want)
 			break;
@@ -75,7 +78,7 @@ bool FileTuner::process(const vector<sample_t> &inBuffer, vector<sample_t> &outB
 	const bool skip = consumersReadOnDevice() && !(nostage && atoi(nostage));
 	if (!skip)
 		for (size_t n = 0; n < want; n++)
-			outBuffer[n] = ((float)_raw[n] - 128.0) / 128.0;   /* rtlsdrtuner.cxx:106 */
+			outBuffer[n] = ((float)raw[n] - 128.0) / 128.0;   /* rtlsdrtuner.cxx:106 */
 	setHostBlockValid(!skip);
 	_rawFrames = want / 2;
 	_played += _rawFrames;
@@ -86,5 +89,5 @@ const uint8_t* FileTuner::rawU8(size_t *frames) const
 {
 	if (frames)
 		*frames = _rawFrames;
-	return _rawFrames ? _raw.data() : NULL;
+	return _rawFrames ? _raw[_cur].data() : NULL;
 }

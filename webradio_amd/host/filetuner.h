@@ -31,6 +31,11 @@ public:
 	virtual ~RawU8Block() {}
 	/* bytes of the block most recently produced (2 per frame), or NULL */
 	virtual const uint8_t* rawU8(size_t *frames) const = 0;
+	/* how many buffers the source alternates between: the bytes handed out for one block stay untouched until the
+	 * source starts producing the block `rawU8Buffers()` later.  With 2 or more the GPU runtime lets the source refill
+	 * one buffer while the transfer out of the other is still in flight (wr_dev_wait_uploads_but), so the host runs a
+	 * block ahead of the GPU; with 1 the source's run() waits for the block's transfer first. */
+	virtual unsigned int rawU8Buffers() const { return 1; }
 };
 
 class FileTuner : public Tuner, public RawU8Block
@@ -44,6 +49,7 @@ public:
 	unsigned long framesPlayed() const { return _played; }
 
 	const uint8_t* rawU8(size_t *frames) const;
+	unsigned int rawU8Buffers() const { return 2; }
 
 	static Tuner* factory(const string &name);
 
@@ -56,7 +62,8 @@ private:
 	FILE*			_file;
 	bool			_loop;
 	unsigned long	_played;
-	vector<uint8_t>	_raw;
+	vector<uint8_t>	_raw[2];		/* alternating: the GPU may still be reading the block before this one */
+	unsigned int	_cur;
 	size_t			_rawFrames;
 };
 

@@ -85,6 +85,9 @@ wr_dev *device(int index)
  * rtlsdrtuner.cxx:280), so they are page-locked once and the copy is a DMA nobody waits for */
 struct SourceStage {
 	DevBuf buf;
+	DevBuf buf2;                /* raw blocks converted out of page-locked memory alternate between `buf` and `buf2`: the
+	                               bytes of block b + 1 cross PCIe while block b is being worked on (wr_u8_to_f32_from_host) */
+	bool second;
 	DevBuf raw;                 /* the block as the source holds it in the RTL-SDR byte format (RawU8Block), on the device */
 	unsigned long epoch;
 	const void *host;
@@ -92,7 +95,9 @@ struct SourceStage {
 	wr_dev *dev;
 	struct Pinned { void *ptr; size_t bytes; };
 	std::vector<Pinned> pinned;
-	SourceStage() : epoch(0), host(NULL), floats(0), dev(NULL) {}
+	const float *cur;           /* the staged block: in `buf`, or `buf2` */
+	bool rawStaged;             /* the block now staged came from the source's raw bytes: its float vector was not read */
+	SourceStage() : second(false), epoch(0), host(NULL), floats(0), dev(NULL), cur(NULL), rawStaged(false) {}
 	~SourceStage() { unpin(); }
 	/* the page locks must go before the memory does: freed but still registered, it is handed out
 	 * again by the allocator and a later copy out of it fails ("invalid argument") */
@@ -151,8 +156,17 @@ static void beforeSourceStop(DspSource *src)
 static void beforeSourceRun(DspSource *src)
 {
 	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
-	if (st && st->dev)
-		wr_dev_wait_uploads(st->dev);
+	if (!st || !st->dev)
+		return;
+	/* a source that alternates between raw buffers (RawU8Block::rawU8Buffers) may refill one while the transfer out
+	 * of the other is still in flight: the host then runs a block ahead of the GPU instead of in step with it */
+	unsigned int inflight = 0;
+	if (st->rawStaged) {
+		const RawU8Block *raw = dynamic_cast<const RawU8Block *>(src);
+		const unsigned int nbuf = raw ? raw->rawU8Buffers() : 1u;
+		inflight = nbuf > 1u ? (nbuf - 1u > 3u ? 3u : nbuf - 1u) : 0u;
+	}
+	wr_dev_wait_uploads_but(st->dev, inflight);
 }
 
 wr_dev *deviceFor(const DspBlock *block)
@@ -212,23 +226,31 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 		if (rawBytes && rawFrames * 2 == host.size() && !envUnsigned("WEBRADIO_NO_U8_STAGING", 0)) {
 			const bool pinned = st->pin(dev, rawBytes, host.size());
 			/* page-locked: the conversion kernel reads the bytes over PCIe itself (one launch, nothing the host
-			 * waits for); else a staged copy and the kernel on the device copy */
-			if (!st->buf.reserve(dev, bytes) ||
-			    (pinned ? wr_u8_to_f32_from_host(dev, rawBytes, (float *)st->buf.ptr, host.size())
+			 * waits for), into the buffer the LAST block was not staged in; else a staged copy and the kernel on
+			 * the device copy */
+			if (pinned)
+				st->second = !st->second;
+			DevBuf &dst = (pinned && st->second) ? st->buf2 : st->buf;
+			if (!dst.reserve(dev, bytes) ||
+			    (pinned ? wr_u8_to_f32_from_host(dev, rawBytes, (float *)dst.ptr, host.size())
 			            : (!st->raw.reserve(dev, host.size()) ||
 			               wr_dev_upload(dev, st->raw.ptr, rawBytes, host.size()) != WR_OK)
 			                  ? WR_ERR_HIP
-			                  : wr_u8_to_f32(dev, (const uint8_t *)st->raw.ptr, (float *)st->buf.ptr, host.size())) != WR_OK) {
+			                  : wr_u8_to_f32(dev, (const uint8_t *)st->raw.ptr, (float *)dst.ptr, host.size())) != WR_OK) {
 				LOG_ERROR("staging the source block (byte format) failed: %s\n", wr_last_error());
 				return NULL;
 			}
 			st->epoch = src->epoch();
 			st->host = host.data();
 			st->floats = host.size();
+			st->rawStaged = pinned;
+			st->cur = (const float *)dst.ptr;
 			if (dev_out)
 				*dev_out = dev;
-			return (const float *)st->buf.ptr;
+			return st->cur;
 		}
+		st->rawStaged = false;
+		st->cur = NULL;
 		/* out of page-locked memory the copy is enqueued and the graph walk goes on beside it; the
 		 * source's next run() waits for it before it touches the vector again (beforeSourceRun) */
 		const bool pinned = st->pin(dev, host.data(), bytes);
@@ -241,10 +263,11 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 		st->epoch = src->epoch();
 		st->host = host.data();
 		st->floats = host.size();
+		st->cur = (const float *)st->buf.ptr;
 	}
 	if (dev_out)
 		*dev_out = dev;
-	return (const float *)st->buf.ptr;
+	return st->cur;
 }
 
 bool hostBlockValid(const DspBlock *block)
