@@ -14,7 +14,7 @@ timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${round
 timeout 300 python bench.py --workload c5 --steps 30 --warmup 4 > $O/${round}_c5_1gpu.json 2> /dev/null
 timeout 300 python bench.py --workload c5 --halo ring --steps 30 --warmup 4 > $O/${round}_c5_1gpu_ring.json 2> /dev/null
 ( for src in f32 u8; do for late in 0 1 2; do
-    WEBRADIO_AUDIO_LATE=$late WR_HOST_BENCH_PROFILE=1 timeout 200 tests/cxx/host_bench 256 30 4000000 $src
+    WEBRADIO_AUDIO_LATE=$late WR_HOST_BENCH_PROFILE=1 timeout 200 tests/cxx/host_bench 256 300 4000000 $src
   done; done ) 2>&1 | grep -E "^\{|^process\(\)" > $O/${round}_host_bench.txt
 ( echo "== QT_ONE_ODD=1"; QT_ONE_ODD=1 QT_REPS=1600 QT_BLOCKS=12 QT_PROFILE=0 timeout 200 bash tools/kstats.sh python $R/tools/quick_time.py 256 rotate
   echo "== QT_MIXED=1";   QT_MIXED=1 QT_REPS=1600 QT_BLOCKS=12 QT_PROFILE=0 timeout 200 bash tools/kstats.sh python $R/tools/quick_time.py 256 rotate ) > $O/${round}_mixed_passbands.txt 2>&1

@@ -27,7 +27,8 @@ for name in which:
         odd = os.environ.get("QT_ONE_ODD") == "1" and i == 70       # one receiver with its own passband
         t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0) + (3_000_000 if odd else 0),
                        c2["chan_rate"], capi.WR_FM,
-                       c2["audio_passband"], c2["audio_rate"])
+                       c2["audio_passband"], c2["audio_rate"],
+                       fir_lengths=(int(os.environ["QT_L1"]), 64) if os.environ.get("QT_L1") else None)   # 128 / 256: k_tuner_ddc_long
     for i in range(4):
         t.submit_device(blocks[i % nb], n)
     torch.cuda.synchronize()
