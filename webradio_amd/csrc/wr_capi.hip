@@ -2219,6 +2219,7 @@ static void plan_free(WrFftPlan &p)
 	(void)hipFree(p.tw_n);
 	(void)hipFree(p.tw_sub);
 	(void)hipFree(p.window);
+	(void)hipFree(p.window_p1);
 	(void)hipFree(p.work);
 	memset(&p, 0, sizeof(p));
 }
@@ -2278,6 +2279,18 @@ extern "C" int wr_spectrum_create(wr_spectrum **spec, wr_dev *dev, unsigned int 
 		if ((e = hipMalloc((void **)&s->bins, (size_t)fft_size * 2 * sizeof(float))) != hipSuccess) break;
 		if ((e = hipMemcpy(p.tw_n, tw.data(), fft_size * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
 		if ((e = hipMemcpy(p.window, win.data(), fft_size * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		if (p.n1 == 256 && p.n2 == 256) {
+			/* pass 1's thread (t, c) of column tile T multiplies rows a*16 + t, a = 0..15, of column T*16 + c: stored as
+			 * [T][a / 4][thread][a % 4], a thread takes its 16 values with four 16-byte loads that are contiguous across
+			 * the threads of a wave (they were 16 four-byte loads in 64-byte runs: as many memory instructions as the samples) */
+			std::vector<float> wp(fft_size);
+			for (unsigned int T = 0; T < 16; ++T)
+				for (unsigned int tid = 0; tid < 256; ++tid)
+					for (unsigned int a = 0; a < 16; ++a)
+						wp[((T * 4 + a / 4) * 256 + tid) * 4 + a % 4] = win[(a * 16 + (tid >> 4)) * 256 + T * 16 + (tid & 15)];
+			if ((e = hipMalloc((void **)&p.window_p1, fft_size * sizeof(float))) != hipSuccess) break;
+			if ((e = hipMemcpy(p.window_p1, wp.data(), fft_size * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		}
 		if (sub && (e = hipMemcpy(p.tw_sub, tws.data(), sub * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
 	} while (0);
 	if (e != hipSuccess) {

@@ -22,6 +22,8 @@
  */
 #include "wr_internal.h"
 
+#include <cstdlib>
+
 #define FFT_THREADS 256
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w)
@@ -249,11 +251,18 @@ __device__ __forceinline__ void wt_store1(float *p, float v)
 
 #define F256_S 272        /* LDS row stride (float2): 16 x 16 plus 16 -> conflict-free exchanges */
 
-/* pass 1: 16 adjacent columns n2 of one frame; thread (t = tid >> 4, c = tid & 15).
- * grid = (16, frames).  work[k1][n2] = W_65536^(n2*k1) * sum_n1 w[n]x[n] W_256^(n1*k1). */
+/* pass 1: 16 adjacent columns n2 of FPW consecutive frames; thread (t = tid >> 4, c = tid & 15).
+ * grid = (16, ceil(frames / FPW)).  work[k1][n2] = W_65536^(n2*k1) * sum_n1 w[n]x[n] W_256^(n1*k1).
+ * FPW = 1: one frame per workgroup (small batches: the launch must fill the chip).  FPW = 4 (batches from
+ * FFT64K_P1_LONG_MIN frames on): the window values a thread needs are the same 16 for every frame and stay in registers, as do
+ * the two twiddle tables in LDS; the next frame's loads are issued before this frame's arithmetic; and at the reference's own
+ * hop of half a frame, rows 128..255 of a frame are rows 0..127 of the next -- this thread already holds them.
+ * (r03, 121 frames on one box: 25.0 -> 23.0 us; profiles/r03_fft_pass1_ablation.txt section 5.) */
+template <unsigned int FPW>
 __global__ void __launch_bounds__(256)
 k_fft64k_pass1(const float2 *__restrict__ iq, size_t hop, const float *__restrict__ window,
-               const float2 *__restrict__ tw256, const float2 *__restrict__ tw_n, float2 *__restrict__ work)
+               const float *__restrict__ window_p1, const float2 *__restrict__ tw256, const float2 *__restrict__ tw_n, float2 *__restrict__ work,
+               unsigned int frames)
 {
 	__shared__ float2 ex[16 * F256_S];
 	/* Twiddles from two 256-entry tables in LDS, W_65536^m = W_256^(m >> 8) * W_65536^(m & 255): the
@@ -265,44 +274,73 @@ k_fft64k_pass1(const float2 *__restrict__ iq, size_t hop, const float *__restric
 	tlo[threadIdx.x] = tw_n[threadIdx.x];
 	const unsigned int c = threadIdx.x & 15u, t = threadIdx.x >> 4;
 	const unsigned int col = blockIdx.x * 16u + c;
-	const float2 *x = iq + (size_t)blockIdx.y * hop;
-	float2 v[16];
+	const unsigned int f0 = blockIdx.y * FPW;
+	float wv[16];
+	float2 nx[16];                                         /* the frame about to be transformed, as loaded */
+	{
+		const float2 *x = iq + (size_t)f0 * hop;
 #pragma unroll
-	for (int a = 0; a < 16; ++a) {
-		const unsigned int idx = (a * 16u + t) * 256u + col;
-#ifdef FFT_P1_NT_LOAD
-		const float2 s = nt_load2(&x[idx]);
+		for (int a = 0; a < 16; ++a)
+			nx[a] = x[(a * 16u + t) * 256u + col];
+#ifdef FFT_P1_PLAIN_WINDOW
+#pragma unroll
+		for (int a = 0; a < 16; ++a)
+			wv[a] = window[(a * 16u + t) * 256u + col];
 #else
-		const float2 s = x[idx];
+		const float4 *wp = (const float4 *)window_p1 + (size_t)blockIdx.x * 1024u + threadIdx.x;   /* [tile][a / 4][thread] */
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const float4 w4 = wp[q * 256u];
+			wv[4 * q] = w4.x, wv[4 * q + 1] = w4.y, wv[4 * q + 2] = w4.z, wv[4 * q + 3] = w4.w;
+		}
 #endif
-		const float w = window[idx];
-		v[a] = make_float2(s.x * w, s.y * w);          /* spectrumsink.cxx:109-112 */
 	}
-	fft16(v);                                          /* over a: k = 0..15, for n1 = a*16 + t */
-	__syncthreads();                                   /* the tables */
+#pragma unroll 1
+	for (unsigned int fi = 0; fi < FPW; ++fi) {
+		const unsigned int f = f0 + fi;
+		if (f >= frames)
+			break;
+		float2 v[16];
 #pragma unroll
-	for (int k = 0; k < 16; ++k) {
-		const float2 w = thi[(t * k) & 255u];          /* W_256^(t*k) */
-		ex[k * F256_S + t * 16u + c] = (k == 0) ? v[k] : cmul(v[k], w);
-	}
-	__syncthreads();
+		for (int a = 0; a < 16; ++a)
+			v[a] = make_float2(nx[a].x * wv[a], nx[a].y * wv[a]);          /* spectrumsink.cxx:109-112 */
+		if (FPW > 1 && fi + 1 < FPW && f + 1 < frames) {
+			const float2 *xn = iq + (size_t)(f + 1) * hop;
+			if (hop == 32768u) {
 #pragma unroll
-	for (int b = 0; b < 16; ++b)
-		v[b] = ex[t * F256_S + b * 16u + c];           /* this thread now owns k_low = t */
-	fft16(v);                                          /* over b: k1 = t + 16*k_high */
-	float2 *wout = work + (size_t)blockIdx.y * 65536u;
+				for (int a = 0; a < 8; ++a)
+					nx[a] = nx[a + 8];
 #pragma unroll
-	for (int kh = 0; kh < 16; ++kh) {
-		const unsigned int k1 = t + 16u * kh;
-		const unsigned int m = col * k1;               /* < 65536 */
-		const float2 w = cmul(thi[m >> 8], tlo[m & 255u]);
-		/* intermediate laid out [column tile][k1][16]: this workgroup's 32 KiB are one contiguous run,
-		 * and a pass-2 workgroup (16 rows k1) reads 2 KiB runs from each of the 16 tiles */
-#ifdef FFT_P1_NT_STORE
-		nt_store2(&wout[(blockIdx.x * 256u + k1) * 16u + c], cmul(v[kh], w));
-#else
-		wt_store2(&wout[(blockIdx.x * 256u + k1) * 16u + c], cmul(v[kh], w));
-#endif
+				for (int a = 8; a < 16; ++a)
+					nx[a] = xn[(a * 16u + t) * 256u + col];
+			} else {
+#pragma unroll
+				for (int a = 0; a < 16; ++a)
+					nx[a] = xn[(a * 16u + t) * 256u + col];
+			}
+		}
+		fft16(v);                                          /* over a: k = 0..15, for n1 = a*16 + t */
+		__syncthreads();                                   /* the tables; the frame before's reads of `ex` */
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			const float2 w = thi[(t * k) & 255u];          /* W_256^(t*k) */
+			ex[k * F256_S + t * 16u + c] = (k == 0) ? v[k] : cmul(v[k], w);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int b = 0; b < 16; ++b)
+			v[b] = ex[t * F256_S + b * 16u + c];           /* this thread now owns k_low = t */
+		fft16(v);                                          /* over b: k1 = t + 16*k_high */
+		float2 *wout = work + (size_t)f * 65536u;
+#pragma unroll
+		for (int kh = 0; kh < 16; ++kh) {
+			const unsigned int k1 = t + 16u * kh;
+			const unsigned int m = col * k1;               /* < 65536 */
+			const float2 w = cmul(thi[m >> 8], tlo[m & 255u]);
+			/* intermediate laid out [column tile][k1][16]: this workgroup's 32 KiB are one contiguous run,
+			 * and a pass-2 workgroup (16 rows k1) reads 2 KiB runs from each of the 16 tiles */
+			wt_store2(&wout[(blockIdx.x * 256u + k1) * 16u + c], cmul(v[kh], w));
+		}
 	}
 }
 
@@ -414,6 +452,20 @@ hipError_t wrk_bins_to_db(hipStream_t st, const float *bins, unsigned int n, flo
 	return hipGetLastError();
 }
 
+/* batches of the 65536-point path from this many frames on take four frames per pass-1 workgroup (>= 384 workgroups) */
+#define FFT64K_P1_LONG_MIN 96u
+static int fft64k_p1_fpw(size_t batch)
+{
+	static int forced = -1;
+	if (forced < 0) {
+		const char *v = getenv("WR_FFT_P1_FPW");           /* 1, 2, 4: frames per pass-1 workgroup whatever the batch */
+		forced = v ? atoi(v) : 0;
+	}
+	if (forced == 1 || forced == 2 || forced == 4)
+		return forced;
+	return batch >= FFT64K_P1_LONG_MIN ? 4 : 1;
+}
+
 hipError_t wrk_fft_frames(hipStream_t st, const WrFftPlan &P, const float *iq, size_t hop,
                           size_t nframes_fft, float *bins_out, float *db_out)
 {
@@ -441,8 +493,19 @@ hipError_t wrk_fft_frames(hipStream_t st, const WrFftPlan &P, const float *iq, s
 			if (batch > P.work_frames)
 				batch = P.work_frames;
 			dim3 grid(16, (unsigned int)batch);
-			k_fft64k_pass1<<<grid, 256, 0, st>>>((const float2 *)(iq + 2 * done * hop), hop, P.window,
-			                                     (const float2 *)P.tw_sub, (const float2 *)P.tw_n, (float2 *)P.work);
+			const int fpw = fft64k_p1_fpw(batch);
+			if (fpw == 2)
+				k_fft64k_pass1<2u><<<dim3(16, (unsigned int)((batch + 1) / 2)), 256, 0, st>>>(
+					(const float2 *)(iq + 2 * done * hop), hop, P.window, P.window_p1, (const float2 *)P.tw_sub, (const float2 *)P.tw_n,
+					(float2 *)P.work, (unsigned int)batch);
+			else if (fpw == 4)
+				k_fft64k_pass1<4u><<<dim3(16, (unsigned int)((batch + 3) / 4)), 256, 0, st>>>(
+					(const float2 *)(iq + 2 * done * hop), hop, P.window, P.window_p1, (const float2 *)P.tw_sub, (const float2 *)P.tw_n,
+					(float2 *)P.work, (unsigned int)batch);
+			else
+				k_fft64k_pass1<1u><<<grid, 256, 0, st>>>((const float2 *)(iq + 2 * done * hop), hop, P.window, P.window_p1,
+				                                         (const float2 *)P.tw_sub, (const float2 *)P.tw_n, (float2 *)P.work,
+				                                         (unsigned int)batch);
 			k_fft64k_pass2<<<grid, 256, 0, st>>>(
 				(const float2 *)P.work, (const float2 *)P.tw_sub,
 				bins_out ? (float2 *)(bins_out + 2 * done * P.n) : (float2 *)nullptr,

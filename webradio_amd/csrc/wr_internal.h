@@ -174,6 +174,7 @@ struct WrFftPlan {
 	float *tw_n;                /* [n/2][2] twiddles of the full size (device) */
 	float *tw_sub;              /* [max(n1,n2)/2][2] twiddles of the LDS sub-transforms (device) */
 	float *window;              /* [n] (device) */
+	float *window_p1;           /* 65536-point path: the window in the order pass 1's threads take it (wr_fft.hip), else NULL */
 	float *work;                /* [n][2] intermediate per frame in flight (device), batch-sized */
 	size_t work_frames;
 };
