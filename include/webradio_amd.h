@@ -138,6 +138,13 @@ int wr_dev_wait_uploads(wr_dev *dev);  /* sync */
  * buffers -- it may refill buffer A as soon as everything but the upload out of buffer B has completed, and the host
  * then runs a block ahead of the GPU instead of in step with it. */
 int wr_dev_wait_uploads_but(wr_dev *dev, unsigned int newest);
+/* wr_dev_upload_async on the library's own upload stream: the copy runs beside what the device's stream is doing, and the
+ * device's stream waits for it, so work enqueued after the call sees `dst_dev` filled.  A caller that ALTERNATES between two
+ * `dst_dev` buffers gets the transfer of block b + 1 beside the kernels of block b: the copy waits only for the work that was
+ * enqueued before the call after the last one that wrote the same `dst_dev` (rule for the caller: once the next block has been
+ * uploaded into the other buffer, enqueue no more readers of this one).  `src_host` page-locked (wr_dev_host_register) for
+ * the copy to be a DMA nobody waits for; counts as an upload in flight like wr_dev_upload_async. */
+int wr_dev_upload_ahead(wr_dev *dev, void *dst_dev, const void *src_host, size_t bytes);
 
 /* ------------------------------------------- one kernel per reference block -- */
 /* DownConverter::process (dsp/downconverter.cxx:91-114).  Frame n uses phase

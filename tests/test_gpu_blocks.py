@@ -181,6 +181,35 @@ def test_u8_ingest_from_page_locked_host_memory(dev, oracle):
             dev.free(d)
 
 
+def test_upload_ahead_alternating_buffers(dev):
+    """wr_dev_upload_ahead: the copy runs on the library's upload stream and the device's stream waits for it.  Blocks
+    alternate between two device buffers (what the host runtime does with a float source's block vector), each is read
+    back on the device's stream before the next call, the same buffer twice in a row works too."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 300_001
+    hosts = [np.zeros(n, np.float32), np.zeros(n, np.float32)]
+    for h in hosts:
+        capi.check(dev.lib.wr_dev_host_register(dev.h, capi.ptr(h), h.nbytes))
+    douts = [dev.malloc(n * 4), dev.malloc(n * 4)]
+    try:
+        for b in range(8):
+            which = b & 1 if b != 5 else 0
+            capi.check(dev.lib.wr_dev_wait_uploads(dev.h))       # a float source refills the vector it swapped out at once
+            hosts[which][:] = rng.standard_normal(n).astype(np.float32)
+            capi.check(dev.lib.wr_dev_upload_ahead(dev.h, C.c_void_p(douts[which]), capi.ptr(hosts[which]), hosts[which].nbytes))
+            got = dev.download(douts[which], n)
+            assert np.array_equal(got.view(np.uint32), hosts[which].view(np.uint32)), b
+        assert dev.lib.wr_dev_upload_ahead(dev.h, None, capi.ptr(hosts[0]), 16) == capi.WR_ERR_ARG
+    finally:
+        dev.sync()
+        capi.check(dev.lib.wr_dev_wait_uploads(dev.h))
+        for h in hosts:
+            dev.lib.wr_dev_host_unregister(dev.h, capi.ptr(h))
+        for d in douts:
+            dev.free(d)
+
+
 def test_reference_blocks_chain_equals_oracle_receiver(dev, oracle):
     """mix -> fir -> demod -> fir with the per-block kernels == the oracle's Receiver."""
     from webradio_amd import synth

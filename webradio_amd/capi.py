@@ -48,6 +48,7 @@ SIGNATURES = {
     "wr_dev_upload_async": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wr_dev_wait_uploads": (C.c_int, [_vp]),
     "wr_dev_wait_uploads_but": (C.c_int, [_vp, C.c_uint]),
+    "wr_dev_upload_ahead": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wr_mix": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_u32), C.c_int]),
     "wr_fir_decimate": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _vp, _vp]),
     "wr_fir_decimate_n": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp]),

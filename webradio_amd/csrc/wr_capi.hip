@@ -524,9 +524,8 @@ extern "C" int wr_dev_host_unregister(wr_dev *d, void *host)
  * untouched until wr_dev_wait_uploads (or wr_dev_sync) returns. */
 /* marks "the upload just enqueued on the stream ends here"; the event it reuses belonged to the upload WR_UPLOAD_RING
  * before it, which is waited for first if nobody has yet */
-static int upload_mark(wr_dev *d, hipStream_t st)
+static int upload_mark_locked(wr_dev *d, hipStream_t st)
 {
-	std::lock_guard<std::mutex> g(*d->upload_lock);
 	const unsigned long long n = d->uploads_issued + 1;
 	hipEvent_t &ev = d->upload_ev[n % WR_UPLOAD_RING];
 	if (!ev)
@@ -538,6 +537,12 @@ static int upload_mark(wr_dev *d, hipStream_t st)
 	HIP_TRY(hipEventRecord(ev, st));
 	d->uploads_issued = n;
 	return WR_OK;
+}
+
+static int upload_mark(wr_dev *d, hipStream_t st)
+{
+	std::lock_guard<std::mutex> g(*d->upload_lock);
+	return upload_mark_locked(d, st);
 }
 
 extern "C" int wr_dev_upload_async(wr_dev *d, void *dst_dev, const void *src_host, size_t bytes)
@@ -653,6 +658,59 @@ extern "C" int wr_u8_to_f32(wr_dev *d, const uint8_t *in_dev, float *out_dev, si
 	return WR_OK;
 }
 
+/* The upload stream (wr_dev_upload_ahead, wr_u8_to_f32_from_host): a block crosses PCIe beside whatever the device's stream
+ * is doing with the block before (8 MB take 150 us at 55 GB/s -- more than all the kernels of a C2 block together).
+ * upload_ahead_begin makes the upload stream wait for the last readers of `out_dev`: those were enqueued before the call
+ * that followed the last one to write `out_dev` (a caller alternating between two buffers: before the previous call), or --
+ * the same buffer twice in a row, or one not seen lately -- by now.  upload_ahead_end makes the device's stream wait for
+ * what was put on the upload stream in between and marks the upload (wr_dev_wait_uploads).  Under d->upload_lock. */
+static int upload_ahead_begin(wr_dev *d, void *out_dev, unsigned long long *call)
+{
+	if (!d->up_stream) {
+		int prio_low = 0, prio_high = 0;                     /* lowest priority: the kernels of the block before go first */
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+		HIP_TRY(hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_low));
+		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming));
+		for (int i = 0; i < WR_UPLOAD_RING; ++i)
+			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming));
+	}
+	const unsigned long long n = d->up_calls;
+	HIP_TRY(hipEventRecord(d->up_tail[n % WR_UPLOAD_RING], d->stream));
+	unsigned long long after = n;                      /* wait for the tail recorded by call `after` */
+	for (unsigned long long back = 1; back < WR_UPLOAD_RING && back <= n; ++back)
+		if (d->up_out[(n - back) % WR_UPLOAD_RING] == out_dev) {
+			after = n - back + 1;
+			break;
+		}
+	HIP_TRY(hipStreamWaitEvent(d->up_stream, d->up_tail[after % WR_UPLOAD_RING], 0));
+	d->up_out[n % WR_UPLOAD_RING] = out_dev;
+	d->up_calls = n + 1;
+	*call = n;
+	return WR_OK;
+}
+
+static int upload_ahead_end(wr_dev *d)
+{
+	HIP_TRY(hipEventRecord(d->up_done, d->up_stream));
+	HIP_TRY(hipStreamWaitEvent(d->stream, d->up_done, 0));
+	return upload_mark_locked(d, d->up_stream);
+}
+
+extern "C" int wr_dev_upload_ahead(wr_dev *d, void *dst_dev, const void *src_host, size_t bytes)
+{
+	if (!d || (bytes && (!dst_dev || !src_host)))
+		return fail(WR_ERR_ARG, "wr_dev_upload_ahead: bad argument");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	std::lock_guard<std::mutex> up_guard(*d->upload_lock);
+	unsigned long long n = 0;
+	if (int rc = upload_ahead_begin(d, dst_dev, &n))
+		return rc;
+	if (bytes)
+		HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, d->up_stream));
+	return upload_ahead_end(d);
+}
+
 extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *out_dev, size_t count)
 {
 	if (!d || (count && (!in_host || !out_dev)))
@@ -666,30 +724,10 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 		return fail(WR_ERR_ARG, "wr_u8_to_f32_from_host: the buffer is not page-locked (wr_dev_host_register): %s",
 		            hipGetErrorString(e));
 	}
-	/* On the upload stream, so that these bytes cross PCIe beside whatever the device's stream is doing with the block
-	 * before (8 MB take 170 us at 47 GB/s -- more than all the kernels of a C2 block together).  It may start as soon
-	 * as the last readers of `out_dev` are done: those were enqueued before the call that followed the last one to
-	 * write `out_dev` (a caller alternating between two buffers: before the previous call), or -- the same buffer
-	 * twice in a row, or one not seen lately -- by now.  The device's stream then waits for the conversion. */
-	if (!d->up_stream) {
-		int prio_low = 0, prio_high = 0;                     /* lowest priority: the kernels of the block before go first */
-		HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-		HIP_TRY(hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_low));
-		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming));
-		for (int i = 0; i < WR_UPLOAD_RING; ++i)
-			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming));
-	}
-	const unsigned long long n = d->up_calls;
-	HIP_TRY(hipEventRecord(d->up_tail[n % WR_UPLOAD_RING], d->stream));
-	unsigned long long after = n;                      /* wait for the tail recorded by call `after` */
-	for (unsigned long long back = 1; back < WR_UPLOAD_RING && back <= n; ++back)
-		if (d->up_out[(n - back) % WR_UPLOAD_RING] == (void *)out_dev) {
-			after = n - back + 1;
-			break;
-		}
-	HIP_TRY(hipStreamWaitEvent(d->up_stream, d->up_tail[after % WR_UPLOAD_RING], 0));
-	d->up_out[n % WR_UPLOAD_RING] = (void *)out_dev;
-	d->up_calls = n + 1;
+	std::lock_guard<std::mutex> up_guard(*d->upload_lock);         /* the ring of tails: calls may come from several threads */
+	unsigned long long n = 0;
+	if (int rc = upload_ahead_begin(d, (void *)out_dev, &n))
+		return rc;
 	/* The bytes come over with the DMA engine and are converted out of device memory.  (r03 tried the kernel reading
 	 * host memory itself, WR_U8_ZEROCOPY=1: one launch and 47 GB/s -- but kernels running beside it take up to ten times
 	 * as long, k_tuner_post 14 -> 107 us, a 32 MB device copy 13 -> 146 us: its reads, microseconds each, sit in the
@@ -710,9 +748,7 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 		HIP_TRY(hipMemcpyAsync(d->up_raw[rb], in_host, count, hipMemcpyHostToDevice, d->up_stream));
 		HIP_TRY(wrk_u8_to_f32(d->up_stream, d->up_raw[rb], out_dev, count));
 	}
-	HIP_TRY(hipEventRecord(d->up_done, d->up_stream));
-	HIP_TRY(hipStreamWaitEvent(d->stream, d->up_done, 0));
-	return upload_mark(d, d->up_stream);
+	return upload_ahead_end(d);
 }
 
 /* ------------------------------------------------------------------ tuner -- */

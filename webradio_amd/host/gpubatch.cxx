@@ -254,16 +254,22 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 		/* out of page-locked memory the copy is enqueued and the graph walk goes on beside it; the
 		 * source's next run() waits for it before it touches the vector again (beforeSourceRun) */
 		const bool pinned = st->pin(dev, host.data(), bytes);
-		if (!st->buf.reserve(dev, bytes) ||
-		    (pinned ? wr_dev_upload_async(dev, st->buf.ptr, host.data(), bytes)
-		            : wr_dev_upload(dev, st->buf.ptr, host.data(), bytes)) != WR_OK) {
+		/* page-locked: on the upload stream, into the device copy the LAST block was not staged in -- the 32 MB of block
+		 * b + 1 cross PCIe while the kernels of block b run (the source's next run() still waits for the copy before it
+		 * touches the vector again: a float source refills the vector it swapped out at once, rtlsdrtuner.cxx:265-285) */
+		if (pinned)
+			st->second = !st->second;
+		DevBuf &dst = (pinned && st->second) ? st->buf2 : st->buf;
+		if (!dst.reserve(dev, bytes) ||
+		    (pinned ? wr_dev_upload_ahead(dev, dst.ptr, host.data(), bytes)
+		            : wr_dev_upload(dev, dst.ptr, host.data(), bytes)) != WR_OK) {
 			LOG_ERROR("staging the source block failed: %s\n", wr_last_error());
 			return NULL;
 		}
 		st->epoch = src->epoch();
 		st->host = host.data();
 		st->floats = host.size();
-		st->cur = (const float *)st->buf.ptr;
+		st->cur = (const float *)dst.ptr;
 	}
 	if (dev_out)
 		*dev_out = dev;
