@@ -2,6 +2,8 @@
 (dsp/lowpass.cxx:38-39 FIXME), a second channel-filter stage (H4: a 12.5 kHz channel off a fast
 stream needs more than one 64-tap stage), and the two receiver controls the reference only stubs
 (af_gain, squelch: web/receiverhandler.cxx:112,118-119,127) -- against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -223,7 +225,7 @@ def test_af_gain_and_squelch(dev, oracle, keep_demod):
     t.destroy()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WR_FUZZ_SEEDS", "8"))))
 def test_random_f4_configurations(dev, oracle, seed):
     """Seeded mixtures of everything above in one tuner: filter lengths per receiver, receivers with
     and without a second channel stage (two rate groups), af_gain and squelch on some, detectors
@@ -239,7 +241,7 @@ def test_random_f4_configurations(dev, oracle, seed):
     specs, chans, rxs = [], [], []
     for c in range(nchan):
         f = int(rng.integers(-fs // 2 + 1, fs // 2))
-        l1, l2 = int(rng.choice([8, 16, 32, 64])), int(rng.choice([16, 64]))
+        l1, l2 = int(rng.choice([8, 16, 32, 64, 64, 128, 256])), int(rng.choice([16, 64]))   # 128 / 256: k_tuner_ddc_long (r03)
         pb1 = int(rng.choice([fs // 16, fs // 8, fs // 5]))
         two = bool(rng.integers(0, 2))
         mode = modes[int(rng.integers(0, 3))]
