@@ -19,7 +19,9 @@ Prints ONE JSON line on rank 0 (see the contract in the task description) carryi
 `cpu_baseline` (the oracle -- a scalar port of the reference CPU path -- timed on ALL host
 cores, one pipeline thread per core with its own subset of the receivers, and on one core,
 over a bounded sample of the same workload) and `secondary.c3` (BASELINE config 3: the
-SpectrumSink waterfall, 65536-point FFT at 50 % overlap, off the same resident stream).
+SpectrumSink waterfall, 65536-point FFT at 50 % overlap, off the same resident stream),
+`secondary.c1` (BASELINE config 1) and `secondary.host_fed` (the same C2 job through the C++ host
+classes with the block in HOST memory: the PCIe-inclusive rates -- reported beside `value`, never as it).
 """
 import argparse
 import json
@@ -193,6 +195,32 @@ def c3_secondary(torch, dev, blocks, n, steps, settle_ms):
                      if (committed_traffic().get("c3") or {}).get("frames_per_launch") == rows else None,
                      "traffic_unit": "bytes per launch pair (k_fft64k_pass1 + pass2), profiles/traffic.json"},
     }
+
+
+def host_fed_secondary():
+    """The drop-in path with the block in HOST memory (PCIe inside the timing; never `value`): tests/cxx/host_bench --
+    one FrontEnd, 256 Receivers wired as radio.cxx wires them, Radio::run() pumping 4 000 000-frame blocks through the C++
+    host classes -- from a byte-format source and from a float32 source, the sinks' audio one block late
+    (WEBRADIO_AUDIO_LATE=1) and on time.  Runs after everything timed above; None when the binary has not been built."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cxx", "host_bench")
+    if not os.path.exists(exe):
+        return None
+    rows = []
+    for src in ("u8", "f32"):
+        for late in ("1", "0"):
+            env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_AUDIO_LATE=late)
+            try:
+                r = subprocess.run([exe, "256", "100", "4000000", src], env=env, capture_output=True, text=True, timeout=120)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                d = json.loads(line)
+            except Exception as e:                      # the secondary figures never fail the headline
+                rows.append({"source": src, "audio_late": int(late), "error": str(e)[:200]})
+                continue
+            rows.append({"source": d["source"], "audio": d["audio"], "ms_per_block": d["ms_per_block"],
+                         "msps_tuner_input": d["msps_tuner_input"], "blocks": d["blocks"]})
+    return {"workload": "C2 through the C++ host classes (Radio::run, 256 Receivers), block in host memory: PCIe inside the timing",
+            "unit": "complex Msamples/s of tuner input", "runs": rows}
 
 
 def c1_secondary(torch, dev, steps, settle_ms):
@@ -662,6 +690,9 @@ def main():
                 out["secondary"]["c3"] = c3
             if c1 is not None:
                 out["secondary"]["c1"] = c1
+            hf = host_fed_secondary()
+            if hf is not None:
+                out["secondary"]["host_fed"] = hf
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ifs, args.cpu_blocks)
     else:
