@@ -219,10 +219,12 @@ int wr_chan_set_taps(wr_tuner *tuner, int chan, int stage, const float *coeff_ho
  * written in terms of it) INSIDE the fused path: fir_length a power of two in [2, 64].  A shorter
  * filter is the 64-tap filter with its oldest taps zero, bit for bit (the sum runs oldest sample
  * first, lowpass.cxx:150-158).  The CHANNEL filter (stage 0) may also have 128 or 256 taps
- * (WR_FIR_FUSED_MAX): receivers with such a filter form rate groups of their own, evaluated by a plain kernel
- * with the reference's own arithmetic -- table lookups, unfused products, oldest sample first, the last L - 1
- * MIXED frames kept per channel as LowPass::block does (lowpass.cxx:138-142) -- bit-identical to the reference
- * chain in every nco mode, at a fraction of the fast kernels' speed (still without a full-rate mixer output).
+ * (WR_FIR_FUSED_MAX): receivers with such a filter form rate groups of their own, which keep the last L - 1
+ * MIXED frames per channel as LowPass::block does (lowpass.cxx:138-142).  WR_NCO_EXACT: the reference's own
+ * arithmetic -- table lookups, unfused products, oldest sample first -- bit-identical to the reference chain, at
+ * the exact kernels' pace.  The other nco modes: the window as L / 64 segments of the ROTATE recurrence, within its
+ * tolerance (1e-6), about L / 64 times the 64-tap kernel's time (lane groups whose channels do not share one filter:
+ * the reference's arithmetic).  Never a full-rate mixer output.
  * Longer filters and long audio filters: wr_fir_decimate_n, block by block. */
 int wr_chan_set_filter_n(wr_tuner *tuner, int chan, int stage, unsigned int fir_length,
                          unsigned int passband, unsigned int out_rate);

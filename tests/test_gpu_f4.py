@@ -90,9 +90,12 @@ def test_fir_length_inside_the_fused_path(dev, oracle, nco, lengths):
 @pytest.mark.parametrize("l1,d1,sizes", [(128, 400, ((40_000, 3), (2_000, 5))), (256, 400, ((48_000, 2), (2_000, 4))),
                                          (256, 40, ((200, 12), (4_000, 3))), (128, 20, ((100, 9),))])
 def test_channel_filter_of_128_and_256_taps_inside_the_tuner(dev, oracle, nco, l1, d1, sizes):
-    """r03, SURVEY 8f-4: LowPass::_firLength 128 and 256 for the channel filter INSIDE the tuner's launch sequence
-    (k_tuner_ddc_long: the reference's own arithmetic, the last L - 1 mixed frames kept per channel as LowPass::block
-    does) -- bit-identical to the oracle's mixer -> `_n` filter -> AM -> audio filter cascade in EVERY nco mode.
+    """r03, SURVEY 8f-4: LowPass::_firLength 128 and 256 for the channel filter INSIDE the tuner's launch sequence.
+    EXACT: k_tuner_ddc_long, the reference's own arithmetic with the last L - 1 mixed frames kept per channel as
+    LowPass::block does -- bit-identical to the oracle's mixer -> `_n` filter -> AM -> audio filter cascade.
+    ROTATE: the output frames whose window lies inside the block take k_tuner_ddc_long_rot (L / 64 segments of the
+    ROTATE recurrence), the ones that reach into the previous block still the reference's arithmetic -- within the
+    ROTATE tolerance on every channel.
     70 receivers (two lane groups), blocks shorter than the filter's history (200 frames against 255), a retune
     in mid-stream (the history keeps the frames as they were mixed, downconverter.cxx:59-67), and a receiver with
     the usual 64 taps beside them in the same tuner (another rate group, the fast kernels)."""
@@ -107,6 +110,7 @@ def test_channel_filter_of_128_and_256_taps_inside_the_tuner(dev, oracle, nco, l
         plain = t.add_receiver(4321, pb1, fs // d1, capi.WR_USB, fs // d1 // 8, fs // d1 // d2)
         rxs = {c: OracleChain(oracle, fs, ifs[c], l1, pb1, d1, oracle.AM, 64, fs // d1 // 8, d2) for c in probe}
         rxp = OracleChain(oracle, fs, 4321, 64, pb1, d1, oracle.USB, 64, fs // d1 // 8, d2)
+        again = max(1.0, float(np.abs(oracle.lowpass_design(fs // d1 // 8, fs // d1)).sum()))
         t.profile(True)                                    # both rate groups' launches stamp their events
         pos = 0
         for b in range(blocks):
@@ -121,8 +125,13 @@ def test_channel_filter_of_128_and_256_taps_inside_the_tuner(dev, oracle, nco, l
                 gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)
                 ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
                 assert gc.size == wc.size and ga.size == wa.size
-                assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, b, c)
-                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, b, c)
+                if nco == capi.WR_NCO_EXACT:
+                    assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, b, c)
+                    assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, b, c)
+                else:
+                    assert np.abs(gc - wc).max() <= 1e-6, (n, b, c, float(np.abs(gc - wc).max()))
+                    if wa.size:                            # AM: |.| is 1-Lipschitz, then the linear audio filter
+                        assert np.abs(ga - wa).max() <= 2e-6 * again, (n, b, c)
             wa, wc, _ = rxp.run(iq)
             gc = t.fetch(plain, capi.WR_STAGE_CHAN_IQ, 2 * n)
             if nco == capi.WR_NCO_EXACT:

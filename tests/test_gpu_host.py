@@ -124,14 +124,17 @@ def test_runtime_fir_length_through_the_host_classes(tmp_path, oracle):
 @pytest.mark.parametrize("L", [128, 256])
 def test_long_channel_filter_stays_in_the_tuner_batch(tmp_path, oracle, L):
     """r03: channelFilter()->setFirLength(128 | 256) with the audio filter at its 64 taps: the Receiver stays in the
-    source's tuner batch (WEBRADIO_TRACE shows it submitting) -- k_tuner_ddc_long runs the channel filter in the
-    reference's own arithmetic, so the linear detectors are the oracle's bits in the DEFAULT (ROTATE) nco mode too.
-    A retune between blocks 1 and 2."""
+    source's tuner batch (WEBRADIO_TRACE shows it submitting).  WEBRADIO_NCO=exact: the reference's own arithmetic
+    (k_tuner_ddc_long), the linear detectors are the oracle's bits; the default mode: L / 64 segments of the ROTATE
+    recurrence (k_tuner_ddc_long_rot), within its tolerance.  A retune between blocks 1 and 2."""
     ifs, modes = [50_000, -75_000, 10, 33_333], [0, 2, 3, 0]
     rate, block, cpb, crate, apb, arate = CFG["rate"], CFG["block"], CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"]
     iq = synth.fm_stream(4 * block, rate, ifs[:2], amp=0.3)
     got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(2, 61_000),
-                  env={"WR_TEST_FIR_LENGTH_CHAN": str(L), "WEBRADIO_TRACE": "1"})
+                  env={"WR_TEST_FIR_LENGTH_CHAN": str(L), "WEBRADIO_TRACE": "1", "WEBRADIO_NCO": "exact"})
+    assert int(np.load(str(tmp_path / "out.npz"))["traced"]) > 0
+    fast, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(2, 61_000),
+                   env={"WR_TEST_FIR_LENGTH_CHAN": str(L), "WEBRADIO_TRACE": "1"})
     assert int(np.load(str(tmp_path / "out.npz"))["traced"]) > 0
     table = oracle.sin_table()
     for c, (f, m) in enumerate(zip(ifs, modes)):
@@ -147,6 +150,7 @@ def test_long_channel_filter_stays_in_the_tuner_batch(tmp_path, oracle, L):
         want = np.concatenate(want)
         assert got[c].size == want.size
         assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
+        assert np.abs(fast[c] - want).max() <= 4e-6, (c, float(np.abs(fast[c] - want).max()))   # USB / LSB add two components
 
 
 def test_unfused_blocks_are_bit_exact(tmp_path, oracle):

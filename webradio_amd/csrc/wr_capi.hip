@@ -143,6 +143,7 @@ struct Group {
 	                                        (the others take the per-lane-taps kernel) */
 	unsigned char nsets[64] = {0};       /* how many */
 	bool one_filter = false;             /* ONE channel filter for every channel of the group */
+	bool long_uniform = false;           /* l1 > 64: every lane group's channels share one long filter (k_tuner_ddc_long_rot) */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -749,6 +750,13 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 		HIP_TRY(wrk_u8_to_f32(d->up_stream, d->up_raw[rb], out_dev, count));
 	}
 	return upload_ahead_end(d);
+}
+
+/* WR_LONG_ROTATE=0: channel filters of 128 / 256 taps take the reference's arithmetic in every nco mode (r03's first version) */
+static bool long_rot_enabled()
+{
+	static const bool on = !(getenv("WR_LONG_ROTATE") && atoi(getenv("WR_LONG_ROTATE")) == 0);
+	return on;
 }
 
 /* ------------------------------------------------------------------ tuner -- */
@@ -1480,6 +1488,22 @@ static int group_upload(wr_tuner *t, Group *g)
 	g->uniform_mask = umask;
 	g->fewsets_mask = fmask;
 	g->one_filter = one_filter && first_rep >= 0;
+	g->long_uniform = false;
+	if (g->l1 > WR_FIR_LENGTH) {
+		g->long_uniform = true;
+		for (size_t base = 0; base < S && g->long_uniform; base += WR_LANES) {
+			int rep = -1;
+			for (size_t s = base; s < base + WR_LANES; ++s) {
+				const int ci = g->owner[s];
+				if (ci < 0)
+					continue;
+				if (rep < 0)
+					rep = ci;
+				else if (memcmp(t->chans[ci].taps_long, t->chans[rep].taps_long, sizeof(float) * g->l1))
+					g->long_uniform = false;
+			}
+		}
+	}
 	if (g->one_filter)
 		/* two lane groups that share a wave take the window from the first one's entry: an emptied lane
 		 * group in between holds the common filter too */
@@ -1786,7 +1810,8 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		if (g->l1 > WR_FIR_LENGTH)
 			/* a channel filter of 128 or 256 taps: the plain kernel with the reference's arithmetic (wr_kernels.hip:
 			 * k_tuner_ddc_long), which also rolls phase and mixed history; such a group never defers its post stage */
-			HIP_TRY(wrk_tuner_ddc_long(st, L, g->dev, g->l1, d->table, d->num_cus));
+			HIP_TRY(wrk_tuner_ddc_long(st, L, g->dev, g->l1, d->table, d->num_cus,
+			                           t->nco_mode != WR_NCO_EXACT && g->long_uniform && long_rot_enabled(), d->hi_cs, d->lo_cs));
 		else
 			HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 			                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));

@@ -1589,19 +1589,21 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
  *   The 64-frame pieces of the window go through LDS like the fused kernel's (lane j loads frame j).
  * k_ddc_long_roll: the end-of-block state -- phase advanced by nframes steps, the last L-1 mixed frames.
  */
-__global__ void __launch_bounds__(256)
-k_tuner_ddc_long(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes, size_t k1,
-                 unsigned int d1, unsigned int len, unsigned int slots, unsigned int groups,
-                 const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
-                 const int *__restrict__ flags, const float *__restrict__ taps, const float2 *__restrict__ mixhist,
-                 const float *__restrict__ table, float2 *__restrict__ chan_iq)
+/* units [u0, units) of the reference-arithmetic path, every `ustride`-th: one wave each (see above).  `winl`: this wave's
+ * 64-frame window piece in LDS.  Everything a chunk of 8 taps needs from memory -- the table values, the taps, the mixed
+ * frames of the previous block -- is requested before the chunk's arithmetic, unconditionally (a frame inside the block
+ * loads a clamped history row it does not use and the other way round): one memory latency per chunk, not per tap. */
+__device__ __forceinline__ void ddc_long_exact_units(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
+                                                      size_t units, size_t u0, size_t ustride, unsigned int d1, unsigned int len,
+                                                      unsigned int slots, unsigned int groups,
+                                                      const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+                                                      const int *__restrict__ flags, const float *__restrict__ taps,
+                                                      const float2 *__restrict__ mixhist, const float *__restrict__ table,
+                                                      float2 *__restrict__ chan_iq, v2f *winl)
 {
-	__shared__ v2f winl[4][64];
 	const unsigned int lane = threadIdx.x & 63u;
-	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const size_t units = k1 * groups;
 	const unsigned int hl = len - 1u;                    /* history frames per channel */
-	for (size_t u = (size_t)blockIdx.x * 4u + wave; u < units; u += (size_t)gridDim.x * 4u) {
+	for (size_t u = u0; u < units; u += ustride) {
 		const unsigned int g = (unsigned int)(u % groups);
 		const size_t k = u / groups;
 		const unsigned int s = g * 64u + lane;
@@ -1614,26 +1616,145 @@ k_tuner_ddc_long(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_
 			float2 xf = make_float2(0.0f, 0.0f);
 			if (nl >= 0)
 				xf = input_frame(cur, cur_u8, (size_t)nl);
-			winl[wave][lane] = (v2f){xf.x, xf.y};            /* (one wave reads what it wrote: LDS is in order) */
-			for (unsigned int j = 0; j < 64u; ++j) {
-				const long long n = n0 + j;
-				const float hj = taps[(size_t)(len - 1u - (64u * seg + j)) * slots + s];
-				if (n >= 0) {
-					const v2f xs = winl[wave][j];
-					const v2f cs = nco<WR_NCO_EXACT>(p0 + (unsigned int)n * st, table, nullptr, nullptr);
-					mac<WR_NCO_EXACT>(xs, cs, hj, acc);
-				} else {
-					const float2 m = mixhist[(size_t)(hl + n) * slots + s];   /* the frame as it was mixed back then */
-					float ti, tq;
-					asm("v_mul_f32 %0, %1, %2" : "=v"(ti) : "v"(hj), "v"(m.x));
-					asm("v_mul_f32 %0, %1, %2" : "=v"(tq) : "v"(hj), "v"(m.y));
-					acc.x = acc.x + ti;
-					acc.y = acc.y + tq;
+			winl[lane] = (v2f){xf.x, xf.y};                  /* (one wave reads what it wrote: LDS is in order) */
+			for (unsigned int jb = 0; jb < 64u; jb += 8u) {
+				v2f cs[8];
+				float hj[8];
+				float2 m[8];
+#pragma unroll
+				for (unsigned int jj = 0; jj < 8u; ++jj) {
+					const long long n = n0 + jb + jj;
+					hj[jj] = taps[(size_t)(len - 1u - (64u * seg + jb + jj)) * slots + s];
+					cs[jj] = nco<WR_NCO_EXACT>(p0 + (unsigned int)n * st, table, nullptr, nullptr);
+					m[jj] = mixhist[(size_t)(n < 0 ? hl + n : 0) * slots + s];   /* the frame as it was mixed back then */
+				}
+#pragma unroll
+				for (unsigned int jj = 0; jj < 8u; ++jj) {
+					const long long n = n0 + jb + jj;
+					if (n >= 0) {
+						mac<WR_NCO_EXACT>(winl[jb + jj], cs[jj], hj[jj], acc);
+					} else {
+						float ti, tq;
+						asm("v_mul_f32 %0, %1, %2" : "=v"(ti) : "v"(hj[jj]), "v"(m[jj].x));
+						asm("v_mul_f32 %0, %1, %2" : "=v"(tq) : "v"(hj[jj]), "v"(m[jj].y));
+						acc.x = acc.x + ti;
+						acc.y = acc.y + tq;
+					}
 				}
 			}
 		}
 		if (active)
 			chan_iq[k * slots + s] = make_float2(acc.x, acc.y);
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_tuner_ddc_long(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes, size_t k1,
+                 unsigned int d1, unsigned int len, unsigned int slots, unsigned int groups,
+                 const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+                 const int *__restrict__ flags, const float *__restrict__ taps, const float2 *__restrict__ mixhist,
+                 const float *__restrict__ table, float2 *__restrict__ chan_iq)
+{
+	__shared__ v2f winl[4][64];
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	ddc_long_exact_units(cur, cur_u8, k1 * groups, (size_t)blockIdx.x * 4u + wave, (size_t)gridDim.x * 4u, d1, len, slots, groups,
+	                     phase, step, flags, taps, mixhist, table, chan_iq, winl[wave]);
+}
+
+/* The same channel filter with the ROTATE arithmetic, when every channel of a lane group has the same filter: the L-frame
+ * window is L / 64 segments, each exactly a unit of k_tuner_ddc -- lane j folds tap L-1-(64 q + j) into window sample j, one
+ * Horner chain per lane over the 64 samples with the turn selected by the phase fraction's carry, closed with the LO of the
+ * segment's last frame (hi x lo tables) -- added up into one output.  Seven VALU instructions per channel-tap instead of two
+ * table gathers: 128 taps in about twice the time of 64, within the ROTATE tolerance (|IQ - reference| <= 1e-6) instead of
+ * bit-identical.  Frames of the previous block under the window (the first ceil((L - 1) / D1) outputs of a block) come
+ * from `mixhist` as they were mixed back then (lowpass.cxx:138-142 keeps them; a retune in between does not touch them): a
+ * plain real-tap sum, and the chain starts at the block's first frame.
+ * One wave per (k, lane group); the wave's window in LDS, the next segment's frame requested before this segment's chain. */
+__global__ void __launch_bounds__(256)
+k_tuner_ddc_long_rot(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t k1,
+                     unsigned int d1, unsigned int len, unsigned int slots, unsigned int groups,
+                     const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+                     const int *__restrict__ flags, const float4 *__restrict__ rot, const float *__restrict__ taps,
+                     const float2 *__restrict__ hi_cs, const float2 *__restrict__ lo_cs, float2 *__restrict__ chan_iq,
+                     const float2 *__restrict__ mixhist)
+{
+	__shared__ v2f hi_l[WR_SPLIT_N], lo_l[WR_SPLIT_N];
+	__shared__ v2f winl[4][2][64];
+	__shared__ float hseg[4][64];
+	for (unsigned int e = threadIdx.x; e < WR_SPLIT_N; e += blockDim.x) {
+		const float2 hv = hi_cs[e], lv = lo_cs[e];
+		hi_l[e] = (v2f){hv.x, hv.y};
+		lo_l[e] = (v2f){lv.x, lv.y};
+	}
+	__syncthreads();
+	const unsigned int lane = threadIdx.x & 63u;
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const unsigned int segs = len / 64u, hl = len - 1u;
+	const size_t units = k1 * groups;
+	for (size_t u = (size_t)blockIdx.x * 4u + wave; u < units; u += (size_t)gridDim.x * 4u) {
+		const unsigned int g = (unsigned int)(u % groups);
+		const size_t k = u / groups;
+		const unsigned int s = g * 64u + lane;
+		const bool active = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
+		/* the group's filter: that of its first active channel (the host checked that the others have the same) */
+		const unsigned long long act = __ballot(active);
+		if (!act)
+			continue;
+		const unsigned int su = g * 64u + (unsigned int)(__ffsll((long long)act) - 1);
+		const unsigned int p0 = phase[s], st = step[s], fstep = st << 16;
+		const float4 r4 = rot[s];
+		const long long n0 = (long long)k * d1 - (long long)hl;      /* the window's first frame; < 0: in the previous block */
+		v2f acc = {0.0f, 0.0f};
+		long long nf = n0 + lane;
+		float2 xn = nf >= 0 ? input_frame(cur, cur_u8, (size_t)nf) : make_float2(0.0f, 0.0f);
+		float hn = taps[(size_t)(len - 1u - lane) * slots + su];
+		for (unsigned int q = 0; q < segs; ++q) {
+			const long long ns = n0 + 64ll * q;                       /* this segment's first frame */
+			v2f *w = winl[wave][q & 1u];
+			w[lane] = (v2f){hn * xn.x, hn * xn.y};                    /* (one wave reads what it wrote: LDS is in order) */
+			if (ns < 0)
+				hseg[wave][lane] = hn;
+			if (q + 1u < segs) {
+				nf = ns + 64 + lane;
+				xn = nf >= 0 ? input_frame(cur, cur_u8, (size_t)nf) : make_float2(0.0f, 0.0f);
+				hn = taps[(size_t)(len - 1u - (64u * (q + 1u) + lane)) * slots + su];
+			}
+			unsigned int j0 = 0;                                      /* the segment's first frame inside the block */
+			if (ns < 0) {
+				j0 = ns + 64 <= 0 ? 64u : (unsigned int)(-ns);
+				for (unsigned int j = 0; j < j0; ++j) {               /* frames as they were mixed back then */
+					const float2 m = mixhist[(size_t)(hl + ns + j) * slots + s];
+					const float h = hseg[wave][j];
+					acc.x = __builtin_fmaf(h, m.x, acc.x);
+					acc.y = __builtin_fmaf(h, m.y, acc.y);
+				}
+				if (j0 == 64u)
+					continue;
+			}
+			const unsigned int Pj = p0 + (unsigned int)(ns + j0) * st;    /* phase of the chain's first frame */
+			unsigned int F = Pj << 16;                                /* its 16 fraction bits, left-aligned */
+			v2f A = w[j0];
+			if (j0 == 0) {
+#pragma unroll 8
+				for (unsigned int j = 1; j < 64u; ++j) {
+					unsigned int F2;
+					const bool carry = __builtin_uadd_overflow(F, fstep, &F2);
+					F = F2;
+					horner_step(A, carry ? r4.z : r4.x, carry ? r4.w : r4.y, w[j]);
+				}
+			} else {
+				for (unsigned int j = j0 + 1u; j < 64u; ++j) {
+					unsigned int F2;
+					const bool carry = __builtin_uadd_overflow(F, fstep, &F2);
+					F = F2;
+					horner_step(A, carry ? r4.z : r4.x, carry ? r4.w : r4.y, w[j]);
+				}
+			}
+			const v2f cs = nco<WR_NCO_ROTATE>(p0 + (unsigned int)(ns + 63) * st, nullptr, hi_l, lo_l);
+			horner_close(acc, A, cs);
+		}
+		if (active)
+			chan_iq[(size_t)k * slots + s] = make_float2(acc.x, acc.y);
 	}
 }
 
@@ -1666,31 +1787,56 @@ k_ddc_long_roll(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u
 }
 
 hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
-                              const float *table_dev, int num_cus)
+                              const float *table_dev, int num_cus, bool rotate, const float *hi_dev, const float *lo_dev)
 {
 	if (!L.slots_used)
 		return hipSuccess;
 	const unsigned int groups = L.slots_used / 64u;
-	const size_t units = L.k1 * groups;
+	/* `rotate` (a tolerance nco mode, one filter per lane group): only the frames whose window reaches into the previous
+	 * block take the reference's arithmetic, the others k_tuner_ddc_long_rot */
+	size_t k_exact = L.k1;
+	bool exact_done = false;
+	if (rotate && L.k1) {
+		const size_t units_r = L.k1 * groups;
+		unsigned int wgs_r = (unsigned int)((units_r + 3) / 4);
+		const unsigned int cap_r = (unsigned int)num_cus * 8u;
+		if (wgs_r > cap_r)
+			wgs_r = cap_r;
+		exact_done = true;
+		k_exact = 0;
+		if (L.ev_start && L.ev_stop)
+			hipExtLaunchKernelGGL(k_tuner_ddc_long_rot, dim3(wgs_r), dim3(256), 0, st, (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
+			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len, L.slots, groups,
+			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
+			                      (const float4 *)G.rot, (const float *)G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
+			                      (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
+		else
+			k_tuner_ddc_long_rot<<<wgs_r, 256, 0, st>>>((const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len,
+			                                            L.slots, groups, G.phase[L.sp], G.step, G.flags, (const float4 *)G.rot,
+			                                            G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
+			                                            (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
+	}
+	const bool prof_exact = L.ev_start && L.ev_stop && !exact_done;
+	const size_t units = exact_done ? 0 : k_exact * groups;
 	if (units) {
 		unsigned int wgs = (unsigned int)((units + 3) / 4);
 		const unsigned int cap = (unsigned int)num_cus * 8u;
 		if (wgs > cap)
 			wgs = cap;
-		if (L.ev_start && L.ev_stop)
+		if (prof_exact)
 			/* profiling: the filter kernel's own start and end (the roll behind it is not in the bracket) */
 			hipExtLaunchKernelGGL(k_tuner_ddc_long, dim3(wgs), dim3(256), 0, st, (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
-			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, L.k1, L.d1, len, L.slots, groups,
+			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, k_exact, L.d1, len, L.slots, groups,
 			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
 			                      (const float *)G.taps1L, (const float2 *)G.mixhist[L.sp], table_dev, (float2 *)G.chan_iq[L.cb]);
 		else
-			k_tuner_ddc_long<<<wgs, 256, 0, st>>>((const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, L.k1, L.d1, len,
+			k_tuner_ddc_long<<<wgs, 256, 0, st>>>((const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, k_exact, L.d1, len,
 			                                      L.slots, groups, G.phase[L.sp], G.step, G.flags, G.taps1L,
 			                                      (const float2 *)G.mixhist[L.sp], table_dev, (float2 *)G.chan_iq[L.cb]);
 	}
 	const size_t total = (size_t)(len - 1u) * L.slots;
 	const unsigned int rwgs = (unsigned int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-	if (L.ev_start && L.ev_stop && !units) {
+	if (L.ev_start && L.ev_stop && !L.k1) {
 		/* profiling a block too short for an output frame: the roll is all there is */
 		hipExtLaunchKernelGGL(k_ddc_long_roll, dim3(rwgs), dim3(256), 0, st, (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
 		                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.nframes, len, L.slots,

@@ -110,7 +110,7 @@ class Tuner:
                      stage2=None):
         """Receiver() + setFrontEnd(): the wiring of radio.cxx:62-90 with explicit parameters.
         fir_lengths: (channel, audio) LowPass::_firLength, powers of two: the channel filter up to 256
-        (WR_FIR_FUSED_MAX; above 64 the tuner runs it in the reference's own arithmetic whatever the nco mode),
+        (WR_FIR_FUSED_MAX; above 64: WR_NCO_EXACT the reference's own arithmetic, the other modes the ROTATE recurrence in L / 64 segments),
         the audio filter up to 64 (default 64, 64).
         stage2: (fir_length, passband, out_rate) of a second channel LowPass in front of the demodulator."""
         c = C.c_int()
