@@ -144,6 +144,7 @@ struct Group {
 	unsigned char nsets[64] = {0};       /* how many */
 	bool one_filter = false;             /* ONE channel filter for every channel of the group */
 	bool long_uniform = false;           /* l1 > 64: every lane group's channels share one long filter (k_tuner_ddc_long_rot) */
+	bool long_one = false;               /* ... and it is the same filter in every lane group (two lane groups per wave) */
 	size_t last_k1, last_k2;
 	int active;
 };
@@ -1488,9 +1489,10 @@ static int group_upload(wr_tuner *t, Group *g)
 	g->uniform_mask = umask;
 	g->fewsets_mask = fmask;
 	g->one_filter = one_filter && first_rep >= 0;
-	g->long_uniform = false;
+	g->long_uniform = g->long_one = false;
 	if (g->l1 > WR_FIR_LENGTH) {
-		g->long_uniform = true;
+		g->long_uniform = g->long_one = true;
+		int rep_all = -1;
 		for (size_t base = 0; base < S && g->long_uniform; base += WR_LANES) {
 			int rep = -1;
 			for (size_t s = base; s < base + WR_LANES; ++s) {
@@ -1502,7 +1504,14 @@ static int group_upload(wr_tuner *t, Group *g)
 				else if (memcmp(t->chans[ci].taps_long, t->chans[rep].taps_long, sizeof(float) * g->l1))
 					g->long_uniform = false;
 			}
+			if (rep >= 0) {
+				if (rep_all < 0)
+					rep_all = rep;
+				else if (memcmp(t->chans[rep].taps_long, t->chans[rep_all].taps_long, sizeof(float) * g->l1))
+					g->long_one = false;
+			}
 		}
+		g->long_one = g->long_one && g->long_uniform;
 	}
 	if (g->one_filter)
 		/* two lane groups that share a wave take the window from the first one's entry: an emptied lane
@@ -1811,7 +1820,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			/* a channel filter of 128 or 256 taps: the plain kernel with the reference's arithmetic (wr_kernels.hip:
 			 * k_tuner_ddc_long), which also rolls phase and mixed history; such a group never defers its post stage */
 			HIP_TRY(wrk_tuner_ddc_long(st, L, g->dev, g->l1, d->table, d->num_cus,
-			                           t->nco_mode != WR_NCO_EXACT && g->long_uniform && long_rot_enabled(), d->hi_cs, d->lo_cs));
+			                           t->nco_mode != WR_NCO_EXACT && g->long_uniform && long_rot_enabled(), g->long_one, d->hi_cs, d->lo_cs));
 		else
 			HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 			                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));

@@ -149,7 +149,8 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
 /* the same for a channel filter of `len` = 128 or 256 taps (k_tuner_ddc_long: the reference's arithmetic in every
  * nco mode); also rolls the group's state (phase, mixed history) into the other set */
 hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
-                              const float *table_dev, int num_cus, bool rotate, const float *hi_dev, const float *lo_dev);
+                              const float *table_dev, int num_cus, bool rotate, bool rotate_one_filter, const float *hi_dev,
+                              const float *lo_dev);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 /* second channel-filter stage: k1a first-stage frames of chan_iq[cb] -> k1a / d1b frames of chan_iq2[cb];
  * history from iq2_hist[p2], next history into iq2_hist[p2 ^ 1] */

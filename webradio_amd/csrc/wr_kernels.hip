@@ -1670,6 +1670,9 @@ k_tuner_ddc_long(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_
  * from `mixhist` as they were mixed back then (lowpass.cxx:138-142 keeps them; a retune in between does not touch them): a
  * plain real-tap sum, and the chain starts at the block's first frame.
  * One wave per (k, lane group); the wave's window in LDS, the next segment's frame requested before this segment's chain. */
+/* NG: lane groups per wave (2 when the whole rate group has ONE filter and an even number of lane groups: the two
+ * recurrences share the window and every one of its LDS reads, and fill each other's issue gaps -- see k_tuner_ddc) */
+template <unsigned int NG>
 __global__ void __launch_bounds__(256)
 k_tuner_ddc_long_rot(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t k1,
                      unsigned int d1, unsigned int len, unsigned int slots, unsigned int groups,
@@ -1689,22 +1692,35 @@ k_tuner_ddc_long_rot(const float2 *__restrict__ cur, const uchar2 *__restrict__ 
 	__syncthreads();
 	const unsigned int lane = threadIdx.x & 63u;
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const unsigned int segs = len / 64u, hl = len - 1u;
-	const size_t units = k1 * groups;
+	const unsigned int segs = len / 64u, hl = len - 1u, gsets = groups / NG;
+	const size_t units = k1 * gsets;
 	for (size_t u = (size_t)blockIdx.x * 4u + wave; u < units; u += (size_t)gridDim.x * 4u) {
-		const unsigned int g = (unsigned int)(u % groups);
-		const size_t k = u / groups;
-		const unsigned int s = g * 64u + lane;
-		const bool active = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
-		/* the group's filter: that of its first active channel (the host checked that the others have the same) */
-		const unsigned long long act = __ballot(active);
+		const unsigned int gs = (unsigned int)(u % gsets);
+		const size_t k = u / gsets;
+		unsigned int s[NG], p0[NG], st[NG], fstep[NG];
+		float4 r4[NG];
+		bool active[NG];
+		v2f acc[NG];
+		unsigned long long act = 0;
+		unsigned int su = 0;
+#pragma unroll
+		for (unsigned int c = 0; c < NG; ++c) {
+			s[c] = (gs * NG + c) * 64u + lane;
+			active[c] = (flags[s[c]] & PHASE_FLAG_ACTIVE) != 0;
+			/* the filter: that of the first active channel (the host checked that the others have the same) */
+			const unsigned long long a = __ballot(active[c]);
+			if (!act && a)
+				su = (gs * NG + c) * 64u + (unsigned int)(__ffsll((long long)a) - 1);
+			act |= a;
+			p0[c] = phase[s[c]];
+			st[c] = step[s[c]];
+			fstep[c] = st[c] << 16;
+			r4[c] = rot[s[c]];
+			acc[c] = (v2f){0.0f, 0.0f};
+		}
 		if (!act)
 			continue;
-		const unsigned int su = g * 64u + (unsigned int)(__ffsll((long long)act) - 1);
-		const unsigned int p0 = phase[s], st = step[s], fstep = st << 16;
-		const float4 r4 = rot[s];
 		const long long n0 = (long long)k * d1 - (long long)hl;      /* the window's first frame; < 0: in the previous block */
-		v2f acc = {0.0f, 0.0f};
 		long long nf = n0 + lane;
 		float2 xn = nf >= 0 ? input_frame(cur, cur_u8, (size_t)nf) : make_float2(0.0f, 0.0f);
 		float hn = taps[(size_t)(len - 1u - lane) * slots + su];
@@ -1723,38 +1739,58 @@ k_tuner_ddc_long_rot(const float2 *__restrict__ cur, const uchar2 *__restrict__ 
 			if (ns < 0) {
 				j0 = ns + 64 <= 0 ? 64u : (unsigned int)(-ns);
 				for (unsigned int j = 0; j < j0; ++j) {               /* frames as they were mixed back then */
-					const float2 m = mixhist[(size_t)(hl + ns + j) * slots + s];
 					const float h = hseg[wave][j];
-					acc.x = __builtin_fmaf(h, m.x, acc.x);
-					acc.y = __builtin_fmaf(h, m.y, acc.y);
+#pragma unroll
+					for (unsigned int c = 0; c < NG; ++c) {
+						const float2 m = mixhist[(size_t)(hl + ns + j) * slots + s[c]];
+						acc[c].x = __builtin_fmaf(h, m.x, acc[c].x);
+						acc[c].y = __builtin_fmaf(h, m.y, acc[c].y);
+					}
 				}
 				if (j0 == 64u)
 					continue;
 			}
-			const unsigned int Pj = p0 + (unsigned int)(ns + j0) * st;    /* phase of the chain's first frame */
-			unsigned int F = Pj << 16;                                /* its 16 fraction bits, left-aligned */
-			v2f A = w[j0];
+			unsigned int F[NG];
+			v2f A[NG];
+#pragma unroll
+			for (unsigned int c = 0; c < NG; ++c) {
+				F[c] = (p0[c] + (unsigned int)(ns + j0) * st[c]) << 16;   /* the chain's first frame: its 16 fraction bits */
+				A[c] = w[j0];
+			}
 			if (j0 == 0) {
 #pragma unroll 8
 				for (unsigned int j = 1; j < 64u; ++j) {
-					unsigned int F2;
-					const bool carry = __builtin_uadd_overflow(F, fstep, &F2);
-					F = F2;
-					horner_step(A, carry ? r4.z : r4.x, carry ? r4.w : r4.y, w[j]);
+					const v2f uj = w[j];
+#pragma unroll
+					for (unsigned int c = 0; c < NG; ++c) {
+						unsigned int F2;
+						const bool carry = __builtin_uadd_overflow(F[c], fstep[c], &F2);
+						F[c] = F2;
+						horner_step(A[c], carry ? r4[c].z : r4[c].x, carry ? r4[c].w : r4[c].y, uj);
+					}
 				}
 			} else {
 				for (unsigned int j = j0 + 1u; j < 64u; ++j) {
-					unsigned int F2;
-					const bool carry = __builtin_uadd_overflow(F, fstep, &F2);
-					F = F2;
-					horner_step(A, carry ? r4.z : r4.x, carry ? r4.w : r4.y, w[j]);
+					const v2f uj = w[j];
+#pragma unroll
+					for (unsigned int c = 0; c < NG; ++c) {
+						unsigned int F2;
+						const bool carry = __builtin_uadd_overflow(F[c], fstep[c], &F2);
+						F[c] = F2;
+						horner_step(A[c], carry ? r4[c].z : r4[c].x, carry ? r4[c].w : r4[c].y, uj);
+					}
 				}
 			}
-			const v2f cs = nco<WR_NCO_ROTATE>(p0 + (unsigned int)(ns + 63) * st, nullptr, hi_l, lo_l);
-			horner_close(acc, A, cs);
+#pragma unroll
+			for (unsigned int c = 0; c < NG; ++c) {
+				const v2f cs = nco<WR_NCO_ROTATE>(p0[c] + (unsigned int)(ns + 63) * st[c], nullptr, hi_l, lo_l);
+				horner_close(acc[c], A[c], cs);
+			}
 		}
-		if (active)
-			chan_iq[(size_t)k * slots + s] = make_float2(acc.x, acc.y);
+#pragma unroll
+		for (unsigned int c = 0; c < NG; ++c)
+			if (active[c])
+				chan_iq[(size_t)k * slots + s[c]] = make_float2(acc[c].x, acc[c].y);
 	}
 }
 
@@ -1787,7 +1823,8 @@ k_ddc_long_roll(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u
 }
 
 hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
-                              const float *table_dev, int num_cus, bool rotate, const float *hi_dev, const float *lo_dev)
+                              const float *table_dev, int num_cus, bool rotate, bool rotate_one_filter, const float *hi_dev,
+                              const float *lo_dev)
 {
 	if (!L.slots_used)
 		return hipSuccess;
@@ -1804,17 +1841,25 @@ hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGr
 			wgs_r = cap_r;
 		exact_done = true;
 		k_exact = 0;
-		if (L.ev_start && L.ev_stop)
-			hipExtLaunchKernelGGL(k_tuner_ddc_long_rot, dim3(wgs_r), dim3(256), 0, st, (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,
+		const bool two = rotate_one_filter && groups % 2u == 0;
+		const hipEvent_t e0 = (L.ev_start && L.ev_stop) ? (hipEvent_t)L.ev_start : nullptr;
+		const hipEvent_t e1 = (L.ev_start && L.ev_stop) ? (hipEvent_t)L.ev_stop : nullptr;
+		if (two) {
+			wgs_r = (unsigned int)((units_r / 2 + 3) / 4);
+			if (wgs_r > cap_r)
+				wgs_r = cap_r;
+			hipExtLaunchKernelGGL(k_tuner_ddc_long_rot<2u>, dim3(wgs_r), dim3(256), 0, st, e0, e1, 0u,
 			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len, L.slots, groups,
 			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
 			                      (const float4 *)G.rot, (const float *)G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
 			                      (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
-		else
-			k_tuner_ddc_long_rot<<<wgs_r, 256, 0, st>>>((const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len,
-			                                            L.slots, groups, G.phase[L.sp], G.step, G.flags, (const float4 *)G.rot,
-			                                            G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
-			                                            (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
+		} else {
+			hipExtLaunchKernelGGL(k_tuner_ddc_long_rot<1u>, dim3(wgs_r), dim3(256), 0, st, e0, e1, 0u,
+			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len, L.slots, groups,
+			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
+			                      (const float4 *)G.rot, (const float *)G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
+			                      (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
+		}
 	}
 	const bool prof_exact = L.ev_start && L.ev_stop && !exact_done;
 	const size_t units = exact_done ? 0 : k_exact * groups;
