@@ -392,6 +392,17 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
         assert int(r["rc"]) == 0 and int(r["left"]) == 0
         assert r["audio"].size == g["audio"].size
         assert np.abs(r["audio"] - g["audio"]).max() <= tol
+    # one block late: FileTuner alternates between two byte buffers and its run() no longer waits for the transfer of the
+    # block it has just handed out (RawU8Block::rawU8Buffers, wr_dev_wait_uploads_but) -- the same audio, a block later
+    # (silence first, the last block's audio dropped at stop())
+    for late in ("1", "2"):
+        subprocess.check_call([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
+                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_AUDIO_LATE=late))
+        r = np.load(out)
+        assert int(r["rc"]) == 0 and int(r["left"]) == 0 and r["audio"].size == g["audio"].size
+        per = g["audio"].size // 4 * int(late)
+        assert not r["audio"][:per].any()
+        assert np.abs(r["audio"][per:] - g["audio"][:-per]).max() <= 4.8e-7
 
 
 STRESS_RUNNER = r'''
