@@ -172,14 +172,12 @@ int wr_demod(wr_dev *dev, int mode, const float *in_dev, size_t nframes,
 
 /* RTL-SDR byte format to float, (u8 - 128)/128 (io/rtlsdrtuner.cxx:106) */
 int wr_u8_to_f32(wr_dev *dev, const uint8_t *in_dev, float *out_dev, size_t count);
-/* the same straight out of HOST memory page-locked with wr_dev_host_register: the kernel reads the bytes over
- * PCIe itself -- one launch instead of a copy and a launch, and a quarter of the float block's bytes.  Counts
- * as an upload in flight: the host buffer must not be rewritten until wr_dev_wait_uploads (or wr_dev_sync).
- * The conversion runs on a stream of the library's own and the device's stream waits for it, so work enqueued after
- * the call sees `out_dev` filled -- and a caller that ALTERNATES between two `out_dev` buffers gets the transfer of
- * block b + 1 beside the kernels of block b: the conversion waits only for the work that was enqueued before the call
- * after the last one that wrote the same `out_dev` (rule for the caller: once the next block has been converted into
- * the other buffer, enqueue no more readers of this one). */
+/* the same straight out of HOST memory page-locked with wr_dev_host_register -- a quarter of the float block's
+ * bytes over PCIe.  Counts as an upload in flight: the host buffer must not be rewritten until wr_dev_wait_uploads
+ * (or wr_dev_sync; wr_dev_wait_uploads_but for a source that alternates between buffers).
+ * The bytes cross PCIe as a DMA copy on a stream of the library's own (into one of two internal raw buffers in turn), the
+ * device's stream waits for the copy and converts: work enqueued after the call sees `out_dev` filled, in stream order
+ * like any kernel's output, and the transfer of block b + 1 runs beside the kernels of block b. */
 int wr_u8_to_f32_from_host(wr_dev *dev, const uint8_t *in_host_registered, float *out_dev, size_t count);
 
 /* ------------------------------------------------- fused per-tuner path -- */

@@ -727,30 +727,41 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 		            hipGetErrorString(e));
 	}
 	std::lock_guard<std::mutex> up_guard(*d->upload_lock);         /* the ring of tails: calls may come from several threads */
-	unsigned long long n = 0;
-	if (int rc = upload_ahead_begin(d, (void *)out_dev, &n))
-		return rc;
 	/* The bytes come over with the DMA engine and are converted out of device memory.  (r03 tried the kernel reading
 	 * host memory itself, WR_U8_ZEROCOPY=1: one launch and 47 GB/s -- but kernels running beside it take up to ten times
 	 * as long, k_tuner_post 14 -> 107 us, a 32 MB device copy 13 -> 146 us: its reads, microseconds each, sit in the
 	 * same L2 / fabric queues as everybody's HBM traffic.  A DMA copy does not go through them.) */
 	static const bool zerocopy = getenv("WR_U8_ZEROCOPY") && atoi(getenv("WR_U8_ZEROCOPY")) != 0;
 	if (zerocopy) {
+		unsigned long long n = 0;
+		if (int rc = upload_ahead_begin(d, (void *)out_dev, &n))
+			return rc;
 		HIP_TRY(wrk_u8_to_f32(d->up_stream, (const uint8_t *)mapped, out_dev, count));
-	} else {
-		const unsigned int rb = (unsigned int)(n & 1u);
-		if (d->up_raw_cap[rb] < count) {
-			HIP_TRY(hipStreamSynchronize(d->up_stream));
-			(void)hipFree(d->up_raw[rb]);
-			d->up_raw[rb] = nullptr;
-			d->up_raw_cap[rb] = 0;
-			HIP_TRY(hipMalloc((void **)&d->up_raw[rb], count));
-			d->up_raw_cap[rb] = count;
-		}
-		HIP_TRY(hipMemcpyAsync(d->up_raw[rb], in_host, count, hipMemcpyHostToDevice, d->up_stream));
-		HIP_TRY(wrk_u8_to_f32(d->up_stream, d->up_raw[rb], out_dev, count));
+		return upload_ahead_end(d);
 	}
-	return upload_ahead_end(d);
+	/* Only the COPY runs on the upload stream, into one of two raw buffers in turn; the conversion follows on the device's
+	 * stream once the copy's event has fired.  So the copies of consecutive blocks follow each other on the link without
+	 * a kernel in between (the upload stream waits for nothing but the conversion that last read the raw buffer it is about
+	 * to overwrite -- two calls ago), and `out_dev` is written in stream order like any kernel's output. */
+	const unsigned int rb = (unsigned int)(d->up_calls & 1u);
+	if (d->up_raw_cap[rb] < count) {
+		if (d->up_stream)
+			HIP_TRY(hipStreamSynchronize(d->up_stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));
+		(void)hipFree(d->up_raw[rb]);
+		d->up_raw[rb] = nullptr;
+		d->up_raw_cap[rb] = 0;
+		HIP_TRY(hipMalloc((void **)&d->up_raw[rb], count));
+		d->up_raw_cap[rb] = count;
+	}
+	unsigned long long n = 0;
+	if (int rc = upload_ahead_begin(d, (void *)d->up_raw[rb], &n))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(d->up_raw[rb], in_host, count, hipMemcpyHostToDevice, d->up_stream));
+	if (int rc = upload_ahead_end(d))                          /* the host buffer is free again when the COPY is done */
+		return rc;
+	HIP_TRY(wrk_u8_to_f32(d->stream, d->up_raw[rb], out_dev, count));
+	return WR_OK;
 }
 
 /* WR_LONG_ROTATE=0: channel filters of 128 / 256 taps take the reference's arithmetic in every nco mode (r03's first version) */
