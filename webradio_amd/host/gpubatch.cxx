@@ -85,8 +85,8 @@ wr_dev *device(int index)
  * rtlsdrtuner.cxx:280), so they are page-locked once and the copy is a DMA nobody waits for */
 struct SourceStage {
 	DevBuf buf;
-	DevBuf buf2;                /* raw blocks converted out of page-locked memory alternate between `buf` and `buf2`: the
-	                               bytes of block b + 1 cross PCIe while block b is being worked on (wr_u8_to_f32_from_host) */
+	DevBuf buf2;                /* a float source's blocks alternate between `buf` and `buf2`: block b + 1 crosses PCIe on the
+	                               upload stream while block b is being worked on (wr_dev_upload_ahead) */
 	bool second;
 	DevBuf raw;                 /* the block as the source holds it in the RTL-SDR byte format (RawU8Block), on the device */
 	unsigned long epoch;
@@ -225,12 +225,10 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 		const uint8_t *rawBytes = rawsrc ? rawsrc->rawU8(&rawFrames) : NULL;
 		if (rawBytes && rawFrames * 2 == host.size() && !envUnsigned("WEBRADIO_NO_U8_STAGING", 0)) {
 			const bool pinned = st->pin(dev, rawBytes, host.size());
-			/* page-locked: the conversion kernel reads the bytes over PCIe itself (one launch, nothing the host
-			 * waits for), into the buffer the LAST block was not staged in; else a staged copy and the kernel on
-			 * the device copy */
-			if (pinned)
-				st->second = !st->second;
-			DevBuf &dst = (pinned && st->second) ? st->buf2 : st->buf;
+			/* page-locked: the bytes cross PCIe as a DMA copy on the library's upload stream, beside the kernels of
+			 * the block before, and are converted on the device (wr_u8_to_f32_from_host: nothing the host waits
+			 * for); else a staged copy and the kernel on the device copy */
+			DevBuf &dst = st->buf;
 			if (!dst.reserve(dev, bytes) ||
 			    (pinned ? wr_u8_to_f32_from_host(dev, rawBytes, (float *)dst.ptr, host.size())
 			            : (!st->raw.reserve(dev, host.size()) ||
