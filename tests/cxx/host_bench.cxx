@@ -140,10 +140,22 @@ int main(int argc, char **argv)
 	}
 	for (int w = 0; w < 8; w++)                              /* warm-up (allocations, page locks, the clocks' ramp) */
 		Radio::run();
+	std::vector<double> per;                                 /* WR_HOST_BENCH_TIMES=1: every run()'s own duration */
+	const bool times = getenv("WR_HOST_BENCH_TIMES") != NULL;
 	const double t0 = now();
-	for (unsigned int b = 0; b < blocks; b++)
+	for (unsigned int b = 0; b < blocks; b++) {
+		const double a = times ? now() : 0.0;
 		Radio::run();
+		if (times)
+			per.push_back(now() - a);
+	}
 	const double dt = now() - t0;
+	if (times) {
+		fprintf(stderr, "run() us:");
+		for (size_t n = 0; n < per.size() && n < 48; n++)
+			fprintf(stderr, " %.0f", per[n] * 1e6);
+		fprintf(stderr, "\n");
+	}
 	double sum = 0;
 	unsigned long total = 0;
 	for (size_t n = 0; n < rx.size(); n++) {
