@@ -52,8 +52,26 @@ extern "C" int wr_debug_timeline_rt(unsigned long long *out, size_t n)
 {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_rt), n * sizeof(unsigned long long));
 }
+/* where the wave ran: HW_ID (gfx9: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]) and XCC_ID[3:0] */
+__device__ unsigned int g_ddc_hw[16384 * 2];
+extern "C" int wr_debug_timeline_hw(unsigned int *out, size_t n)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_hw), n * sizeof(unsigned int));
+}
+extern "C" int wr_debug_timeline_reset(void)
+{
+	void *p = nullptr;
+	if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ddc_tl)) == hipSuccess)
+		(void)hipMemset(p, 0, sizeof(g_ddc_tl));
+	if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ddc_rt)) == hipSuccess)
+		(void)hipMemset(p, 0, sizeof(g_ddc_rt));
+	if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ddc_hw)) == hipSuccess)
+		(void)hipMemset(p, 0, sizeof(g_ddc_hw));
+	return 0;
+}
 #define TL(slot) do { if (lane == 0 && wid < 16384u && (slot) < TL_SLOTS) { g_ddc_tl[wid * TL_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); \
-	if ((slot) == 0 || (slot) == 11) g_ddc_rt[wid * 2u + ((slot) ? 1u : 0u)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+	if ((slot) == 0 || (slot) == 11) g_ddc_rt[wid * 2u + ((slot) ? 1u : 0u)] = __builtin_amdgcn_s_memrealtime(); \
+	if ((slot) == 0) { g_ddc_hw[wid * 2u] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_ddc_hw[wid * 2u + 1u] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } } while (0)
 /* the post-stage tenants of the same launch: wave start, stage phase done, filter done, wave end (of
  * the last tile of a run) */
 __device__ unsigned long long g_post_tl[8192 * 4];
