@@ -400,9 +400,10 @@ def run_c5(args, torch, dist, rank, world, device_index):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "the launches of one step -- k_seek, k_tuner_ddc on [halo | chunk], k_tuner_post (the demod + audio "
-                          "filter run on their own here: wr_tuner_seek needs the previous chunk's finished) -- timed "
-                          "together: kernel_ms is the mean per step over groups of consecutive steps",
+                "kernel": "k_tuner_ddc on [halo | chunk], ONE launch per step since r03: wr_tuner_seek launches nothing (the "
+                          "DDC takes the phase in closed form and reads all-zero state sets) and the demod + audio filter of the "
+                          "chunk before ride in it; kernel_ms is the mean per step over groups of consecutive steps "
+                          "(WR_LAZY_SEEK=0: k_seek, k_tuner_ddc, k_tuner_post as three launches, r02's schedule)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                 "kernel_ms": round(ddc_ms, 5), "launches_timed": launches,

@@ -326,7 +326,11 @@ int wr_chan_reset_history(wr_tuner *tuner, int chan);
  * DownConverter::phase, which takes its closed-form value after `frame` input frames from
  * phase 0 (downconverter.cxx:103).  A block [halo | chunk] submitted next reproduces the
  * sequential result for the chunk once the first halo/(D1*D2) audio frames are dropped
- * (webradio_amd/timeshard.py).  One call, no per-channel traffic. */
+ * (webradio_amd/timeshard.py).  One call, no per-channel traffic -- and no launch: the next submit's launch
+ * computes the phase itself and reads all-zero state sets, and a block's demodulator + audio filter that are
+ * still waiting for that submit ride in it as usual (one launch per chunk).  Whatever else touches the tuner's
+ * state in between (a getter, a setter, a kept demodulator stage, a second or a long channel-filter stage)
+ * makes the seek real first. */
 int wr_tuner_seek(wr_tuner *tuner, unsigned long long frame);
 /* The halo ring of such a time-sharded stream (chunk c on rank c mod world, the halo of
  * every chunk -- the last H frames of the one before it, webradio_amd/timeshard.py: halo_frames --

@@ -46,6 +46,54 @@ def test_time_shard_single_rank_bit_identical(dev, nco):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("between", ["nothing", "getter", "setter", "seek_twice", "kept_demod", "no_fetch"])
+def test_lazy_seek_equals_the_sequential_pass(dev, between):
+    """r03: wr_tuner_seek launches nothing where the next submit's DDC can take the phase in closed form and read
+    all-zero state sets (one launch per chunk: the post stage of the chunk before rides in it).  Whatever comes between
+    the seek and the submit -- a getter, a setter (its group upload), a second seek, the demodulator rows kept (two-kernel
+    path: the seek is made real first) -- and also when NOTHING is fetched between the chunks (so that the chunk before
+    really rides), every chunk is the sequential pass's bits."""
+    nco = capi.WR_NCO_ROTATE if between == "no_fetch" else capi.WR_NCO_EXACT     # (ROTATE: the mode whose post stage rides)
+    iq = _stream()
+    H = timeshard.halo_frames(D1, D2)
+    t = Tuner(dev, FS, len(IFS), T + H, nco)
+    chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_FM, 160, 1_000) for f in IFS]
+    if between == "kept_demod":
+        t.keep_stages(capi.WR_STAGE_DEMOD)
+    if between == "no_fetch":
+        t.audio_ring(N)
+    drop = H // (D1 * D2)
+    got = []
+    for c in range(N):
+        first = max(0, c * T - H)
+        block = iq[2 * first: 2 * (c + 1) * T]
+        if between == "seek_twice":
+            t.seek(12345)
+        t.seek(first)
+        if between == "getter":
+            ph, prev = t.state(chans[1])
+            assert not prev.any()
+        if between == "setter":
+            t.set_if(chans[2], IFS[2])                       # the same value: marks the group for an upload
+        t.submit_host(block)
+        if between != "no_fetch":
+            a = np.stack([t.fetch(ch, capi.WR_STAGE_AUDIO, T + H) for ch in chans])
+            got.append(a[:, (drop if c else 0):])
+    if between == "no_fetch":
+        t.flush()
+        for c in range(N):
+            a, seq = t.ring_acquire()
+            t.ring_release()
+            assert seq == c
+            slots = [t.slot(ch) for ch in chans]
+            got.append(a[slots][:, (drop if c else 0):])
+    t.destroy()
+    got = np.concatenate(got, axis=1)
+    want = _sequential(dev, nco)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_native_ring_world_one_bit_identical(dev):
     """The C ABI's halo ring (wr_ring_*: ncclSend / ncclRecv on RCCL, its own stream, events to the device's
     stream) at world size 1, where the rank is its own neighbour: every chunk's halo really travels through

@@ -128,6 +128,13 @@ struct Group {
 	 * k_tuner_ddc) or, when somebody needs the results first, on its own (tuner_flush). */
 	bool post_pending = false;
 	WrPostArgs post_args;
+	/* wr_tuner_seek, lazily: the next submit's launch takes the phase in closed form (WrTunerLaunch::seeking) and reads
+	 * all-zero state sets (z_hist: LO rows; z_prev; z_dem), so a seek costs no launch of its own and the post stage of the
+	 * chunk before may still ride in that launch.  Anything else that touches the group's state first makes it real
+	 * (seek_materialize: k_seek on the actual sets, as before r03). */
+	bool seek_pending = false;
+	unsigned long long seek_frame = 0;
+	float *z_hist = nullptr, *z_prev = nullptr, *z_dem = nullptr;
 	unsigned long long pend_seq = 0;   /* ring bookkeeping of that block */
 	size_t pend_k2 = 0;
 	unsigned int pend_slots = 0;
@@ -764,6 +771,12 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 	return WR_OK;
 }
 
+static bool lazy_seek_enabled()
+{
+	static const bool on = !(getenv("WR_LAZY_SEEK") && atoi(getenv("WR_LAZY_SEEK")) == 0);
+	return on;
+}
+
 /* WR_LONG_ROTATE=0: channel filters of 128 / 256 taps take the reference's arithmetic in every nco mode (r03's first version) */
 static bool long_rot_enabled()
 {
@@ -812,6 +825,9 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.mixhist[1]);
 	(void)hipFree(g->dev.gain);
 	(void)hipFree(g->dev.squelch);
+	(void)hipFree(g->z_hist);
+	(void)hipFree(g->z_prev);
+	(void)hipFree(g->z_dem);
 	(void)hipFree(g->dev.prev_iq[0]);
 	(void)hipFree(g->dev.prev_iq[1]);
 	(void)hipFree(g->dev.chan_iq[0]);
@@ -875,6 +891,9 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 		if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq2[0], (g->k1max / d1b + 1) * S * 2);
 		if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq2[1], (g->k1max / d1b + 1) * S * 2);
 	}
+	if (!rc) rc = dev_alloc_zero(&g->z_hist, (size_t)WR_HIST * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->z_prev, S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->z_dem, (size_t)WR_HIST * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
@@ -1369,11 +1388,25 @@ static int tuner_flush(wr_tuner *t)
 
 /* host is about to touch device arrays the kernels of the last submit read or write: get the
  * pending post stage out, then drain the stream */
+static int seek_materialize(wr_tuner *t, Group *g)
+{
+	if (!g->seek_pending)
+		return WR_OK;
+	/* (a post stage still waiting for the next submit would write ITS end-of-block state over the seek's: the caller
+	 * has flushed) */
+	g->seek_pending = false;
+	HIP_TRY(wrk_seek(t->dev->stream, g->dev, (unsigned int)g->slots, g->sp, g->parity, g->p2, g->seek_frame));
+	return WR_OK;
+}
+
 static int tuner_quiesce(wr_tuner *t)
 {
 	int rc = tuner_flush(t);
 	if (rc)
 		return rc;
+	for (Group *g : t->groups)
+		if ((rc = seek_materialize(t, g)) != WR_OK)
+			return rc;
 	HIP_TRY(hipStreamSynchronize(t->dev->stream));
 	return WR_OK;
 }
@@ -1824,6 +1857,32 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			HIP_TRY(hipEventRecord(t->ev[t->ev_used], st));
 			t->ev_used += 1;
 		}
+		/* a seek that is still pending (wr_tuner_seek): this launch takes the phase in closed form and reads the
+		 * all-zero state sets; with the demodulator rows kept (two kernels) it is made real first */
+		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
+		WrGroupDev Gs = g->dev;
+		if (g->seek_pending) {
+			if (two_kernels || g->d1b || g->l1 > WR_FIR_LENGTH) {
+				if (g->post_pending) {
+					HIP_TRY(wrk_tuner_post_args(st, g->post_args));
+					g->post_pending = false;
+					int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots);
+					if (rc)
+						return rc;
+				}
+				int rc = seek_materialize(t, g);
+				if (rc)
+					return rc;
+			} else {
+				L.seeking = true;
+				L.seek_lo = (unsigned int)g->seek_frame;
+				Gs.hist_cs[g->sp] = g->z_hist;
+				Gs.hist_lo[g->sp] = g->z_hist;
+				Gs.prev_iq[g->parity] = g->z_prev;
+				Gs.dem[g->parity] = g->z_dem;
+				g->seek_pending = false;
+			}
+		}
 		/* The previous block's post stage rides along with this block's DDC where the kernel
 		 * variant can take it (wrk_tuner_ddc says); otherwise it goes out on its own first. */
 		bool rode = false;
@@ -1833,7 +1892,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			HIP_TRY(wrk_tuner_ddc_long(st, L, g->dev, g->l1, d->table, d->num_cus,
 			                           t->nco_mode != WR_NCO_EXACT && g->long_uniform && long_rot_enabled(), g->long_one, d->hi_cs, d->lo_cs));
 		else
-			HIP_TRY(wrk_tuner_ddc(st, L, g->dev, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
+			HIP_TRY(wrk_tuner_ddc(st, L, Gs, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 			                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
 		if (prof_now) {
 			t->ev_span.resize(t->ev_used / 2 + 1, 1u);
@@ -1850,7 +1909,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		/* A second channel-filter stage sits between the DDC and the demodulator: its kernel runs
 		 * here, and everything after it works on ITS output (chan_iq2) at ITS rate. */
 		WrTunerLaunch Lp = L;
-		WrGroupDev Gp = g->dev;
+		WrGroupDev Gp = Gs;
 		if (g->d1b) {
 			HIP_TRY(wrk_tuner_iq2(st, g->dev, g->slots, L.slots_used, L.k1, g->d1b, g->cb, g->p2));
 			g->p2 ^= 1;
@@ -1862,7 +1921,6 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		/* demodulator output wanted (wr_tuner_keep_stages) or an unusual audio decimation: demod
 		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
-		const bool two_kernels = (t->keep_mask & (1u << WR_STAGE_DEMOD)) != 0 || !wrk_tuner_post_supported(L.d2);
 		const bool defer = !two_kernels && !g->d1b && g->l1 <= WR_FIR_LENGTH && L.k1 && t->defer_post &&
 		                   t->nco_mode == WR_NCO_ROTATE;
 		if (two_kernels) {
@@ -1870,7 +1928,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			HIP_TRY(wrk_tuner_audio(st, Lp, Gp));
 		} else if (defer) {
 			g->post_pending = true;
-			g->post_args = wrk_post_args(L, g->dev);
+			g->post_args = wrk_post_args(L, Gs);
 			g->pend_seq = seq;
 			g->pend_k2 = L.k2;
 			g->pend_slots = L.slots_used;
@@ -2260,14 +2318,26 @@ extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
 	if (dev_bind(d))
 		return WR_ERR_HIP;
 	hipStream_t st = d->stream;
-	/* a post stage still waiting for the next submit would write ITS end-of-block state over ours */
-	int rc = tuner_flush(t);
+	int rc = tuner_launch_held(t);
 	if (rc)
 		return rc;
 	for (Group *g : t->groups) {
 		if (g->dirty) {
 			rc = group_upload(t, g);
 			if (rc)
+				return rc;
+		}
+		/* Lazily where the group's launch can take it (one channel-filter stage of up to 64 taps): nothing is launched
+		 * here, the next submit's DDC computes the phase in closed form and reads all-zero state sets, and the post
+		 * stage of the chunk before, if it is still waiting, rides in that launch as usual -- a time-sharded stream
+		 * (BASELINE config 5) then costs ONE launch per chunk instead of three (seek, DDC, post stage).
+		 * WR_LAZY_SEEK=0: as before. */
+		const bool lazy = !g->d1b && g->l1 <= WR_FIR_LENGTH && lazy_seek_enabled();
+		if (!lazy && g->post_pending) {
+			/* a post stage still waiting for the next submit would write ITS end-of-block state over ours */
+			HIP_TRY(wrk_tuner_post_args(st, g->post_args));
+			g->post_pending = false;
+			if ((rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots)) != WR_OK)
 				return rc;
 		}
 		const size_t S = g->slots;
@@ -2280,6 +2350,12 @@ extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
 			c.phase_dirty = c.prev_dirty = c.cs_hist_reset = c.dem_hist_reset = false;
 			c.prev_iq[0] = c.prev_iq[1] = 0.0f;
 		}
+		if (lazy) {
+			g->seek_pending = true;
+			g->seek_frame = frame;
+			continue;
+		}
+		g->seek_pending = false;
 		/* on the device from the step array itself: no host data in flight, nothing to wait for */
 		HIP_TRY(wrk_seek(st, g->dev, (unsigned int)S, g->sp, g->parity, g->p2, frame));
 		if (g->l1 > WR_FIR_LENGTH)

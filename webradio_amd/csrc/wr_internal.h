@@ -101,6 +101,9 @@ struct WrTunerLaunch {
 	unsigned char nsets[64];           /* distinct channel filters of lane group g (valid where fewsets_mask says) */
 	int          one_filter;           /* every channel of the rate group uses ONE and the same channel filter */
 	void        *ev_start, *ev_stop;   /* hipEvent_t pair the DDC launch itself stamps (profiling), or NULL */
+	bool         seeking = false;      /* the first block after wr_tuner_seek: phase = frame * step in closed form, the state sets
+	                                      handed to the launch are all-zero ones (wr_capi.hip: seek_pending) */
+	unsigned int seek_lo = 0;          /* the frame's low 32 bits */
 };
 
 /* ---- kernel launchers (wr_kernels.hip); all return hipError_t ---- */

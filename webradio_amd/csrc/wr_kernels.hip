@@ -793,11 +793,19 @@ k_tuner_post(WrPostArgs A)
 	const int *__restrict__ tapsel, unsigned int kmax, float2 *__restrict__ chan_iq, \
 	const float *__restrict__ table, const float2 *__restrict__ hi_cs, const float2 *__restrict__ lo_cs, \
 	unsigned int n_ddc, const WrPostArgs &post, unsigned long long gmap0, unsigned long long gmap1, int whole, \
-	unsigned int kslow, unsigned int n_bnd
+	unsigned int kslow, unsigned int n_bnd, unsigned int seek_on, unsigned int seek_lo
 #define DDC_PASS \
 	cur, cur_u8, hist, hist_next, nframes, k1, d1, slots, groups, phase, step, hist_cs, flags, phase_next, hist_cs_next, \
 	hist_lo, hist_lo_next, taps1, rot, taps1u, tapsel, kmax, chan_iq, table, hi_cs, lo_cs, n_ddc, post, gmap0, gmap1, \
-	whole, kslow, n_bnd
+	whole, kslow, n_bnd, seek_on, seek_lo
+/* the channel's phase at the block's first frame: kept from the block before, or -- the launch right after a
+ * wr_tuner_seek (`seek_on`; the histories it reads are all-zero sets then) -- frame * step mod 2^32 in closed form
+ * (downconverter.cxx:103), `seek_lo` = the frame's low 32 bits */
+#ifdef DDC_NO_LAZY_SEEK                          /* (timing comparisons only) */
+#define DDC_PHASE(s_) (phase[s_])
+#else
+#define DDC_PHASE(s_) (seek_on ? step[s_] * seek_lo : phase[s_])
+#endif
 #define DDC_ROLE_ALL      0                /* no roles: every frame, the state roll, the riding post stage */
 #define DDC_ROLE_BOUNDARY 1                /* one block-boundary unit per wave (or the post stage, by workgroup index) */
 #define DDC_ROLE_ROLL     2                /* the end-of-block state roll only */
@@ -941,7 +949,7 @@ ddc_body(DDC_PARAMS, v2f *lds, const int role)
 	if (k < k1u) {
 		{
 			/* one coalesced load each (WrGroupDev::rot, taps1u), all independent of one another */
-			p0 = phase[s];
+			p0 = DDC_PHASE(s);
 			st = step[s];
 			fl = flags[s];
 			if (NCO == WR_NCO_ROTATE) {
@@ -1251,7 +1259,7 @@ ddc_body(DDC_PARAMS, v2f *lds, const int role)
 		const unsigned int gtid = (blockIdx.x - roll_first) * blockDim.x + threadIdx.x, gsz = (n_ddc - roll_first) * blockDim.x;
 		for (unsigned int s = gtid; s < slots; s += gsz) {
 			const bool act = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
-			phase_next[s] = act ? phase[s] + nlo * step[s] : phase[s];
+			phase_next[s] = act ? DDC_PHASE(s) + nlo * step[s] : DDC_PHASE(s);
 		}
 		for (unsigned int e = gtid; e < WR_HIST * slots; e += gsz) {
 			const unsigned int r = e / slots, s = e - r * slots;
@@ -1265,7 +1273,7 @@ ddc_body(DDC_PARAMS, v2f *lds, const int role)
 						const float2 o = hist_lo[f * slots + s];
 						lo = (v2f){o.x, o.y};
 					} else {
-						lo = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
+						lo = nco<NCO>(DDC_PHASE(s) + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
 					}
 				}
 				hist_lo_next[e] = make_float2(lo.x, lo.y);
@@ -1280,9 +1288,9 @@ ddc_body(DDC_PARAMS, v2f *lds, const int role)
 					 * into the next block's first frame: made with THIS block's step, as the
 					 * reference adds phase_step right after using a frame.)  A zero row = nothing
 					 * before that frame counts, which is also how a fresh channel starts. */
-					cs = rot_into(phase[s], step[s], (unsigned int)(f - (WR_HIST - 1)), table);
+					cs = rot_into(DDC_PHASE(s), step[s], (unsigned int)(f - (WR_HIST - 1)), table);
 				} else {
-					cs = nco<NCO>(phase[s] + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
+					cs = nco<NCO>(DDC_PHASE(s) + (unsigned int)(f - WR_HIST) * step[s], table, hi_l, lo_l);
 				}
 			}
 			hist_cs_next[e] = make_float2(cs.x, cs.y);
@@ -1333,7 +1341,8 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
             float2 *__restrict__ chan_iq,
             const float *__restrict__ table, const float2 *__restrict__ hi_cs,
             const float2 *__restrict__ lo_cs, unsigned int n_ddc, WrPostArgs post,
-            unsigned long long gmap0, unsigned long long gmap1, int whole, unsigned int kslow, unsigned int n_bnd)
+            unsigned long long gmap0, unsigned long long gmap1, int whole, unsigned int kslow, unsigned int n_bnd,
+            unsigned int seek_on, unsigned int seek_lo)
 {
 	extern __shared__ v2f lds[];                /* see DDC_LDS_BYTES */
 	constexpr bool ROLES = DDC_ROLES && NCO == WR_NCO_ROTATE && UTAPS;
@@ -1412,7 +1421,7 @@ k_tuner_ddc(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8,
 				g0 = g;
 				s0 = s;
 			}
-			const unsigned int p0 = phase[s];
+			const unsigned int p0 = DDC_PHASE(s);
 			stv[c] = step[s];
 			fl[c] = flags[s];
 			const float4 r4 = rot[s];
@@ -2330,7 +2339,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		                      G.phase[L.sp ^ 1], (float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp],
 		                      (float2 *)G.hist_lo[L.sp ^ 1], (const float *)G.taps1, (const float4 *)G.rot, (const float *)G.taps1u,
 		                      (const int *)G.tapsel, kmax, (float2 *)G.chan_iq[L.cb], table_dev,
-		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0, kslow, n_bnd);
+		                      (const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0, kslow, n_bnd, L.seeking ? 1u : 0u, L.seek_lo);
 		return hipGetLastError();
 	}
 	k_tuner_ddc<NCO, UTAPS, PD2, NG><<<wgs + n_bnd + post_wgs, W * 64u, lds, st>>>(
@@ -2339,7 +2348,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		L.slots, ngroups, G.phase[L.sp], G.step, (const float2 *)G.hist_cs[L.sp], G.flags, G.phase[L.sp ^ 1],
 		(float2 *)G.hist_cs[L.sp ^ 1], (const float2 *)G.hist_lo[L.sp], (float2 *)G.hist_lo[L.sp ^ 1], G.taps1,
 		(const float4 *)G.rot, G.taps1u, G.tapsel, kmax, (float2 *)G.chan_iq[L.cb], table_dev,
-		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0, kslow, n_bnd);
+		(const float2 *)hi_dev, (const float2 *)lo_dev, wgs, pa, gmap[0], gmap[1], whole ? 1 : 0, kslow, n_bnd, L.seeking ? 1u : 0u, L.seek_lo);
 	return hipGetLastError();
 }
 
