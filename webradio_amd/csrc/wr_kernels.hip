@@ -2507,8 +2507,15 @@ hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A0)
 	 * workgroup, all of them in flight at once (runs of tiles are for the workgroups that ride in a
 	 * DDC launch, where instructions are what is short); 15.4 against 18.2 us for a C2 block */
 	WrPostArgs A = A0;
-	A.run = 1u;
-	A.ntiles = A.tiles;
+	{
+		/* ... unless there are tiles enough to fill the chip several times over anyway (the flush behind a launch of
+		 * several blocks): runs of tiles then save the rows two neighbouring tiles share from being loaded and
+		 * demodulated twice (59 of 139 at D2 = 5) -- WR_POST_FLUSH_RUN overrides */
+		static const int forced = getenv("WR_POST_FLUSH_RUN") ? atoi(getenv("WR_POST_FLUSH_RUN")) : 0;
+		const unsigned int all = A.tiles * A.groups;
+		A.run = forced > 0 ? (unsigned int)forced : all >= 4096u ? 2u : 1u;   /* C2, four blocks: 43.6 / 33.6 / 36.0 us at runs of 1 / 2 / 4 */
+	}
+	A.ntiles = (A.tiles + A.run - 1u) / A.run;
 	switch (A.d2) {
 	case 1: return launch_post<1>(st, A);
 	case 2: return launch_post<2>(st, A);
