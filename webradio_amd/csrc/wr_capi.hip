@@ -2155,9 +2155,13 @@ static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, u
 		r.cap = want;
 	}
 	hipStream_t st = t->dev->stream;
-	if (need)
-		HIP_TRY(hipMemcpy2DAsync(r.host, k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
-		                         k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));
+	if (need) {
+		if (k2 == g->k2max)                     /* rows back to back (the usual block size): one linear copy */
+			HIP_TRY(hipMemcpyAsync(r.host, g->dev.audio, need * sizeof(float), hipMemcpyDeviceToHost, st));
+		else
+			HIP_TRY(hipMemcpy2DAsync(r.host, k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
+			                         k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));
+	}
 	HIP_TRY(hipEventRecord(r.done, st));
 	r.stride = r.frames = k2;
 	r.slots = used;
