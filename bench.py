@@ -301,6 +301,7 @@ def run_c5(args, torch, dist, rank, world, device_index):
     ring = None
     if native:
         ring = timeshard.RingHalo(dist, rank, world, dev=dev)        # wr_ring_* on RCCL
+        tuner.mark_launches(True)                                    # the exchanges wait for the tuner's launches, not the stream
     elif world > 1:
         ring = timeshard.RingHalo(dist, rank, world)                 # torch.distributed (gloo: host tensors)
     posted = [None]
@@ -321,9 +322,9 @@ def run_c5(args, torch, dist, rank, world, device_index):
             # the halo is input, not a result: round i + 1's pair goes out on the ring's own stream before this
             # round's chunk is submitted and travels while it computes; nothing here waits on the host
             if posted[0] is None:
-                ring.post(tail_of(i), halo_of(i))
+                ring.post(tail_of(i), halo_of(i), tuner)
             ring.wait()                                     # round i's pair (and rank 0's halo, which came a round earlier)
-            ring.post(tail_of(i + 1), halo_of(i + 1))
+            ring.post(tail_of(i + 1), halo_of(i + 1), tuner)
             posted[0] = i + 1
         elif world == 1:
             bufs[(i + 1) % nb][:2 * H].copy_(tail)          # next chunk's halo: a device copy

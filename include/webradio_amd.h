@@ -353,6 +353,14 @@ int wr_ring_version(int *version);                 /* ncclGetVersion of the RCCL
 int wr_ring_make_id(void *id_host, size_t nbytes);
 int wr_ring_create(wr_ring **ring, wr_dev *dev, const void *id_host, size_t nbytes, int rank, int world);
 int wr_ring_exchange(wr_ring *ring, const float *send_dev, float *recv_dev, size_t nfloats);
+/* The same, ordered behind the TUNER's launches so far instead of behind everything the device's stream holds: for a
+ * halo that is input (already in device memory) received into a buffer only the tuner reads.  Needs
+ * wr_tuner_mark_launches(tuner, 1): every launch that reads a submitted block then stamps an event with its own
+ * completion signal, and the exchange waits for that -- nothing is put on the device's stream (an event record there
+ * sits between two launches: 11 us a chunk).  The rule for the caller: `send_dev` is complete when the call is made,
+ * `recv_dev` has no reader other than blocks already submitted to `tuner`. */
+int wr_tuner_mark_launches(wr_tuner *tuner, int enable);
+int wr_ring_exchange_after(wr_ring *ring, wr_tuner *tuner, const float *send_dev, float *recv_dev, size_t nfloats);
 int wr_ring_wait(wr_ring *ring);
 int wr_ring_info(wr_ring *ring, int *rank, int *world, unsigned long long *exchanges);
 int wr_ring_destroy(wr_ring *ring);

@@ -115,6 +115,61 @@ def test_native_ring_world_one_bit_identical(dev):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_ring_exchange_after_the_tuners_launches(dev):
+    """wr_ring_exchange_after + wr_tuner_mark_launches, used the way bench.py --workload c5 uses them: resident chunks in a
+    rotation of three [halo | chunk] buffers, every halo through ncclSend / ncclRecv (world 1: to itself), posted a round
+    ahead and ordered behind the TUNER's launches (their own completion events) instead of an event record on the
+    device's stream; nothing fetched between the chunks (one launch per chunk: lazy seek, riding post stage).
+    The audio is the sequential pass's, bit for bit."""
+    import torch
+    nco = capi.WR_NCO_ROTATE
+    H = timeshard.halo_frames(D1, D2)
+    iq = torch.from_numpy(_stream()).cuda()
+    nb = 3
+    bufs = [torch.zeros(2 * (H + T), device="cuda") for _ in range(nb)]
+    t = Tuner(dev, FS, len(IFS), T + H, nco)
+    chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_FM, 160, 1_000) for f in IFS]
+    t.audio_ring(N)
+    t.mark_launches(True)
+    ring = timeshard.RingHalo(None, 0, 1, dev=dev)
+
+    def load(c):                                              # chunk c into its buffer (behind the halo)
+        bufs[c % nb][2 * H:].copy_(iq[2 * c * T: 2 * (c + 1) * T])
+
+    load(0)
+    for c in range(N):
+        if c + 1 < N:
+            load(c + 1)
+            # chunk c + 1's halo = the last H frames of chunk c: to the ring neighbour (ourselves), a round ahead
+            ring.post(bufs[c % nb][2 * T:], bufs[(c + 1) % nb][: 2 * H], t)
+        if c == 0:
+            t.seek(0)
+            t.submit_device(bufs[0][2 * H:], T)
+        else:
+            t.seek(c * T - H)
+            t.submit_device(bufs[c % nb], H + T)
+        if c + 1 < N:
+            ring.wait()                                       # before the next chunk's submit reads its halo
+    t.flush()
+    got = []
+    drop = H // (D1 * D2)
+    slots = [t.slot(ch) for ch in chans]
+    for c in range(N):
+        a, seq = t.ring_acquire()
+        t.ring_release()
+        assert seq == c
+        got.append(a[slots][:, (drop if c else 0):])
+    assert ring.native.exchanges() == N - 1
+    ring.close()
+    t.destroy()
+    got = np.concatenate(got, axis=1)
+    want = _sequential(dev, nco)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the argument checks of the new entry points
+    assert dev.lib.wr_tuner_mark_launches(None, 1) == capi.WR_ERR_ARG
+    assert dev.lib.wr_ring_exchange_after(None, None, None, None, 0) == capi.WR_ERR_ARG
+
+
 def test_ring_entry_points_argument_checks(dev):
     """wr_ring_* fail with WR_ERR_ARG and a message on bad arguments, before RCCL is touched."""
     import ctypes as C

@@ -92,6 +92,8 @@ SIGNATURES = {
     "wr_ring_make_id": (C.c_int, [_vp, _sz]),
     "wr_ring_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, _sz, C.c_int, C.c_int]),
     "wr_ring_exchange": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "wr_ring_exchange_after": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),
+    "wr_tuner_mark_launches": (C.c_int, [_vp, C.c_int]),
     "wr_ring_wait": (C.c_int, [_vp]),
     "wr_ring_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]),
     "wr_ring_destroy": (C.c_int, [_vp]),

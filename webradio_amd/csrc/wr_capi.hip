@@ -175,6 +175,11 @@ struct wr_tuner {
 	                              around every n consecutive submits (see wr_tuner_profile) */
 	unsigned int prof_tick;
 	std::vector<unsigned int> ev_span;   /* launches between the events of pair i */
+	/* wr_tuner_mark_launches: every launch stamps one of these on completion (its own dispatch signal, no packet of
+	 * its own on the stream), so that another stream can wait for "the tuner's work so far" -- wr_ring_exchange_after */
+	bool mark_launches = false;
+	hipEvent_t launch_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	unsigned long long launches_marked = 0;
 	std::vector<hipEvent_t> ev;    /* start/stop pairs */
 	size_t ev_used;                /* events recorded and not yet read */
 	double prof_ms;
@@ -679,9 +684,10 @@ static int upload_ahead_begin(wr_dev *d, void *out_dev, unsigned long long *call
 		int prio_low = 0, prio_high = 0;                     /* lowest priority: the kernels of the block before go first */
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
 		HIP_TRY(hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_low));
-		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming));
+		/* (both order streams of this one device against each other: a device-scope release, not the default system fence) */
+		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming | hipEventReleaseToDevice));
 		for (int i = 0; i < WR_UPLOAD_RING; ++i)
-			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming | hipEventReleaseToDevice));
 	}
 	const unsigned long long n = d->up_calls;
 	HIP_TRY(hipEventRecord(d->up_tail[n % WR_UPLOAD_RING], d->stream));
@@ -967,6 +973,9 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 		group_free(g);
 	for (hipEvent_t e : t->ev)
 		(void)hipEventDestroy(e);
+	for (hipEvent_t e : t->launch_ev)
+		if (e)
+			(void)hipEventDestroy(e);
 	for (wr_tuner::RingSlot &r : t->ring) {
 		if (r.done)
 			(void)hipEventDestroy(r.done);
@@ -1794,6 +1803,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 	const uint8_t *cur_u8 = u8 ? (const uint8_t *)src : nullptr;
 
 	bool hist_written = false;
+	bool marked = false, unmarked = false;   /* wr_tuner_mark_launches: launches that stamped the submit's event / that could not */
 	const unsigned long long seq = t->submit_seq++;
 	/* stride 1: this submit's launch stamps its own start and stop (hipExtLaunchKernelGGL).  Stride
 	 * n > 1: an event before the launch of the group's first submit and one after the launch of its
@@ -1851,6 +1861,13 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		if (prof_now) {
 			L.ev_start = t->ev[t->ev_used];     /* stamped by the launch itself (wrk_tuner_ddc) */
 			L.ev_stop = t->ev[t->ev_used + 1];
+		} else if (t->mark_launches && g->l1 <= WR_FIR_LENGTH) {
+			L.ev_start = nullptr;               /* completion only: the slot of this submit (every rate group's launch
+			                                       stamps it in turn: the last one stands) */
+			L.ev_stop = t->launch_ev[(t->launches_marked + 1) % 4];
+			marked = true;
+		} else if (t->mark_launches) {
+			unmarked = true;
 		}
 		if (group_first && !(t->ev_used & 1)) {
 			/* (once per submit: the first rate group's launch is the first of the bracket) */
@@ -1964,6 +1981,13 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 	if (!hist_written)
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
 	t->in_par ^= 1;
+	if (t->mark_launches && (marked || unmarked)) {
+		/* (a launch that could not stamp it -- profiling, a long channel filter -- or a history kernel behind the DDC:
+		 * an ordinary record, at an ordinary record's price) */
+		if (unmarked || !hist_written)
+			HIP_TRY(hipEventRecord(t->launch_ev[(t->launches_marked + 1) % 4], st));
+		++t->launches_marked;
+	}
 
 	/* host mirror of the phase advance k_tuner_ddc wrote into the other state set */
 	for (Chan &c : t->chans) {
@@ -2371,6 +2395,25 @@ extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
 			c.prev_iq[0] = c.prev_iq[1] = 0.0f;
 		}
 	return WR_OK;
+}
+
+extern "C" int wr_tuner_mark_launches(wr_tuner *t, int enable)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	if (enable)
+		for (int i = 0; i < 4; ++i)
+			if (!t->launch_ev[i])
+				HIP_TRY(hipEventCreateWithFlags(&t->launch_ev[i], hipEventDisableTiming | hipEventReleaseToDevice));
+	t->mark_launches = enable != 0;
+	return WR_OK;
+}
+
+hipEvent_t wrc_tuner_last_launch(const wr_tuner *t)
+{
+	return (t && t->mark_launches && t->launches_marked) ? t->launch_ev[t->launches_marked % 4] : nullptr;
 }
 
 /* --------------------------------------------------------------- spectrum -- */

@@ -23,6 +23,8 @@
 int         wrc_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));   /* sets wr_last_error() */
 int         wrc_dev_index(const wr_dev *dev);
 hipStream_t wrc_dev_stream(const wr_dev *dev);
+/* the event the tuner's last launch stamped on completion (wr_tuner_mark_launches), or NULL (wr_ring.hip) */
+hipEvent_t  wrc_tuner_last_launch(const wr_tuner *t);
 
 /* ---- host design math (wr_design.cpp) ---- */
 void     wrd_sin_table(float *table);

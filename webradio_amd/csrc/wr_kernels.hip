@@ -2328,8 +2328,9 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 			return e;
 	}
 	const WrPostArgs pa = post ? *post : WrPostArgs();
-	if (L.ev_start && L.ev_stop) {
-		/* profiling: the launch stamps the two events with the dispatch's own start and end, as
+	if (L.ev_stop) {
+		/* profiling (both events) or a caller that wants to wait for THIS launch from another stream (the stop event
+		 * alone, wr_tuner_mark_launches): the launch stamps the events with the dispatch's own start and end, as
 		 * rocprof sees them -- events recorded around it would add their own barrier packets */
 		hipExtLaunchKernelGGL((k_tuner_ddc<NCO, UTAPS, PD2, NG>), dim3(wgs + n_bnd + post_wgs), dim3(W * 64u), (uint32_t)lds, st,
 		                      (hipEvent_t)L.ev_start, (hipEvent_t)L.ev_stop, 0u,

@@ -140,6 +140,10 @@ class Tuner:
         """Hold up to n back-to-back device blocks and launch them as one (the same bits, per group)."""
         check(self.lib.wr_tuner_set_blocks_per_launch(self.h, n))
 
+    def mark_launches(self, enable=True):
+        """every launch that reads a submitted block stamps an event on completion (Ring.exchange_after waits for it)"""
+        check(self.lib.wr_tuner_mark_launches(self.h, 1 if enable else 0))
+
     def seek(self, frame):
         """Every channel as if the stream started at `frame` (NCO phase closed-form): time sharding."""
         check(self.lib.wr_tuner_seek(self.h, C.c_ulonglong(frame)))
@@ -321,6 +325,11 @@ class Ring:
     def exchange(self, send_dev, recv_dev, nfloats):
         """enqueue: send_dev -> rank + 1, recv_dev <- rank - 1 (device pointers or torch tensors)"""
         check(self.lib.wr_ring_exchange(self.h, ptr(send_dev), ptr(recv_dev), nfloats))
+
+    def exchange_after(self, tuner, send_dev, recv_dev, nfloats):
+        """the same, ordered behind the tuner's launches so far (Tuner.mark_launches(True)) instead of behind the
+        device's stream: for a halo that is input, received into a buffer only the tuner reads"""
+        check(self.lib.wr_ring_exchange_after(self.h, tuner.h, ptr(send_dev), ptr(recv_dev), nfloats))
 
     def wait(self):
         """the device's stream waits for the last exchange (no host wait)"""

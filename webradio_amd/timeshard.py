@@ -60,10 +60,15 @@ class RingHalo:
                 dist.broadcast_object_list(ident, src=0)        # 128 bytes, once
             self.native = Ring(dev, ident[0], rank, world)
 
-    def post(self, tail, recv):
+    def post(self, tail, recv, tuner=None):
         """native only: enqueue the pair (tail -> rank + 1, recv <- rank - 1) behind what the device's
-        stream holds now; returns at once"""
-        self.native.exchange(tail, recv, tail.numel())
+        stream holds now -- or, with a `tuner` that marks its launches, behind that tuner's launches only
+        (the halo is input and `recv` a buffer nobody else reads: nothing goes on the device's stream);
+        returns at once"""
+        if tuner is not None:
+            self.native.exchange_after(tuner, tail, recv, tail.numel())
+        else:
+            self.native.exchange(tail, recv, tail.numel())
 
     def wait(self):
         self.native.wait()
