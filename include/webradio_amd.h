@@ -40,8 +40,10 @@ extern "C" {
 #endif
 
 #define WR_ABI_VERSION   3       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
-                                    blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream), wr_u8_to_f32_from_host
-                                    added.  Nothing of an earlier version changed or removed */
+                                    blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream, incl.
+                                    wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
+                                    wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
+                                    Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
