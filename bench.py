@@ -552,7 +552,9 @@ def main():
         return dt, got, ms
 
     n_launches = launches_of(args.steps)
-    stride = max(1, min(args.profile_stride, n_launches // 2))
+    # (an event record between two launches costs the stream ~10 us: as few pairs as the stride allows -- at the driver's 20 steps
+    # ONE pair around the five launches, recorded before the first and behind the last)
+    stride = max(1, min(args.profile_stride, n_launches))
     elapsed, launches, ddc_ms = timed_steps(args.steps, stride)
     frames_per_launch = float(n) * args.steps / n_launches
 
@@ -573,7 +575,7 @@ def main():
         k1 = min(args.steps, 96)
         for i in range(600):                     # ~25 ms of this launch shape before its timed steps
             tuner.submit_device(blocks[i % nb], n)
-        dt1, got1, ms1 = timed_steps(k1, max(1, min(args.profile_stride, k1 // 2)))
+        dt1, got1, ms1 = timed_steps(k1, max(1, min(args.profile_stride, k1)))
         one = {"blocks_per_launch": 1, "steps": k1, "ms_per_step": round(dt1 / k1 * 1e3, 5),
                "value": round(float(n) * k1 / dt1 / 1e6, 2), "unit": "complex Msamples/s",
                "kernel_ms": round(ms1, 5), "launches_timed": got1,
