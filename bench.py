@@ -68,9 +68,10 @@ def parse():
     ap.add_argument("--cpu-blocks", type=int, default=0,
                     help="blocks of the all-cores CPU baseline (0: as many as take about 10-20 s)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 (SpectrumSink) measurement")
-    ap.add_argument("--profile-stride", type=int, default=8,
-                    help="one HIP event pair around every n consecutive launches of the dominant kernel (n = 1: every "
-                         "launch stamps its own start and stop, which costs ~2 us of stream time per launch)")
+    ap.add_argument("--profile-stride", type=int, default=64,
+                    help="one HIP event pair around every n consecutive launches of the dominant kernel, at most all of the "
+                         "timed region's (an event record between two launches costs the stream ~10 us; n = 1: every "
+                         "launch stamps its own start and stop, ~4 us of stream time per launch)")
     ap.add_argument("--halo", choices=["auto", "copy", "ring"], default="auto",
                     help="c5: where a chunk's halo comes from.  ring: the C ABI's wr_ring_* (RCCL ncclSend/ncclRecv on a side "
                          "stream, issued a round ahead) -- what N > 1 over nccl uses; at N = 1 the rank is its own neighbour.  "
@@ -658,7 +659,7 @@ def main():
                 "kernel_ms": round(ddc_ms, 5),
                 "launches_timed": launches,
                 "timing": "HIP events on the launch stream inside the timed region, one pair around every %d consecutive "
-                          "launches: the mean per launch includes the gaps between launches" % max(1, args.profile_stride),
+                          "launches: the mean per launch includes the gaps between launches" % stride,
                 "algorithmic_bytes_per_launch": nl * ALGO_BYTES_PER_SAMPLE,
                 "frames_per_launch": nl,
                 "note": "the path is VALU-bound at 256 channels, not HBM-bound (DESIGN.md 3.1): a channel-tap of the "
