@@ -360,7 +360,7 @@ def run_c5(args, torch, dist, rank, world, device_index):
                 step(done)
                 done += 1
             torch.cuda.synchronize()
-    tuner.profile(max(1, args.profile_stride))
+    tuner.profile(max(1, min(args.profile_stride, args.steps)))     # (one launch per step; a pair must close inside the timed region)
     barrier()
     t0 = time.perf_counter()
     for i in range(done, done + args.steps):
