@@ -684,8 +684,9 @@ static int upload_ahead_begin(wr_dev *d, void *out_dev, unsigned long long *call
 		int prio_low = 0, prio_high = 0;                     /* lowest priority: the kernels of the block before go first */
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
 		HIP_TRY(hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_low));
-		/* (both order streams of this one device against each other: a device-scope release, not the default system fence) */
-		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming | hipEventReleaseToDevice));
+		/* up_done (recorded on the upload stream: nothing of the device's stream pays for it) publishes the copied block and keeps
+		 * the default fence; up_tail only keeps the copy from overwriting what earlier work still reads: a device-scope release */
+		HIP_TRY(hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming));
 		for (int i = 0; i < WR_UPLOAD_RING; ++i)
 			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming | hipEventReleaseToDevice));
 	}

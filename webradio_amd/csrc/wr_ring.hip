@@ -86,8 +86,8 @@ struct wr_ring {
 	unsigned long long exchanges;
 };
 
-/* the two events order streams of ONE device against each other (the data they guard are in this GPU's memory, the peer's
- * writes arrive through the receive kernel that runs here): a device-scope release is all they need.  With the default
+/* `ready` only keeps the exchange from running ahead of the device's stream (the data it guards were written long before): a
+ * device-scope release is all it needs.  With the default
  * system-scope fence every record on the device's stream cost the chunk's launch 11 us (r03: 452 -> 606 Gsps at world 1) */
 #define WR_RING_EVENT_FLAGS (hipEventDisableTiming | hipEventReleaseToDevice)
 
@@ -155,7 +155,8 @@ extern "C" int wr_ring_create(wr_ring **out, wr_dev *dev, const void *id, size_t
 	if (e == hipSuccess)
 		e = hipEventCreateWithFlags(&r->ready, WR_RING_EVENT_FLAGS);
 	if (e == hipSuccess)
-		e = hipEventCreateWithFlags(&r->done, WR_RING_EVENT_FLAGS);
+		e = hipEventCreateWithFlags(&r->done, hipEventDisableTiming);   /* publishes the received halo: the default fence (it is
+		                                                                    recorded on the ring's own stream) */
 	if (e != hipSuccess) {
 		g_rccl.CommDestroy(r->comm);
 		delete r;
