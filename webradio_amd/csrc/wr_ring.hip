@@ -216,6 +216,17 @@ extern "C" int wr_ring_wait(wr_ring *r)
 		return wrc_fail(WR_ERR_ARG, "wr_ring_wait: NULL");
 	if (!r->pending)
 		return WR_OK;
+	HIP_TRY_R(hipSetDevice(wrc_dev_index(r->dev)));
+	/* posted a round ahead, the pair has normally completed by now: then there is nothing to wait for, and a wait that
+	 * is enqueued all the same is one more packet between two launches */
+	const hipError_t q = hipEventQuery(r->done);
+	if (q == hipSuccess) {
+		r->pending = false;
+		return WR_OK;
+	}
+	if (q != hipErrorNotReady)
+		return wrc_fail(WR_ERR_HIP, "wr_ring_wait: %s", hipGetErrorString(q));
+	(void)hipGetLastError();
 	HIP_TRY_R(hipStreamWaitEvent(wrc_dev_stream(r->dev), r->done, 0));
 	r->pending = false;
 	return WR_OK;
