@@ -123,7 +123,9 @@ struct SourceStage {
 				pinned.erase(pinned.begin() + n);
 				break;
 			}
-		if (pinned.size() >= 4) {                          /* a source that allocates per block: give up on the oldest */
+		if (pinned.size() >= 8) {                          /* (RtlSdrTuner rotates five vectors: its ring of N_BUFFERS = 4,
+		                                                      rtlsdrtuner.cxx:33-34, and the one handed out)
+		                                                      a source that allocates per block: give up on the oldest */
 			wr_dev_wait_uploads(d);
 			wr_dev_host_unregister(d, pinned[0].ptr);
 			pinned.erase(pinned.begin());
