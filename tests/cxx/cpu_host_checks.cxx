@@ -52,6 +52,48 @@ extern "C" long wr_filetuner_play(const char *path, unsigned int block_frames, u
 	return (long)c.got.size();
 }
 
+/* RawU8Block::rawU8Buffers() = 2 is a promise: the bytes handed out for one block stay untouched until the source starts
+ * producing the block after the next (the GPU runtime lets a transfer out of them run that long).  Returns 0 when, over
+ * `nruns` blocks, consecutive blocks come out of different buffers and block r's bytes are still there after run r + 1. */
+extern "C" int wr_filetuner_two_buffers(const char *path, unsigned int block_frames, unsigned int nruns)
+{
+	FileTuner t("f");
+	Capture c;
+	t.setSubdevice(path);
+	t.setSampleRate(2048000);
+	t.setChannels(2);
+	t.setBlockSize(block_frames * 2);
+	t.setLoop(true);
+	t.connect(&c);
+	if (t.rawU8Buffers() != 2)
+		return 1;
+	if (!t.start())
+		return 2;
+	const uint8_t *prev = NULL;
+	std::vector<uint8_t> prev_copy;
+	int rc = 0;
+	for (unsigned int n = 0; n < nruns && !rc; n++) {
+		if (!t.run()) {
+			rc = 3;
+			break;
+		}
+		size_t fr = 0;
+		const uint8_t *raw = t.rawU8(&fr);
+		if (!raw || fr != block_frames)
+			rc = 4;
+		else if (prev && raw == prev)
+			rc = 5;                                        /* the same buffer twice in a row */
+		else if (prev && memcmp(prev, prev_copy.data(), prev_copy.size()))
+			rc = 6;                                        /* the block before was overwritten */
+		if (!rc) {
+			prev = raw;
+			prev_copy.assign(raw, raw + fr * 2);
+		}
+	}
+	t.stop();
+	return rc;
+}
+
 /* ---- device hand-over bookkeeping of DspBlock (no GPU involved: pointers are just tokens) ---- */
 namespace {
 struct Src : public DspSource {

@@ -57,6 +57,16 @@ def test_loop_and_raw_bytes(checks, oracle, tmp_path):
     assert np.array_equal(raw, np.tile(u8, 3)[1200:1400])    # bytes of the last block
 
 
+def test_two_byte_buffers_in_turn(checks, tmp_path):
+    """RawU8Block::rawU8Buffers() == 2: consecutive blocks come out of different byte buffers and a block's bytes are
+    still intact after the next run() (what lets the GPU runtime keep a transfer in flight while the source moves on)."""
+    u8 = (np.arange(4096) * 13 % 256).astype(np.uint8)
+    path = tmp_path / "cap.bin"
+    u8.tofile(path)
+    checks.wr_filetuner_two_buffers.argtypes = [C.c_char_p, C.c_uint, C.c_uint]
+    assert checks.wr_filetuner_two_buffers(str(path).encode(), 128, 9) == 0
+
+
 def test_missing_file(checks, tmp_path):
     n, ok, out, raw = _play(checks, tmp_path / "nope.bin", 10, 1, 0)
     assert n == -1                                           # init() fails -> start() false
