@@ -276,6 +276,16 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 	return st->cur;
 }
 
+void submitBatchFirst(const DspBlock *consumer, const vector<sample_t> &host)
+{
+	DspSource *src = TunerBatch::rootSource(consumer);
+	if (!src || host.empty() || host.data() != src->currentBlock().data())
+		return;
+	TunerBatch *batch = src->batch();
+	if (batch && batch->channels())
+		(void)batch->submitOnce(host, (unsigned int)(host.size() / 2));      /* (the receivers see its verdict when they ask) */
+}
+
 bool hostBlockValid(const DspBlock *block)
 {
 	DspSource *src = TunerBatch::rootSource(block);

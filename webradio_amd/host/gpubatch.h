@@ -52,6 +52,11 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 /* false while the root source of `block` left its host vector unfilled for the current block (a byte-format
  * source all of whose consumers read on the device): a device path that fails must then fail loudly */
 bool hostBlockValid(const DspBlock *block);
+/* For a consumer of the source's block that is NOT part of the tuner batch (the SpectrumSink, which FrontEnd connects
+ * first): have the batch submit this block now, before the consumer enqueues its own work -- the receivers' launches then
+ * come first on the device's stream and the audio does not wait behind the spectrum's copy and transform (the batch
+ * submits once per block whoever asks first).  No batch, or not the source's current block: nothing happens. */
+void submitBatchFirst(const DspBlock *consumer, const vector<sample_t> &host);
 
 
 /* WEBRADIO_TRACE=1: what the tuner batches did, in order -- 'S' a block submitted (enqueued, nothing
@@ -111,6 +116,7 @@ public:
 
 	wr_dev *dev() const { return _dev; }
 	DspSource *source() const { return _source; }
+	size_t channels() const { return _channels.size(); }
 
 private:
 	TunerBatch(DspSource *source, wr_dev *dev);

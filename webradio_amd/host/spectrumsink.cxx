@@ -65,6 +65,8 @@ bool SpectrumSink::process(const vector<sample_t> &inBuffer, vector<sample_t> &o
 	std::lock_guard<std::mutex> g(_lock);
 	if (!_spec)
 		return false;
+	/* the receivers of the same tuner go first on the device's stream: their audio is what run() waits for */
+	wrhost::submitBatchFirst(this, inBuffer);
 	/* fed straight from the tuner: use the device copy every GPU consumer of it shares */
 	wr_dev *sdev = NULL;
 	const float *staged = wrhost::stagedBlock(this, inBuffer, &sdev);
