@@ -77,33 +77,123 @@ def parse():
                          "stream, issued a round ahead) -- what N > 1 over nccl uses; at N = 1 the rank is its own neighbour.  "
                          "copy: a device copy (N = 1 only).  auto: ring for N > 1 over nccl, copy at N = 1; gloo ranks "
                          "(tests: two ranks on one GPU) exchange host tensors through torch.distributed")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks from this process even at --gpus 1 (tests: the launch path itself -- file-store "
+                         "rendezvous, watchdog, RCCL at world size 1)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)    # tests: this rank exits 3 after the rendezvous
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0,
+                    help="N > 1 without a launcher: seconds the ranks this process starts may take before it kills them "
+                         "and exits 124 with their stderr")
+    ap.add_argument("--rdzv-timeout", type=float, default=300.0,
+                    help="N > 1: seconds init_process_group (and every host-side collective) may wait for the other "
+                         "ranks -- a fresh box pages torch in for a minute or two, not at the same pace in every rank")
+    ap.add_argument("--watchdog", type=float, default=1200.0,
+                    help="seconds after which a rank that is still running dumps every thread's stack to stderr and "
+                         "exits (faulthandler): a hang becomes an error that says where.  0 turns it off")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     return ap.parse_args()
 
 
-def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks here, as the driver's
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would
-    (Radio::run pumps its front ends one after the other, radio.cxx:56-59; here every front end has
-    its own process and GPU).  Rank 0's JSON line goes to this process's stdout; the exit code is the
-    launcher's."""
-    import socket
+def _gpu_count(timeout_s=240.0):
+    """The number of GPUs torch sees, asked of a CHILD process: the launching process never opens the
+    device (it only waits for its ranks), and a runtime that does not come up costs a timeout, not the job."""
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        return int(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:                                          # incl. TimeoutExpired
+        raise SystemExit("bench.py: could not count the GPUs (%s)" % str(e)[:200])
+
+
+def _kill_ranks(procs):
+    import signal
+    for p in procs:
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)                    # every rank leads its own session
+            except (ProcessLookupError, PermissionError):
+                pass
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except Exception:
+            pass
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (Radio::run pumps its front
+    ends one after the other, radio.cxx:56-59; here every front end has its own process and GPU).
+
+    r04: the ranks are this script's own children -- no torch.distributed.run agent in between -- and meet
+    through a FILE store in a fresh temp directory (`init_method=file://...`), so no rendezvous port is
+    picked, raced for or left in TIME_WAIT; gloo's and RCCL's own data sockets bind to kernel-chosen
+    ports.  This process never imports torch or opens the GPU.  It is also the watchdog: a rank that exits
+    non-zero takes the others down at once, and a job that overruns --spawn-timeout is killed (every
+    rank's session) with the ranks' stderr tails on ours and exit code 124 -- a hang here becomes an error
+    with a name, not a silent wait.  Rank 0's stdout is ours (the ONE JSON line); the other ranks' goes to
+    stderr."""
+    import shutil
+    import subprocess
+    import tempfile
+    have = _gpu_count()
     if have < args.gpus and args.backend == "nccl":
         raise SystemExit("bench.py: --gpus %d but this box has %d GPU(s): refusing to measure fewer GPUs than asked for "
                          "(--backend gloo lets ranks share a GPU, for tests only)" % (args.gpus, have))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this host driver
-    env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
+    if have < 1:
+        raise SystemExit("bench.py: no GPU (the HIP path has no CPU fallback)")
+    rdzv = tempfile.mkdtemp(prefix="wr_bench_rdzv_")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                             "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
+    base["WR_BENCH_RDZV_FILE"] = os.path.join(rdzv, "store")
+    base["WORLD_SIZE"] = base["LOCAL_WORLD_SIZE"] = str(args.gpus)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("OMP_NUM_THREADS", "1")                         # what torch.distributed.run gives its workers
+    if args.backend == "nccl":
+        base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this host driver
+    procs, errs = [], []
+    t0 = time.monotonic()
+    try:
+        for r in range(args.gpus):
+            err = open(os.path.join(rdzv, "rank%d.err" % r), "w+b")
+            errs.append(err)
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdin=subprocess.DEVNULL, stdout=None if r == 0 else sys.stderr, stderr=err,
+                                          start_new_session=True))
+        rc, why = 0, None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc, why = (bad[0][1] if bad[0][1] > 0 else 1), "rank %d exited with %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > args.spawn_timeout:
+                rc, why = 124, "the %d ranks did not finish within --spawn-timeout %.0f s (still running: %s)" % (
+                    args.gpus, args.spawn_timeout, [r for r, c in enumerate(codes) if c is None])
+                break
+            time.sleep(0.05)
+        _kill_ranks(procs)
+        for r, err in enumerate(errs):                              # the ranks' stderr, in rank order, on ours
+            err.flush()
+            err.seek(0)
+            data = err.read()
+            if rc != 0:
+                data = data[-6000:]
+            if data:
+                sys.stderr.write("".join("[rank %d] %s\n" % (r, l) for l in data.decode(errors="replace").splitlines()))
+        if why:
+            sys.stderr.write("bench.py: %s -- all ranks killed\n" % why)
+        sys.stderr.flush()
+    finally:
+        _kill_ranks(procs)
+        for err in errs:
+            err.close()
+        shutil.rmtree(rdzv, ignore_errors=True)
+    raise SystemExit(rc)
 
 
 def cpu_baseline(cfg, ifs, blocks):
@@ -452,8 +542,11 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                          # does not return
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     import torch
     from webradio_amd import capi, synth
     from webradio_amd.device import Device, Tuner
@@ -473,13 +566,18 @@ def main():
     device_index = local_rank % have
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("WR_BENCH_RDZV_FILE"):
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"timeout": datetime.timedelta(seconds=args.rdzv_timeout)}
+        if os.environ.get("WR_BENCH_RDZV_FILE"):                    # started by spawn_ranks: a file store, no port
+            kw.update(init_method="file://" + os.environ["WR_BENCH_RDZV_FILE"], rank=rank, world_size=world)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(args.backend)
+            kw["device_id"] = torch.device("cuda", device_index)
+        dist.init_process_group(args.backend, **kw)
+        if rank == args.fail_rank:
+            raise SystemExit(3)
 
     if args.workload == "c5":
         finish(run_c5(args, torch, dist, rank, world, device_index), dist, args.gpus)

@@ -39,11 +39,11 @@
 extern "C" {
 #endif
 
-#define WR_ABI_VERSION   3       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
+#define WR_ABI_VERSION   4       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
                                     blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream, incl.
                                     wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
                                     wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
-                                    Nothing of an earlier version changed or removed */
+                                    4: wr_tune added.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
@@ -93,6 +93,15 @@ typedef struct wr_ring     wr_ring;
 int         wr_abi_version(void);
 const char *wr_last_error(void);
 int         wr_device_count(int *count);
+/* Launch heuristics of the library, process-wide; they never change a result, only which of several
+ * bit-identical kernel variants a launch takes.  Sets `key` to `value` (value < 0: back to the built-in /
+ * environment default) and stores the value it had in *previous (optional).  For tests (both variants on
+ * streams too short to reach a threshold) and for tuning; the reference has no counterpart. */
+enum wr_tunable {
+	WR_TUNE_DDC_NG2_MIN_PASSES = 1   /* k_tuner_ddc runs two lane groups per wave from this many passes of the grid on
+	                                    (default 4, or $WR_DDC_NG2_MIN_PASSES at first use); 0: whenever the launch allows */
+};
+int         wr_tune(int key, long value, long *previous);
 
 /* --------------------------------------------- host-side design helpers -- */
 /* DownConverter::init / setIF: phaseStep = (int)((int64)hz * 2^31 / (int64)rate)
@@ -360,7 +369,9 @@ int wr_ring_exchange(wr_ring *ring, const float *send_dev, float *recv_dev, size
  * wr_tuner_mark_launches(tuner, 1): every launch that reads a submitted block then stamps an event with its own
  * completion signal, and the exchange waits for that -- nothing is put on the device's stream (an event record there
  * sits between two launches: 11 us a chunk).  The rule for the caller: `send_dev` is complete when the call is made,
- * `recv_dev` has no reader other than blocks already submitted to `tuner`. */
+ * `recv_dev` has no reader other than blocks already submitted to `tuner`.  Blocks the tuner still holds
+ * (wr_tuner_set_blocks_per_launch) are launched by the call; blocks launched before marking was switched on are covered
+ * by one record made when it is switched on; a tuner that does not mark its launches is WR_ERR_STATE. */
 int wr_tuner_mark_launches(wr_tuner *tuner, int enable);
 int wr_ring_exchange_after(wr_ring *ring, wr_tuner *tuner, const float *send_dev, float *recv_dev, size_t nfloats);
 int wr_ring_wait(wr_ring *ring);

@@ -9,14 +9,66 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
-# The lean DDC loop runs two lane groups per wave (k_tuner_ddc: NG = 2) only for streams long enough to fill the
-# grid four times over; the tests' streams are short, so they ask for it whenever the launch allows -- an even number
-# of lane groups on one channel filter -- and cover NG = 1 through odd group counts and mixed passbands.
-os.environ.setdefault("WR_DDC_NG2_MIN_PASSES", "0")
+# r04: the suite runs the launch heuristic that ships.  (r03 forced WR_DDC_NG2_MIN_PASSES=0 for every test, so C5's and
+# C1's NG = 1 launches were never the ones compared with the oracle.)  The modules below run every test twice instead:
+# "shipped" -- the library's own threshold, what bench.py and the host runtime launch -- and "ng2" -- two lane groups
+# per wave whenever the launch allows (wr_tune), which the tests' short streams would otherwise never reach.
+NG2_MODULES = ("test_gpu_tuner", "test_gpu_timeshard", "test_gpu_ring", "test_gpu_fuzz")
+
+# Oracle-parity modules first, process-spawning contract tests last: under `-x` a hiccup in a launcher test must not
+# cost the parity run (GPUTEST_r03).
+ORDER = ["test_gpu_blocks", "test_gpu_tuner", "test_gpu_spectrum", "test_gpu_f4", "test_gpu_fuzz", "test_gpu_ring",
+         "test_gpu_timeshard", "test_gpu_host", "test_gpu_c_client", "test_gpu_bench"]
+
+PER_TEST_LIMIT_S = 300.0        # no test takes a tenth of this; see the watchdog below
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] in NG2_MODULES and "dev" in metafunc.fixturenames:
+        metafunc.parametrize("ddc_lane_groups", ["shipped", "ng2"], indirect=True)
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        name = item.module.__name__.split(".")[-1]
+        return ORDER.index(name) if name in ORDER else -1        # CPU-side modules keep their place at the front
+    items.sort(key=key)                                            # stable: order within a module is kept
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(PER_TEST_LIMIT_S))  # pytest-timeout, where it is installed
+
+
+@pytest.fixture(autouse=True)
+def _watchdog(request):
+    """A test that is still running after PER_TEST_LIMIT_S + 60 s dumps every thread's stack and ends the
+    run: a hang is a NAMED failure in the log, never a silent wait for the driver's limit.  (pytest-timeout's
+    own signal fires first and fails just the one test; this is the backstop for code stuck in C.)"""
+    import faulthandler
+    sys.stderr.write("")                                            # (faulthandler writes to the real stderr)
+    faulthandler.dump_traceback_later(PER_TEST_LIMIT_S + 60.0, exit=True)
+    yield
+    faulthandler.cancel_dump_traceback_later()
+
+
+@pytest.fixture(autouse=True)
+def ddc_lane_groups(request):
+    """"ng2": k_tuner_ddc's two-lane-groups-per-wave variant whenever a launch allows it; "shipped": the
+    library's threshold (four passes of the grid).  Only the NG2_MODULES' tests are parametrised with it."""
+    which = getattr(request, "param", None)
+    if which is None:
+        yield None
+        return
+    import ctypes as C
+    from webradio_amd import capi
+    lib = capi.load()
+    assert lib.wr_tune(1, 0 if which == "ng2" else -1, None) == 0
+    yield which
+    assert lib.wr_tune(1, -1, None) == 0
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout)")
     # The built libraries are git-ignored; if this checkout has none (fresh clone), build them
     # once (hipcc cross-compiles gfx950 without a GPU).  Nothing is ever substituted for them.
     needed = [os.path.join(ROOT, "webradio_amd", "lib", "libwebradio_amd.so"),

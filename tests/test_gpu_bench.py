@@ -4,10 +4,11 @@ works; the latter with the gloo backend because the test box has a single GPU (o
 node the driver uses the default nccl = RCCL backend)."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
+
+import _proc
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +24,8 @@ def _line(out):
 
 
 def test_single_gpu_line():
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2",
-                                   "--cpu-blocks", "1"], cwd=ROOT)
+    out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2",
+                                   "--cpu-blocks", "1"], cwd=ROOT, timeout=420)
     j = _line(out)
     for k in REQUIRED + ["cpu_baseline"]:
         assert k in j, k
@@ -57,7 +58,7 @@ def test_single_gpu_line():
 
 def test_two_rank_launch_path():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    out = _proc.output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                                    "--master-addr", "127.0.0.1", "--master-port", "29711", os.path.join(ROOT, "bench.py"),
                                    "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo"], cwd=ROOT, env=env)
     j = _line(out)
@@ -70,7 +71,7 @@ def test_c5_workload_line_and_two_rank_ring():
     """bench.py --workload c5 (BASELINE config 5): the JSON line at N = 1, and the two-rank path --
     chunks dealt round-robin, the halo through torch.distributed send/recv -- over gloo with both
     ranks on the one GPU of the test box (the driver's node uses nccl = RCCL)."""
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--steps", "3",
+    out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--steps", "3",
                                    "--warmup", "1"], cwd=ROOT)
     j = _line(out)
     for k in REQUIRED:
@@ -78,7 +79,7 @@ def test_c5_workload_line_and_two_rank_ring():
     assert j["config"]["halo_frames"] == 260_000 and j["config"]["chunk_frames"] % 20_000 == 0
     assert abs(j["value"] - j["config"]["chunk_frames"] * 3 / (j["ms_per_step"] * 3 / 1e3) / 1e6) / j["value"] < 1e-3
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    out = _proc.output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                                    "--master-addr", "127.0.0.1", "--master-port", "29713", os.path.join(ROOT, "bench.py"),
                                    "--workload", "c5", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo"],
                                   cwd=ROOT, env=env)
@@ -93,10 +94,53 @@ def test_plain_invocation_starts_its_own_ranks():
     has one GPU, which the two ranks share."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     for extra in ([], ["--workload", "c5"]):
-        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                                       "--warmup", "1", "--backend", "gloo"] + extra, cwd=ROOT, env=env)
+        out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                                       "--warmup", "1", "--backend", "gloo", "--spawn-timeout", "120", "--rdzv-timeout", "60"] + extra,
+                           cwd=ROOT, env=env, timeout=170)
         j = _line(out)
         assert j["n_gpus"] == 2 and j["steps"] == 3
+
+
+def _plain_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+
+
+@pytest.mark.parametrize("extra", [[], ["--workload", "c5", "--halo", "ring"]], ids=["c2", "c5-ring"])
+def test_spawned_rank_over_rccl_at_world_size_one(extra):
+    """The launch path a multi-GPU node takes, as far as one GPU can walk it: spawn_ranks starts the (one) rank,
+    the rank joins through the file store with the nccl backend (= RCCL), barriers and the max-over-ranks reduction
+    run on the device, C5's halo goes through wr_ring_*."""
+    out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary", "--settle-ms", "0", "--spawn-timeout", "150",
+                        "--rdzv-timeout", "60"] + extra, cwd=ROOT, env=_plain_env(), timeout=200)
+    j = _line(out)
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 0
+    if extra:
+        assert j["config"]["halo"] == "ring" and j["config"]["ring_exchanges"] == 3 + 1 + 1
+
+
+def test_spawn_watchdog_kills_ranks_that_overrun():
+    """A job that does not finish inside --spawn-timeout is killed -- both ranks -- and the launcher exits 124 with
+    a message: a hang in the N > 1 path costs its own limit, not the caller's."""
+    import time
+    t0 = time.monotonic()
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                   "--backend", "gloo", "--spawn-timeout", "0.2"], cwd=ROOT, env=_plain_env(), check=False, timeout=300)
+    assert p.returncode == 124, (p.returncode, p.stderr[-2000:])
+    assert b"did not finish within --spawn-timeout" in p.stderr and b"all ranks killed" in p.stderr
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert time.monotonic() - t0 < 280
+
+
+def test_one_failing_rank_ends_the_job():
+    """Rank 1 exits with 3 after the rendezvous: the launcher takes rank 0 down (it would otherwise sit in a
+    barrier until the collective's timeout) and exits 3."""
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                   "--backend", "gloo", "--fail-rank", "1", "--spawn-timeout", "150", "--rdzv-timeout", "100"],
+                  cwd=ROOT, env=_plain_env(), check=False, timeout=200)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert b"rank 1 exited with 3" in p.stderr
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
 
 
 def test_more_gpus_than_the_box_has_is_an_error():
@@ -105,14 +149,14 @@ def test_more_gpus_than_the_box_has_is_an_error():
     want = torch.cuda.device_count() + 7
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     for extra in ([], ["--workload", "c5"]):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2",
-                            "--warmup", "1"] + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2",
+                            "--warmup", "1"] + extra, cwd=ROOT, env=env, check=False)
         assert p.returncode != 0
         assert b"refusing to measure fewer GPUs" in p.stderr and not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     # under a launcher that made fewer ranks than --gpus says: an error too
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env2,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env2,
+                  check=False)
     assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr
 
 
@@ -141,7 +185,7 @@ def test_rccl_loads_and_reduces_at_world_size_one():
     all-reduce and a grouped send/recv pair (the C5 halo ring's primitive) run on the device."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = subprocess.check_output([sys.executable, "-c", _RCCL_PROBE], cwd=ROOT, env=env, timeout=300)
+    out = _proc.output([sys.executable, "-c", _RCCL_PROBE], cwd=ROOT, env=env, timeout=240)
     assert b"rccl ok" in out
 
 
@@ -149,7 +193,7 @@ def test_c5_halo_through_the_native_ring():
     """bench.py --workload c5 --halo ring at N = 1: the rank is its own ring neighbour, so every chunk's halo goes
     through wr_ring_* -- ncclSend/ncclRecv on the ring's stream, posted a round ahead -- the branch a multi-GPU
     node takes over nccl.  One exchange per step plus the one posted ahead."""
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--halo", "ring",
+    out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--halo", "ring",
                                    "--steps", "3", "--warmup", "1", "--settle-ms", "0"], cwd=ROOT)
     j = _line(out)
     assert j["n_gpus"] == 1 and j["config"]["halo"] == "ring" and "wr_ring" in j["config"]["workload"]

@@ -5,11 +5,12 @@ the reference: FrontEnd + Receivers + Radio::run().  Checked against the oracle 
   - the REFERENCE's radio.cxx linked against our classes (oracle/_ref/libwr_boundary.so)."""
 import ctypes as C
 import os
-import subprocess
 import sys
 
 import numpy as np
 import pytest
+
+import _proc
 
 from webradio_amd import synth
 
@@ -45,7 +46,7 @@ np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], spec=spec, left=L.wr_host
 def _run(libname, tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(-1, 0), fft=0, env=None):
     lib = os.path.join(CXXT, libname) if not os.path.isabs(libname) else libname
     if not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-C", CXXT, "all"])
+        _proc.run(["make", "-s", "-C", CXXT, "all"], timeout=600)
     inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     nblocks = (iq.size // 2) // block
     cap = nblocks * (block // (rate // crate) // (crate // arate)) + 16
@@ -54,7 +55,7 @@ def _run(libname, tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
     e = dict(os.environ, WEBRADIO_QUIET="1")
     e.update(env or {})
     # a fresh process per run: the host runtime keeps per-process device contexts and env switches
-    subprocess.check_call([sys.executable, "-c", RUNNER, lib, inp, out], env=e)
+    _proc.run([sys.executable, "-c", RUNNER, lib, inp, out], env=e)
     r = np.load(out)
     assert int(r["rc"]) == 0
     assert int(r["left"]) == 0                    # registries empty again (radio.cxx:98,143)
@@ -225,7 +226,7 @@ def test_stop_start_keeps_phase_and_two_front_ends(tmp_path, oracle):
     cap = nblk * (block // 2000) + 16
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([rate, block, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], mode, restart_at, cap], np.int64))
-    subprocess.check_call([sys.executable, "-c", RESTART_RUNNER, lib, inp, out],
+    _proc.run([sys.executable, "-c", RESTART_RUNNER, lib, inp, out],
                           env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
     r = np.load(out)
     assert int(r["rc"]) == 0 and int(r["left"]) == 0
@@ -274,7 +275,7 @@ def test_stop_set_rate_and_block_size_start(tmp_path, oracle):
     cap = 4096
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([r1, b1, r2, b2, n1, n2, mode, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], cap], np.int64))
-    subprocess.check_call([sys.executable, "-c", RERATE_RUNNER, lib, inp, out],
+    _proc.run([sys.executable, "-c", RERATE_RUNNER, lib, inp, out],
                           env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
     r = np.load(out)
     assert int(r["rc"]) == 0 and int(r["left"]) == 0
@@ -322,7 +323,7 @@ def test_late_audio_keeps_both_front_ends_in_flight(tmp_path, oracle):
              params=np.array([rate, block, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], mode, nblk, cap], np.int64))
     res = {}
     for late in ("0", "1", "2"):
-        subprocess.check_call([sys.executable, "-c", TRACED_RUNNER, lib, inp, out],
+        _proc.run([sys.executable, "-c", TRACED_RUNNER, lib, inp, out],
                               env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1",
                                        WEBRADIO_AUDIO_LATE=late))
         r = np.load(out)
@@ -386,7 +387,7 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
     #  WEBRADIO_NO_U8_STAGING=1: FileTuner converts on the host and the float block is staged, as r02 did)
     for env, tol in (({"WEBRADIO_NCO_EXACT": "1"}, 4.8e-7), ({}, 1e-5),
                      ({"WEBRADIO_NCO_EXACT": "1", "WEBRADIO_NO_U8_STAGING": "1"}, 4.8e-7)):
-        subprocess.check_call([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
+        _proc.run([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
                               env=dict(os.environ, WEBRADIO_QUIET="1", **env))
         r = np.load(out)
         assert int(r["rc"]) == 0 and int(r["left"]) == 0
@@ -396,7 +397,7 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
     # block it has just handed out (RawU8Block::rawU8Buffers, wr_dev_wait_uploads_but) -- the same audio, a block later
     # (silence first, the last block's audio dropped at stop())
     for late in ("1", "2"):
-        subprocess.check_call([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
+        _proc.run([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
                               env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_AUDIO_LATE=late))
         r = np.load(out)
         assert int(r["rc"]) == 0 and int(r["left"]) == 0 and r["audio"].size == g["audio"].size
@@ -432,8 +433,8 @@ def test_setters_from_another_thread_while_running(tmp_path):
     iq = synth.fm_stream(30 * block, rate, [50_000, -75_000], amp=0.3)
     inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     np.savez(inp, iq=iq, params=np.array([rate, block, 12, CFG["crate"], CFG["arate"]], np.int64))
-    subprocess.check_call([sys.executable, "-c", STRESS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
-                          timeout=300)
+    _proc.run([sys.executable, "-c", STRESS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
+                          timeout=240)
     r = np.load(out)
     assert int(r["calls"]) > 1000 and int(r["left"]) == 0
     assert r["audio"].shape == (12, block // 2000) and np.isfinite(r["audio"]).all()
@@ -479,8 +480,8 @@ def test_multistage_decimation_chain_on_device(tmp_path, oracle):
     lib = os.path.join(CXXT, "libwr_host_pipeline.so")
     inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     np.savez(inp, iq=iq, params=np.array([fs, block, f_if, mode, apb, arate], np.int64), rates=np.array(rates), pbs=np.array(pbs))
-    subprocess.check_call([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
-                          timeout=300)
+    _proc.run([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
+                          timeout=240)
     r = np.load(out)
     got = r["audio"]
     # the oracle's cascade: the reference's blocks chained the same way
@@ -531,7 +532,7 @@ def test_two_lowpass_stages_in_a_row_ride_the_tuner_batch(tmp_path, oracle, fuse
     env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1")
     if not fused:
         env["WEBRADIO_NO_FUSION"] = "1"
-    subprocess.check_call([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=env, timeout=300)
+    _proc.run([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=env, timeout=240)
     r = np.load(out)
     assert (int(r["traced"]) > 0) == bool(fused)
     table = oracle.sin_table()
@@ -583,7 +584,7 @@ def test_second_consumer_inside_a_fused_chain(tmp_path, oracle):
     cap, tcap = 4096, 1 << 16
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([rate, block, mode, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], tap_at, cap, tcap], np.int64))
-    subprocess.check_call([sys.executable, "-c", TAP_RUNNER, lib, inp, out],
+    _proc.run([sys.executable, "-c", TAP_RUNNER, lib, inp, out],
                           env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
     r = np.load(out)
     assert int(r["rc"]) == 0 and int(r["left"]) == 0

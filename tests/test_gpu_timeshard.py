@@ -185,14 +185,13 @@ def test_ring_entry_points_argument_checks(dev):
     assert lib.wr_ring_destroy(None) == capi.WR_OK
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, outdir):
     sys.path.insert(0, ROOT)
     import torch
-    import torch.distributed as dist
     from webradio_amd.device import Device
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # one GPU on the test box: gloo ring
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _proc
+    dist = _proc.init_gloo(rank, world, os.path.join(outdir, "rdzv"))      # (one GPU on the test box: a gloo ring)
     dev = Device(0)
     iq = _stream()
     shard = timeshard.TunerShard(dev, FS, IFS, 128_000, 5_000, capi.WR_FM, 160, 1_000, T + timeshard.halo_frames(D1, D2))
@@ -206,9 +205,8 @@ def _worker(rank, world, port, outdir):
 
 
 def test_time_shard_two_ranks(dev, tmp_path):
-    import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import _proc
+    _proc.spawn_ranks(_worker, 2, (2, str(tmp_path)), timeout=150)
     parts = {}
     for r in range(2):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))

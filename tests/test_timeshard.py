@@ -34,16 +34,15 @@ def _oracle_process_factory(oracle, mode):
     return process
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
-    import torch.distributed as dist
     import wr_oracle as oracle
     from webradio_amd import timeshard
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _proc
+    dist = _proc.init_gloo(rank, world, os.path.join(outdir, "rdzv"))      # (one GPU on the test box: a gloo ring)
     T, n = CFG["T"], CFG["nchunks"]
     iq = _stream(T * n)
     ring = timeshard.RingHalo(dist, rank, world)
@@ -93,9 +92,8 @@ def test_single_rank_time_shard_equals_sequential(oracle):
 
 
 def test_two_ranks_gloo_ring_halo(tmp_path, oracle):
-    import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import _proc
+    _proc.spawn_ranks(_worker, 2, (2, str(tmp_path)), timeout=150)
     T, n = CFG["T"], CFG["nchunks"]
     parts = {}
     for r in range(2):

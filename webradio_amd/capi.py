@@ -16,7 +16,7 @@ WR_AM, WR_FM, WR_USB, WR_LSB = range(4)
 WR_STAGE_CHAN_IQ, WR_STAGE_DEMOD, WR_STAGE_AUDIO = 1, 2, 3
 WR_NCO_SPLIT, WR_NCO_EXACT, WR_NCO_ROTATE = 0, 1, 2
 WR_HOST, WR_DEVICE = 0, 1
-WR_ABI_VERSION = 3            # include/webradio_amd.h
+WR_ABI_VERSION = 4            # include/webradio_amd.h
 WR_FIR_LENGTH = 64
 WR_TABLE_SIZE = 65536
 
@@ -30,6 +30,7 @@ SIGNATURES = {
     "wr_abi_version": (C.c_int, []),
     "wr_last_error": (C.c_char_p, []),
     "wr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "wr_tune": (C.c_int, [C.c_int, C.c_long, C.POINTER(C.c_long)]),
     "wr_phase_step": (C.c_int, [C.c_int, _u32, C.POINTER(C.c_int)]),
     "wr_sin_table": (C.c_int, [_vp]),
     "wr_lowpass_design": (C.c_int, [_u32, _u32, _vp, C.POINTER(_u32)]),

@@ -259,6 +259,16 @@ static int dev_alloc_zero(T **p, size_t count)
 extern "C" int wr_abi_version(void) { return WR_ABI_VERSION; }
 extern "C" const char *wr_last_error(void) { return g_err; }
 
+extern "C" int wr_tune(int key, long value, long *previous)
+{
+	if (key != WR_TUNE_DDC_NG2_MIN_PASSES)
+		return fail(WR_ERR_ARG, "wr_tune: unknown key %d", key);
+	const long before = wrk_tune_ng2_min_passes(value, true);
+	if (previous)
+		*previous = before;
+	return WR_OK;
+}
+
 extern "C" int wr_device_count(int *count)
 {
 	if (!count)
@@ -584,8 +594,13 @@ extern "C" int wr_dev_wait_uploads_but(wr_dev *d, unsigned int newest)
 	const unsigned long long issued = d->uploads_issued;
 	if (issued <= d->uploads_done + newest)
 		return WR_OK;
-	const unsigned long long upto = issued - newest;       /* uploads 1..upto must have completed (stream order) */
-	HIP_TRY(hipEventSynchronize(d->upload_ev[upto % WR_UPLOAD_RING]));
+	/* uploads 1..upto must have completed.  They are not all on one stream (wr_dev_upload_async: the device's;
+	 * wr_dev_upload_ahead / wr_u8_to_f32_from_host: the upload stream), so the event of upload `upto` does not speak
+	 * for the ones before it: every event in (done, upto] is waited for -- at most WR_UPLOAD_RING - 1 of them, the
+	 * issuing side never lets more stay open */
+	const unsigned long long upto = issued - newest;
+	for (unsigned long long i = d->uploads_done + 1; i <= upto; ++i)
+		HIP_TRY(hipEventSynchronize(d->upload_ev[i % WR_UPLOAD_RING]));
 	d->uploads_done = upto;
 	return WR_OK;
 }
@@ -1862,6 +1877,9 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		if (prof_now) {
 			L.ev_start = t->ev[t->ev_used];     /* stamped by the launch itself (wrk_tuner_ddc) */
 			L.ev_stop = t->ev[t->ev_used + 1];
+			if (t->mark_launches)
+				unmarked = true;                /* the launch's stop event is the profiler's: the completion mark is an
+				                                   ordinary record behind it (below) */
 		} else if (t->mark_launches && g->l1 <= WR_FIR_LENGTH) {
 			L.ev_start = nullptr;               /* completion only: the slot of this submit (every rate group's launch
 			                                       stamps it in turn: the last one stands) */
@@ -2408,13 +2426,35 @@ extern "C" int wr_tuner_mark_launches(wr_tuner *t, int enable)
 		for (int i = 0; i < 4; ++i)
 			if (!t->launch_ev[i])
 				HIP_TRY(hipEventCreateWithFlags(&t->launch_ev[i], hipEventDisableTiming | hipEventReleaseToDevice));
+	if (enable && !t->mark_launches) {
+		/* blocks launched before marking was on carry no mark: one ordinary record behind them (and behind the held
+		 * ones, which go out now) stands for all of them */
+		if (int rc = tuner_launch_held(t))
+			return rc;
+		if (t->submitted) {
+			HIP_TRY(hipEventRecord(t->launch_ev[(t->launches_marked + 1) % 4], t->dev->stream));
+			++t->launches_marked;
+		}
+	}
 	t->mark_launches = enable != 0;
 	return WR_OK;
 }
 
-hipEvent_t wrc_tuner_last_launch(const wr_tuner *t)
+/* wr_ring_exchange_after: the event that fires when every block submitted to `t` so far has been read (*ev = nullptr:
+ * the tuner has launched nothing yet, nothing to wait for).  Blocks still held by wr_tuner_set_blocks_per_launch are
+ * launched first; a tuner that does not mark its launches is an error, not a silent "no ordering". */
+int wrc_tuner_launch_mark(wr_tuner *t, hipEvent_t *ev)
 {
-	return (t && t->mark_launches && t->launches_marked) ? t->launch_ev[t->launches_marked % 4] : nullptr;
+	*ev = nullptr;
+	if (!t->mark_launches)
+		return fail(WR_ERR_STATE, "wr_ring_exchange_after: wr_tuner_mark_launches(tuner, 1) first");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	if (int rc = tuner_launch_held(t))
+		return rc;
+	if (t->launches_marked)
+		*ev = t->launch_ev[t->launches_marked % 4];
+	return WR_OK;
 }
 
 /* --------------------------------------------------------------- spectrum -- */

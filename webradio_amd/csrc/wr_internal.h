@@ -24,7 +24,7 @@ int         wrc_fail(int code, const char *fmt, ...) __attribute__((format(print
 int         wrc_dev_index(const wr_dev *dev);
 hipStream_t wrc_dev_stream(const wr_dev *dev);
 /* the event the tuner's last launch stamped on completion (wr_tuner_mark_launches), or NULL (wr_ring.hip) */
-hipEvent_t  wrc_tuner_last_launch(const wr_tuner *t);
+int         wrc_tuner_launch_mark(wr_tuner *t, hipEvent_t *ev);
 
 /* ---- host design math (wr_design.cpp) ---- */
 void     wrd_sin_table(float *table);
@@ -148,6 +148,8 @@ struct WrPostArgs {
 /* `post` (optional): the post stage of the PREVIOUS block, run by extra workgroups of the same
  * launch beside this block's DDC (only taken up by the ROTATE / uniform-taps kernel; *post_taken
  * says whether it was) */
+/* WR_TUNE_DDC_NG2_MIN_PASSES: set (value < 0: default again) and/or read; returns the value in force before */
+long wrk_tune_ng2_min_passes(long value, bool set);
 hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G,
                          const float *table_dev, const float *hi_dev, const float *lo_dev,
                          int num_cus, const WrPostArgs *post = nullptr, bool *post_taken = nullptr);

@@ -23,6 +23,7 @@
  */
 #include "wr_internal.h"
 
+#include <atomic>
 #include <cstdlib>
 
 #include <hip/hip_ext.h>
@@ -2192,6 +2193,21 @@ hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t c
  *   ROTATE, per-lane taps: 16 x 1 -- one lane group's taps (16 KiB) per workgroup
  *   SPLIT                : 16 x 1 -- the replicated tables take 128 KiB
  *   EXACT                : 16 x 2 -- small LDS footprint, two workgroups hide the gather latency */
+/* include/webradio_amd.h: WR_TUNE_DDC_NG2_MIN_PASSES */
+static std::atomic<long> g_ng2_min_passes{-1};
+long wrk_tune_ng2_min_passes(long value, bool set)
+{
+	static const long builtin = [] {
+		const char *e = getenv("WR_DDC_NG2_MIN_PASSES");
+		return (long)((e && *e) ? strtoul(e, nullptr, 0) : 4ul);
+	}();
+	const long v = g_ng2_min_passes.load(std::memory_order_relaxed);
+	const long before = v < 0 ? builtin : v;
+	if (set)
+		g_ng2_min_passes.store(value < 0 ? -1 : value, std::memory_order_relaxed);
+	return before;
+}
+
 template <int NCO, bool UTAPS> struct DdcGeom {
 	static constexpr unsigned int waves = (NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL)) ? DDC_ROTATE_WAVES : DDC_WAVES;
 	static constexpr unsigned int wgs_per_cu = (NCO == WR_NCO_ROTATE && (UTAPS || DDC_LTAPS_SMALL)) ? DDC_ROTATE_WGS_PER_CU
@@ -2216,10 +2232,7 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 		 * with few passes per wave the grid ends ragged (BASELINE config 5: 5 065 frames per chunk, 2.5 passes per
 		 * wave -- 48 us against 43 with one lane group per wave); from four passes on the shared reads win */
 		const size_t waves2 = (size_t)num_cus * (DDC_NG2_WAVES_PER_EU * 4u / W - (PD2 ? 1u : 0u)) * W;
-		static const size_t min_passes = [] {                /* WR_DDC_NG2_MIN_PASSES=0: always (the tests' small streams) */
-			const char *e = getenv("WR_DDC_NG2_MIN_PASSES");
-			return (size_t)((e && *e) ? strtoul(e, nullptr, 0) : 4ul);
-		}();
+		const size_t min_passes = (size_t)wrk_tune_ng2_min_passes(0, false);      /* wr_tune: 0 = always */
 		if (L.one_filter && n >= 2u && n <= 16u && (n & 1u) == 0u && L.k1 * (n / 2u) >= min_passes * waves2)
 			return launch_ddc<NCO, UTAPS, PD2, 2u>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, gsel, whole);
 	}
@@ -2328,8 +2341,8 @@ static hipError_t launch_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGro
 			return e;
 	}
 	const WrPostArgs pa = post ? *post : WrPostArgs();
-	if (L.ev_stop) {
-		/* profiling (both events) or a caller that wants to wait for THIS launch from another stream (the stop event
+	if (L.ev_start || L.ev_stop) {
+		/* profiling (both events; with two launches per rate group the first takes the start, the last the stop) or a caller that wants to wait for THIS launch from another stream (the stop event
 		 * alone, wr_tuner_mark_launches): the launch stamps the events with the dispatch's own start and end, as
 		 * rocprof sees them -- events recorded around it would add their own barrier packets */
 		hipExtLaunchKernelGGL((k_tuner_ddc<NCO, UTAPS, PD2, NG>), dim3(wgs + n_bnd + post_wgs), dim3(W * 64u), (uint32_t)lds, st,
@@ -2391,12 +2404,18 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 	if (uni) {
 		hipError_t e;
 		const unsigned long long sel = (uni == all) ? 0ull : uni;
+		/* two launches (uniform + odd groups): the FIRST stamps the start event, the LAST the stop event -- the
+		 * completion mark of wr_tuner_mark_launches must not fire while the second launch still reads the block
+		 * (r03 gave both to the first: a halo exchange ordered behind the mark could overwrite its input) */
+		WrTunerLaunch L1 = L;
+		if (odd)
+			L1.ev_stop = nullptr;
 		if (NCO == WR_NCO_ROTATE && post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
 			if (post_taken)
 				*post_taken = true;
-			e = launch_ddc_riding<NCO, true>(post->d2, st, L, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true);
+			e = launch_ddc_riding<NCO, true>(post->d2, st, L1, G, table_dev, hi_dev, lo_dev, num_cus, post, sel, true);
 		} else {
-			e = launch_ddc<NCO, true, 0>(st, L, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, sel, true);
+			e = launch_ddc<NCO, true, 0>(st, L1, G, table_dev, hi_dev, lo_dev, num_cus, nullptr, sel, true);
 		}
 		if (e != hipSuccess)
 			return e;
@@ -2404,7 +2423,7 @@ static hipError_t launch_ddc_fast(hipStream_t st, const WrTunerLaunch &L, const 
 	}
 	if (odd || !uni) {
 		WrTunerLaunch L2 = L;
-		L2.ev_start = L2.ev_stop = nullptr;                 /* the profiling events went to the first launch */
+		L2.ev_start = nullptr;                              /* the start event went to the first launch */
 		const unsigned long long sel = (odd == all) ? 0ull : odd;
 		if (!uni && NCO == WR_NCO_ROTATE && post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2)) {
 			/* no lane group left for the fast kernel (every group holds more than WR_TAPSETS channel

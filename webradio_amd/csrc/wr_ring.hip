@@ -166,7 +166,7 @@ extern "C" int wr_ring_create(wr_ring **out, wr_dev *dev, const void *id, size_t
 	return WR_OK;
 }
 
-static int ring_exchange(wr_ring *r, const wr_tuner *after, const float *send_dev, float *recv_dev, size_t nfloats)
+static int ring_exchange(wr_ring *r, wr_tuner *after, const float *send_dev, float *recv_dev, size_t nfloats)
 {
 	if (!r || !send_dev || !recv_dev || !nfloats)
 		return wrc_fail(WR_ERR_ARG, "wr_ring_exchange: bad argument");
@@ -174,7 +174,10 @@ static int ring_exchange(wr_ring *r, const wr_tuner *after, const float *send_de
 		return wrc_fail(WR_ERR_ARG, "wr_ring_exchange: send and receive buffers must differ");
 	HIP_TRY_R(hipSetDevice(wrc_dev_index(r->dev)));
 	hipStream_t main = wrc_dev_stream(r->dev);
-	hipEvent_t launch = after ? wrc_tuner_last_launch(after) : nullptr;
+	hipEvent_t launch = nullptr;
+	if (after)
+		if (int rc = wrc_tuner_launch_mark(after, &launch))
+			return rc;                                      /* (not marking its launches: WR_ERR_STATE) */
 	if (launch) {
 		/* behind the tuner's last launch: its own completion signal, nothing put on the device's stream (an event
 		 * record there sits between two launches and costs the chunk 11 us: 452 -> 606 Gsps at world 1, r03) */
