@@ -17,12 +17,20 @@
  *   DspBlock scheduling pinned -- host runtime checked against the real
  *                                 dsp/dspblock.cxx in oracle/_ref.
  *   wro_sin_table / wro_phase_step / wro_mix / wro_lowpass_* / wro_fir_* /
- *   wro_spectrum_*     PARITY UNPINNED -- downconverter.cxx, lowpass.cxx and
- *                                 spectrumsink.cxx include <fftw3.h>, which this
- *                                 image lacks; the reference holds no golden
- *                                 vectors or tests.  These are anchored only on
- *                                 the survey's recorded known answers
- *                                 (tests/test_oracle_known_answers.py).
+ *   wro_spectrum_* / the whole Receiver chain
+ *                      pinned since r04, with a qualifier -- downconverter.cxx, lowpass.cxx
+ *                                 and spectrumsink.cxx call FFTW3, which this image lacks; the
+ *                                 image's own FFTW3-API library (hipFFTW over rocFFT) serves
+ *                                 those calls in oracle/_ref/libwr_ref_chain.so
+ *                                 (oracle/ref_chain.cxx, `make ref_chain`), which runs where a
+ *                                 GPU is.  Checked live on the GPU box
+ *                                 (tests/test_gpu_reference_pin.py) and through the vectors it
+ *                                 produced there (tests/golden/reference_chain.npz,
+ *                                 tests/test_oracle_reference_chain.py): mixer bit-identical,
+ *                                 taps <= 3e-8, chain <= 3e-8, spectrum <= 4e-4 dB
+ *                                 (profiles/r04_reference_pin.txt).  The qualifier: the FFT under
+ *                                 the reference is rocFFT, not FFTW3 itself (upstream pins no
+ *                                 FFTW version either, configure.ac:32).
  */
 #ifndef WR_ORACLE_H_
 #define WR_ORACLE_H_

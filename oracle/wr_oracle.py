@@ -355,3 +355,73 @@ def ref_demod(mode_name, iq, block_frames, switch_at=-1, mode2=None):
                              mode2.encode() if mode2 else None, _p(out), n)
     assert got >= 0, got
     return out[:got].copy()
+
+
+# ---- r04: the reference's FFTW-calling blocks (oracle/ref_chain.cxx), over the image's hipFFTW --------------------
+REF_CHAIN_LIB = os.path.join(_HERE, "_ref", "libwr_ref_chain.so")
+_ref_chain = None
+
+
+def ref_chain():
+    """libwr_ref_chain.so -- the REAL dsp/downconverter.cxx, dsp/lowpass.cxx, dsp/demodulator.cxx,
+    io/spectrumsink.cxx behind ref_chain.cxx, linked with the image's FFTW3-API library (hipFFTW:
+    rocFFT underneath, so it RUNS only where a GPU is) -- or None when it has not been built."""
+    global _ref_chain
+    if _ref_chain is None:
+        if not os.path.exists(REF_CHAIN_LIB):
+            if not os.path.isdir(REFERENCE_ROOT):
+                return None
+            subprocess.check_call(["make", "-s", "-C", _HERE, "ref_chain"])
+        R = C.CDLL(REF_CHAIN_LIB)
+        R.ref_lowpass_impulse_response.restype = C.c_int
+        R.ref_lowpass_impulse_response.argtypes = [C.c_uint, C.c_uint, _fp, C.c_uint]
+        R.ref_receiver_chain.restype = C.c_int
+        R.ref_receiver_chain.argtypes = [C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, _fp,
+                                         C.c_size_t, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
+        R.ref_downconverter.restype = C.c_int
+        R.ref_downconverter.argtypes = [C.c_uint, C.c_int, _fp, C.c_size_t, C.c_size_t, _fp]
+        R.ref_spectrum.restype = C.c_int
+        R.ref_spectrum.argtypes = [C.c_uint, C.c_uint, _fp, C.c_size_t, C.c_size_t, _fp]
+        _ref_chain = R
+    return _ref_chain
+
+
+def ref_lowpass_taps(passband, rate, ntaps=64):
+    """the reference LowPass's coefficients, observed as its impulse response"""
+    t = np.empty(ntaps, np.float32)
+    got = ref_chain().ref_lowpass_impulse_response(passband, rate, _p(t), ntaps)
+    assert got == ntaps, got
+    return t
+
+
+def ref_receiver(fs, if_hz, chan_passband, chan_rate, mode, audio_passband, audio_rate, iq, block_frames):
+    """(audio, chan_iq, demod) of the reference's own Receiver chain over the whole of `iq`, block by block"""
+    iq = _f32(iq)
+    n = iq.size // 2
+    d1, d2 = fs // chan_rate, chan_rate // audio_rate
+    k1 = n // d1
+    chan = np.empty(2 * k1 + 2, np.float32)
+    dem = np.empty(k1 + 1, np.float32)
+    aud = np.empty(k1 // d2 + 1, np.float32)
+    made = (C.c_size_t * 3)()
+    rc = ref_chain().ref_receiver_chain(fs, if_hz, chan_passband, chan_rate, mode, audio_passband, audio_rate, _p(iq), n,
+                                        block_frames, _p(chan), chan.size, _p(dem), dem.size, _p(aud), aud.size, made)
+    assert rc == 0, rc
+    return aud[:made[2]].copy(), chan[:made[0]].copy(), dem[:made[1]].copy()
+
+
+def ref_mix(fs, if_hz, iq, block_frames):
+    iq = _f32(iq)
+    out = np.empty_like(iq)
+    rc = ref_chain().ref_downconverter(fs, if_hz, _p(iq), iq.size // 2, block_frames, _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def ref_spectrum_db(fs, fft_size, iq, block_frames):
+    iq = _f32(iq)
+    db = np.empty(fft_size, np.float32)
+    rc = ref_chain().ref_spectrum(fs, fft_size, _p(iq), iq.size // 2, block_frames, _p(db))
+    assert rc == 0, rc
+    return db

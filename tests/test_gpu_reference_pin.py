@@ -1,0 +1,150 @@
+"""-m gpu: the REAL reference blocks run live on this box -- dsp/downconverter.cxx, dsp/lowpass.cxx,
+dsp/demodulator.cxx, io/spectrumsink.cxx behind oracle/ref_chain.cxx (oracle/_ref/libwr_ref_chain.so), their FFTW
+calls served by the image's hipFFTW, which needs the GPU -- and are compared with (1) the oracle, (2) the HIP path
+through the C ABI, (3) the vectors committed under tests/golden/ (the same reference, run when they were made).
+
+oracle/_ref/ travels to the GPU box prebuilt (the sources it is built from exist only in the build container).
+Where it is missing the tests SKIP and say so: the committed vectors still hold the oracle (CPU test
+tests/test_oracle_reference_chain.py) and, below, the HIP path."""
+import os
+
+import numpy as np
+import pytest
+
+import refcases
+from webradio_amd import capi
+from webradio_amd.device import Tuner, Spectrum
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "reference_chain.npz")
+
+
+@pytest.fixture(scope="module")
+def live(oracle, tmp_path_factory):
+    """What the reference produces on THIS box, now: tests/golden/make_reference_chain_golden.py in a process of its
+    own (hipFFTW brings the system's HIP runtime, the rest of the suite runs on torch's: one process cannot hold both)."""
+    if not os.path.exists(oracle.REF_CHAIN_LIB):
+        pytest.skip("oracle/_ref/libwr_ref_chain.so not built (needs /root/reference at build time)")
+    import sys
+    import _proc
+    out = str(tmp_path_factory.mktemp("refchain") / "live.npz")
+    _proc.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_reference_chain_golden.py"), out], timeout=240,
+              env=dict(os.environ, WEBRADIO_QUIET="1"))
+    return np.load(out)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLDEN) if os.path.exists(GOLDEN) else None
+
+
+@pytest.mark.parametrize("pb,rate", refcases.LOWPASS)
+def test_live_lowpass_taps(live, oracle, gold, pb, rate):
+    """LowPass::init/recalculate (lowpass.cxx:81-116,164-197) observed as the impulse response of the running
+    block, against the oracle's design AND the C ABI's (wr_lowpass_design is what the product uploads)."""
+    import ctypes as C
+    want = live["taps_%d_%d" % (pb, rate)]
+    assert np.abs(oracle.lowpass_design(pb, rate) - want).max() <= refcases.TAPS_TOL
+    ours = np.empty(64, np.float32)
+    maxbin = C.c_uint()
+    assert capi.load().wr_lowpass_design(pb, rate, capi.ptr(ours), C.byref(maxbin)) == 0
+    assert np.abs(ours - want).max() <= refcases.TAPS_TOL
+    assert (maxbin.value == 0) == (not want.any())
+    if gold is not None:
+        assert np.abs(gold["taps_%d_%d" % (pb, rate)] - want).max() <= 1e-9      # the same library, the same answer
+
+
+@pytest.mark.parametrize("name", sorted(refcases.MIXES))
+def test_live_mixer(live, oracle, dev, name):
+    """DownConverter::process (downconverter.cxx:91-114): the oracle and wr_mix (k_mix, EXACT arithmetic) give the
+    reference's bits."""
+    import ctypes as C
+    import torch
+    c = refcases.MIXES[name]
+    iq = refcases.mix_input(c)
+    want = live["mix_" + name]
+    step = oracle.phase_step(c["if_hz"], c["fs"])
+    got, _ = oracle.mix(oracle.sin_table(), 0, step, iq)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    x = torch.from_numpy(iq).cuda()
+    y = torch.empty_like(x)
+    ph = C.c_uint(0)
+    assert dev.lib.wr_mix(dev.h, capi.ptr(x), capi.ptr(y), iq.size // 2, C.byref(ph), step) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def _hip_chain(dev, c, iq, nco):
+    t = Tuner(dev, c["fs"], 1, c["block"], nco)
+    ch = t.add_receiver(c["if_hz"], c["cpb"], c["crate"], c["mode"], c["apb"], c["arate"])
+    t.keep_stages(capi.WR_STAGE_DEMOD)
+    n = c["block"]
+    audio, chan, dem = [], [], []
+    for b in range(c["blocks"]):
+        t.submit_host(iq[2 * n * b: 2 * n * (b + 1)])
+        chan.append(t.fetch(ch, capi.WR_STAGE_CHAN_IQ, 2 * n))
+        dem.append(t.fetch(ch, capi.WR_STAGE_DEMOD, n))
+        audio.append(t.fetch(ch, capi.WR_STAGE_AUDIO, n))
+    t.destroy()
+    return np.concatenate(audio), np.concatenate(chan), np.concatenate(dem)
+
+
+@pytest.mark.parametrize("name", sorted(refcases.CHAINS))
+def test_live_receiver_chain(live, oracle, dev, gold, name):
+    """The Receiver chain of radio.cxx:68-83 on the reference's own blocks: channel IQ, demodulator output and
+    audio of the oracle and of the HIP path (EXACT and ROTATE NCO) within the stated tolerances."""
+    c = refcases.CHAINS[name]
+    iq = refcases.chain_input(c)
+    assert np.array_equal(refcases.sha(iq), live["sha_chain_" + name])
+    w_audio, w_chan, w_dem = (live["chain_%s_%s" % (name, k)] for k in ("audio", "chan", "demod"))
+    assert w_audio.size == c["blocks"] * (c["block"] // (c["fs"] // c["crate"]) // (c["crate"] // c["arate"]))
+    rx = oracle.Receiver(c["fs"], c["if_hz"], c["cpb"], c["crate"], c["mode"], c["apb"], c["arate"])
+    n = c["block"]
+    parts = [rx.run(iq[2 * n * b: 2 * n * (b + 1)]) for b in range(c["blocks"])]
+    o_audio, o_chan, o_dem = (np.concatenate([p[i] for p in parts]) for i in range(3))
+    for got, want, tol in ((o_chan, w_chan, refcases.CHAN_TOL), (o_dem, w_dem, refcases.AUDIO_TOL), (o_audio, w_audio, refcases.AUDIO_TOL)):
+        assert got.shape == want.shape and np.abs(got - want).max() <= tol
+    for nco in (capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE):
+        g_audio, g_chan, g_dem = _hip_chain(dev, c, iq, nco)
+        assert g_chan.shape == w_chan.shape and np.abs(g_chan - w_chan).max() <= refcases.CHAN_TOL, nco
+        assert g_audio.shape == w_audio.shape and np.abs(g_audio - w_audio).max() <= refcases.AUDIO_TOL, nco
+        assert np.abs(g_dem - w_dem).max() <= refcases.AUDIO_TOL, nco
+    if gold is not None:
+        assert np.abs(gold["chain_%s_audio" % name] - w_audio).max() <= 1e-7
+
+
+@pytest.mark.parametrize("name", sorted(refcases.SPECTRA))
+def test_live_spectrum(live, oracle, dev, gold, name):
+    """SpectrumSink (spectrumsink.cxx:60-142) on the reference's own code: dB with fft-shift after the last block,
+    against the oracle and wr_spectrum_* (k_fft*)."""
+    c = refcases.SPECTRA[name]
+    iq = refcases.spectrum_input(c)
+    want = live["spec_" + name]
+    strong = want >= want.max() - 60.0
+    o = oracle.Spectrum(c["n"])
+    s = Spectrum(dev, c["n"])
+    n = c["block"]
+    for b in range(c["blocks"]):
+        o.process(iq[2 * n * b: 2 * n * (b + 1)])
+        s.push_host(iq[2 * n * b: 2 * n * (b + 1)])
+    assert np.abs(o.get() - want)[strong].max() <= refcases.DB_TOL
+    got = s.get_db()
+    s.destroy()
+    assert np.abs(got - want)[strong].max() <= refcases.DB_TOL
+    assert int(np.argmax(got)) == int(np.argmax(want))
+    if gold is not None:
+        assert np.abs(gold["spec_" + name] - want)[strong].max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(refcases.CHAINS))
+def test_hip_path_against_committed_reference_vectors(dev, name):
+    """No oracle/_ref needed: the HIP path against what the reference produced when the vectors were made."""
+    assert os.path.exists(GOLDEN), "tests/golden/reference_chain.npz is missing"
+    g = np.load(GOLDEN)
+    c = refcases.CHAINS[name]
+    iq = refcases.chain_input(c)
+    assert np.array_equal(refcases.sha(iq), g["sha_chain_" + name])
+    audio, chan, dem = _hip_chain(dev, c, iq, capi.WR_NCO_ROTATE)
+    assert np.abs(chan - g["chain_%s_chan" % name]).max() <= refcases.CHAN_TOL
+    assert np.abs(audio - g["chain_%s_audio" % name]).max() <= refcases.AUDIO_TOL

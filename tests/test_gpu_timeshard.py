@@ -115,30 +115,54 @@ def test_native_ring_world_one_bit_identical(dev):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_ring_exchange_after_the_tuners_launches(dev):
+def _receivers(which):
+    if which == "uniform-and-odd-groups":
+        # 64 receivers on one channel filter (a lane group for the uniform-taps kernel) + 6 with six different filters
+        # (more than WR_TAPSETS: the per-lane-taps kernel): TWO DDC launches per submit
+        rx = [((c - 32) * 20_000 + 777, 128_000) for c in range(64)]
+        return rx + [(900_000 - 30_000 * i, pb) for i, pb in enumerate((64_000, 128_000, 190_000, 250_000, 320_000, 380_000))]
+    return [(f, 128_000) for f in IFS]
+
+
+@pytest.mark.parametrize("which", ["plain", "profiled-every-launch", "uniform-and-odd-groups", "marking-switched-on-late"])
+def test_ring_exchange_after_the_tuners_launches(dev, which):
     """wr_ring_exchange_after + wr_tuner_mark_launches, used the way bench.py --workload c5 uses them: resident chunks in a
     rotation of three [halo | chunk] buffers, every halo through ncclSend / ncclRecv (world 1: to itself), posted a round
     ahead and ordered behind the TUNER's launches (their own completion events) instead of an event record on the
     device's stream; nothing fetched between the chunks (one launch per chunk: lazy seek, riding post stage).
-    The audio is the sequential pass's, bit for bit."""
+    The audio is the sequential pass's, bit for bit.
+
+    r04: also with every launch profiled (the launch's stop event is the profiler's then: the mark is an
+    ordinary record), with two DDC launches per submit (the LAST one carries the mark), and with marking switched on
+    when a block is already in flight."""
     import torch
     nco = capi.WR_NCO_ROTATE
     H = timeshard.halo_frames(D1, D2)
+    rxs = _receivers(which)
     iq = torch.from_numpy(_stream()).cuda()
     nb = 3
     bufs = [torch.zeros(2 * (H + T), device="cuda") for _ in range(nb)]
-    t = Tuner(dev, FS, len(IFS), T + H, nco)
-    chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_FM, 160, 1_000) for f in IFS]
+    t = Tuner(dev, FS, len(rxs), T + H, nco)
+    chans = [t.add_receiver(f, pb, 5_000, capi.WR_FM, 160, 1_000) for f, pb in rxs]
     t.audio_ring(N)
-    t.mark_launches(True)
+    late = which == "marking-switched-on-late"
+    if not late:
+        t.mark_launches(True)
+    if which == "profiled-every-launch":
+        t.profile(1)
     ring = timeshard.RingHalo(None, 0, 1, dev=dev)
 
     def load(c):                                              # chunk c into its buffer (behind the halo)
         bufs[c % nb][2 * H:].copy_(iq[2 * c * T: 2 * (c + 1) * T])
 
     load(0)
+    if late:
+        # a tuner that does not mark its launches cannot order an exchange: an error, not a silent race
+        assert dev.lib.wr_ring_exchange_after(ring.native.h, t.h, capi.ptr(bufs[0][2 * T:]), capi.ptr(bufs[1][: 2 * H]),
+                                              2 * H) == capi.WR_ERR_STATE
+        assert b"wr_tuner_mark_launches" in dev.lib.wr_last_error()
     for c in range(N):
-        if c + 1 < N:
+        if c + 1 < N and not (late and c == 0):
             load(c + 1)
             # chunk c + 1's halo = the last H frames of chunk c: to the ring neighbour (ourselves), a round ahead
             ring.post(bufs[c % nb][2 * T:], bufs[(c + 1) % nb][: 2 * H], t)
@@ -148,9 +172,17 @@ def test_ring_exchange_after_the_tuners_launches(dev):
         else:
             t.seek(c * T - H)
             t.submit_device(bufs[c % nb], H + T)
+        if late and c == 0:
+            t.mark_launches(True)                             # chunk 0 is in flight, unmarked: one record stands for it
+            load(1)
+            ring.post(bufs[0][2 * T:], bufs[1][: 2 * H], t)
         if c + 1 < N:
             ring.wait()                                       # before the next chunk's submit reads its halo
     t.flush()
+    if which == "profiled-every-launch":
+        launches, ms = t.profile_read()
+        assert launches == N and ms > 0
+        t.profile(False)
     got = []
     drop = H // (D1 * D2)
     slots = [t.slot(ch) for ch in chans]
@@ -163,7 +195,11 @@ def test_ring_exchange_after_the_tuners_launches(dev):
     ring.close()
     t.destroy()
     got = np.concatenate(got, axis=1)
-    want = _sequential(dev, nco)
+    t = Tuner(dev, FS, len(rxs), T * N, nco)                  # the sequential pass of the same receivers
+    chans = [t.add_receiver(f, pb, 5_000, capi.WR_FM, 160, 1_000) for f, pb in rxs]
+    t.submit_host(_stream())
+    want = np.stack([t.fetch(ch, capi.WR_STAGE_AUDIO, T * N) for ch in chans])
+    t.destroy()
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
     # the argument checks of the new entry points
     assert dev.lib.wr_tuner_mark_launches(None, 1) == capi.WR_ERR_ARG
