@@ -43,7 +43,7 @@ extern "C" {
                                     blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream, incl.
                                     wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
                                     wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
-                                    4: wr_tune added.  Nothing of an earlier version changed or removed */
+                                    4: wr_tune, wr_stage_windows_from_host added.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
@@ -190,6 +190,16 @@ int wr_u8_to_f32(wr_dev *dev, const uint8_t *in_dev, float *out_dev, size_t coun
  * device's stream waits for the copy and converts: work enqueued after the call sees `out_dev` filled, in stream order
  * like any kernel's output, and the transfer of block b + 1 runs beside the kernels of block b. */
 int wr_u8_to_f32_from_host(wr_dev *dev, const uint8_t *in_host_registered, float *out_dev, size_t count);
+/* r04, sparse staging: of a block of `nframes` IQ frames in page-locked host memory (bytes when is_u8, else float32
+ * pairs) bring over only what a tuner whose channel filters all have `length` taps and decimate by `period` reads --
+ * frames [k * period - (length - 1), k * period] of every output frame k (dsp/lowpass.cxx:145-159), widened to 16-byte
+ * boundaries -- plus the last `tail_frames` frames (the next block's filter history; a SpectrumSink's current frame), to
+ * the SAME positions of the float block at `out_dev`; the frames in between are left as they are.  At BASELINE config 2
+ * (length 64, period 400) that is a sixth of the block over PCIe.  The kernel reads the host memory itself, on the device's
+ * stream (in order with the tuner's launches behind it); counts as an upload in flight like the call above.
+ * A submit that follows must use the same `length` and `period` for ALL its receivers. */
+int wr_stage_windows_from_host(wr_dev *dev, const void *in_host_registered, int is_u8, float *out_dev, size_t nframes,
+                               unsigned int period, unsigned int length, size_t tail_frames);
 
 /* ------------------------------------------------- fused per-tuner path -- */
 /* One wr_tuner = one FrontEnd's tuner (radio.cxx:120-133) with all the Receivers

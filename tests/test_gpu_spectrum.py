@@ -68,19 +68,24 @@ def test_streaming_partial_frames(dev, oracle):
     s.destroy()
 
 
+@pytest.mark.parametrize("tail_only", [False, True], ids=["whole-block", "tail-only"])
 @pytest.mark.parametrize("n,hop", [(1024, 0), (4096, 2048), (512, 0)])
-def test_device_pushes_in_place(dev, oracle, n, hop):
+def test_device_pushes_in_place(dev, oracle, n, hop, tail_only):
     """Blocks that already lie in device memory (the staged tuner block): with nothing carried over the most
     recent frame is transformed where it lies and only the tail is kept (r03); blocks that are not a
     multiple of the hop leave a tail, the next push takes the staged path and carries it on.  Against the
     oracle fed the same stream (spectrumsink.cxx:101-121), push after push."""
     h = hop or n
-    sizes = [4 * n, 3 * n + 77, 5 * h - 77, 2 * n, n + 1, 6 * n]          # exact, ragged, back to exact, ...
+    sizes = [4 * n, 3 * n + 77, 5 * h - 77, 2 * n, n + 1, 6 * n, 2 * n + h + 5, 3 * n + 1]   # exact, ragged, back to exact, ...
     iq = synth.fm_stream(sum(sizes), 2_400_000, [250_000, -400_000], amp=0.3)
     s = Spectrum(dev, n, hop)
     pos, done = 0, 0
     for sz in sizes:
-        part = np.ascontiguousarray(iq[2 * pos: 2 * (pos + sz)])
+        part = np.array(iq[2 * pos: 2 * (pos + sz)])
+        if tail_only and sz > n + h:
+            # r04: a block of fftSize + hop frames or more is read from its most recent complete frame on, whatever was
+            # carried over: the host runtime stages only that tail of a source block (stagedTail) -- the rest is NaN here
+            part[: 2 * (sz - (n + h))] = np.nan
         p = dev.upload(part)
         s.push_device(p, sz)
         dev.sync()

@@ -1,0 +1,107 @@
+"""-m gpu: sparse staging (wr_stage_windows_from_host, r04): of a host block only the frames the tuner's taps reach --
+[k * period - (length - 1), k * period] for every output frame k -- and the block's tail cross PCIe; they land at their own
+positions of the staged float block, bit for bit what the whole-block paths put there, and a tuner fed from such a block
+gives the very audio it gives from the whole block."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from webradio_amd import capi, synth
+from webradio_amd.device import Tuner
+
+pytestmark = pytest.mark.gpu
+
+
+def _pinned(dev, arr):
+    assert dev.lib.wr_dev_host_register(dev.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes) == 0, dev.lib.wr_last_error()
+    return arr
+
+
+def _needed(nframes, period, length, tail):
+    need = np.zeros(nframes, bool)
+    for k in range(nframes // period + 1):
+        lo, hi = max(0, k * period - (length - 1)), min(nframes - 1, k * period)
+        if lo <= hi:
+            need[lo:hi + 1] = True
+    need[max(0, nframes - tail):] = True
+    return need
+
+
+@pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32"])
+@pytest.mark.parametrize("nframes,period,length,tail", [(40_000, 400, 64, 63), (100_000, 4000, 64, 1200), (8_192, 130, 64, 64),
+                                                       (20_000, 400, 32, 700), (30_001, 333, 64, 100), (1_000, 2_000, 64, 63),
+                                                       (640, 64, 64, 640)])
+def test_windows_and_tail_land_where_the_whole_block_puts_them(dev, u8, nframes, period, length, tail):
+    import torch
+    rng = np.random.default_rng(nframes + period)
+    if u8:
+        host = _pinned(dev, rng.integers(0, 256, 2 * nframes + 64, dtype=np.uint8)[: 2 * nframes])
+        want = ((host.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)).astype(np.float32)
+    else:
+        host = _pinned(dev, rng.standard_normal(2 * nframes).astype(np.float32))
+        want = host
+    assert host.ctypes.data % 16 == 0
+    out = torch.full((2 * nframes,), float("nan"), device="cuda")
+    assert dev.lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), int(u8), capi.ptr(out), nframes, period,
+                                              length, tail) == 0, dev.lib.wr_last_error()
+    assert dev.lib.wr_dev_wait_uploads(dev.h) == 0
+    got = out.cpu().numpy().reshape(-1, 2)
+    need = _needed(nframes, period, length, tail)
+    w = want.reshape(-1, 2)
+    assert np.array_equal(got[need].view(np.uint32), w[need].view(np.uint32))            # everything the taps reach: exact
+    staged = ~np.isnan(got[:, 0])
+    assert np.array_equal(got[staged].view(np.uint32), w[staged].view(np.uint32))        # and nothing staged is wrong
+    if period >= 4 * length and nframes >= 8 * period:
+        assert staged.mean() < 0.5                                                       # it IS sparse
+    dev.lib.wr_dev_host_unregister(dev.h, host.ctypes.data_as(C.c_void_p))
+
+
+def test_argument_checks(dev):
+    import torch
+    out = torch.zeros(1024, device="cuda")
+    host = np.zeros(1024, np.float32)                          # not page-locked
+    lib = dev.lib
+    assert lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), 0, capi.ptr(out), 512, 100, 64, 63) == capi.WR_ERR_ARG
+    assert b"page-locked" in lib.wr_last_error()
+    assert lib.wr_stage_windows_from_host(None, None, 0, None, 0, 100, 64, 0) == capi.WR_ERR_ARG
+    assert lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), 0, capi.ptr(out), 512, 0, 64, 63) == capi.WR_ERR_ARG
+    assert lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), 0, capi.ptr(out), 512, 100, 256, 63) == capi.WR_ERR_ARG
+
+
+@pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32"])
+def test_tuner_fed_from_a_sparsely_staged_block(dev, u8):
+    """Three consecutive blocks at C2's ratios (D1 = 400, 64 taps): the audio of a tuner whose blocks were staged sparsely is
+    the audio of the same tuner fed the whole blocks -- the kernel reads nothing the sparse stage left out."""
+    import torch
+    fs, n = 2_000_000, 80_000
+    ifs = [(-4 + c) * 6250 + 1234 for c in range(8)]
+    iq = synth.fm_stream(3 * n, fs, ifs[::2], fm_base=30.0, beta=2.0)
+    if u8:
+        raw = np.clip(np.round(127.5 + 127.0 * iq), 0, 255).astype(np.uint8)
+        full = ((raw.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)).astype(np.float32)
+    else:
+        raw, full = iq, iq
+    raw = _pinned(dev, raw.copy())
+    want, got = [], []
+    for sparse in (False, True):
+        t = Tuner(dev, fs, 8, n, capi.WR_NCO_ROTATE)
+        chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_FM, 160, 1_000) for f in ifs]
+        rows = []
+        stage = torch.full((2 * n,), float("nan"), device="cuda")
+        for b in range(3):
+            if sparse:
+                piece = raw[2 * n * b: 2 * n * (b + 1)]
+                assert dev.lib.wr_stage_windows_from_host(dev.h, piece.ctypes.data_as(C.c_void_p), int(u8), capi.ptr(stage), n,
+                                                          400, 64, 63) == 0, dev.lib.wr_last_error()
+                t.submit_device(stage, n)
+            else:
+                t.submit_host(full[2 * n * b: 2 * n * (b + 1)])
+            rows.append(np.stack([t.fetch(ch, capi.WR_STAGE_AUDIO, n) for ch in chans]))
+            stage.fill_(float("nan"))
+        t.destroy()
+        (got if sparse else want).append(np.concatenate(rows, axis=1))
+    dev.lib.wr_dev_wait_uploads(dev.h)
+    dev.lib.wr_dev_host_unregister(dev.h, raw.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    assert np.isfinite(got[0]).all() and np.abs(got[0]).max() > 1e-3

@@ -55,6 +55,7 @@ SIGNATURES = {
     "wr_fir_decimate_n": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp]),
     "wr_demod": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _vp]),
     "wr_u8_to_f32": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "wr_stage_windows_from_host": (C.c_int, [_vp, _vp, C.c_int, _vp, _sz, _u32, _u32, _sz]),
     "wr_u8_to_f32_from_host": (C.c_int, [_vp, _vp, _vp, _sz]),
     "wr_tuner_create": (C.c_int, [C.POINTER(_vp), _vp, _u32, _u32, _sz, C.c_int]),
     "wr_tuner_destroy": (C.c_int, [_vp]),

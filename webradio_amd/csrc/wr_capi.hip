@@ -793,6 +793,28 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 	return WR_OK;
 }
 
+extern "C" int wr_stage_windows_from_host(wr_dev *d, const void *in_host, int is_u8, float *out_dev, size_t nframes,
+                                          unsigned int period, unsigned int length, size_t tail_frames)
+{
+	if (!d || (nframes && (!in_host || !out_dev)) || !period || !length)
+		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: bad argument");
+	if (length > (is_u8 ? 480u : 120u))
+		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: windows of %u frames are too long for one wave", length);
+	if (((uintptr_t)in_host | (uintptr_t)out_dev) & 15u)
+		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: both buffers must be 16-byte aligned");
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	void *mapped = nullptr;
+	hipError_t e = hipHostGetDevicePointer(&mapped, const_cast<void *>(in_host), 0);
+	if (e != hipSuccess || !mapped) {
+		(void)hipGetLastError();
+		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: the buffer is not page-locked (wr_dev_host_register): %s",
+		            hipGetErrorString(e));
+	}
+	HIP_TRY(wrk_stage_windows(d->stream, mapped, is_u8 != 0, out_dev, nframes, period, length, tail_frames));
+	return upload_mark(d, d->stream);                  /* the host buffer is free again when the kernel has read it */
+}
+
 static bool lazy_seek_enabled()
 {
 	static const bool on = !(getenv("WR_LAZY_SEEK") && atoi(getenv("WR_LAZY_SEEK")) == 0);
@@ -2570,15 +2592,20 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 	if (dev_bind(d))
 		return WR_ERR_HIP;
 	hipStream_t st = d->stream;
-	if (where == WR_DEVICE && s->pending == 0 && nframes >= s->n) {
-		/* A block that already lies in device memory and nothing carried over (the tuner block of a source
-		 * whose size is a multiple of the hop, block after block): the most recent frame is transformed where
-		 * it lies and only the tail that belongs to the NEXT frame is kept -- not the whole block copied into
-		 * the stage first (32 MB device to device per 4 M-frame block, and three more enqueues on the host). */
-		const size_t nfft = (nframes - s->n) / s->hop + 1;
-		HIP_TRY(wrk_fft_frames(st, s->plan, iq + 2 * (nfft - 1) * s->hop, s->hop, 1, s->bins, nullptr));
+	if (where == WR_DEVICE && s->pending + nframes >= s->n &&
+	    ((s->pending + nframes - s->n) / s->hop) * s->hop >= s->pending) {
+		/* A block that already lies in device memory and whose most recent complete frame starts INSIDE it (any block of
+		 * fftSize + hop frames or more; whatever was carried over belongs to frames nobody can observe,
+		 * spectrumsink.cxx:114-116,136-141): that frame is transformed where it lies and only the tail that belongs to
+		 * the NEXT frame is kept -- not the whole block copied into the stage first (32 MB device to device per 4 M-frame
+		 * block, and three more enqueues on the host).  Nothing before that frame is read: the caller may have staged the
+		 * block's tail only (r04: the host runtime's stagedTail). */
+		const size_t have = s->pending + nframes;
+		const size_t nfft = (have - s->n) / s->hop + 1;
+		const size_t first = (nfft - 1) * s->hop - s->pending;  /* where that frame starts in THIS block */
+		HIP_TRY(wrk_fft_frames(st, s->plan, iq + 2 * first, s->hop, 1, s->bins, nullptr));
 		s->frames_done += nfft;
-		const size_t rest = nframes - nfft * s->hop;
+		const size_t rest = have - nfft * s->hop;
 		if (rest) {
 			if (rest > s->stage_cap) {
 				float *nb = nullptr;
@@ -2590,7 +2617,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 				s->stage = nb;
 				s->stage_cap = cap;
 			}
-			HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * nfft * s->hop, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+			HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * (first + s->hop), rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
 		}
 		s->pending = rest;
 		return WR_OK;

@@ -119,6 +119,8 @@ hipError_t wrk_hist_update(hipStream_t st, const float *in, size_t nframes, unsi
 hipError_t wrk_demod(hipStream_t st, int mode, const float *in, size_t nframes, float prev_i,
                      float prev_q, float *out);
 hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t count);
+hipError_t wrk_stage_windows(hipStream_t st, const void *src_mapped, bool u8, float *dst, size_t nframes, unsigned int period,
+                             unsigned int len, size_t tail_frames);
 
 /* what one launch of the post stage (demodulator + audio filter of ONE block) works on */
 struct WrPostArgs {

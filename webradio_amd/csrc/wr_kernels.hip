@@ -2170,6 +2170,92 @@ hipError_t wrk_demod(hipStream_t st, int mode, const float *in, size_t nframes, 
 	return hipGetLastError();
 }
 
+/* ---- sparse staging (r04): only the frames a decimating tuner's taps ever reach cross PCIe ------------------------------
+ * A channel filter of `len` taps that decimates by `period` reads the input frames [k * period - (len - 1), k * period]
+ * of every output frame k (lowpass.cxx:145-159: y[k] = sum_j coeff[len-1-j] * block[k * D + j], block = 63 frames of
+ * history ++ the input) and nothing between those windows -- 64 of every 400 frames at BASELINE config 2, 64 of 4000 at
+ * config 5 -- plus, for the next block's history and a SpectrumSink's current frame, a tail of the block.  k_stage_windows
+ * copies exactly that from page-locked HOST memory (read by the kernel over PCIe) to the same positions of the staged
+ * device block: the frames in between keep whatever the buffer held and nobody reads them.
+ * A unit is one 16-byte chunk of the 16-byte-ALIGNED span that covers a window (what lies beside a window inside that span
+ * is staged too, it is input all the same); NC chunks per window, 64 / NC windows per wave and iteration.
+ *   u8  source: 8 frames per chunk, converted with the reference's rule (u8 - 128) / 128 (rtlsdrtuner.cxx:106)
+ *   f32 source: 2 frames per chunk */
+template <bool U8>
+__global__ void __launch_bounds__(256) k_stage_windows(const uint8_t *__restrict__ src, float *__restrict__ dst, size_t nframes,
+                                                        unsigned int period, unsigned int len, size_t k1, size_t tail_first,
+                                                        unsigned int nc, unsigned int wpw)
+{
+	constexpr unsigned int FB = U8 ? 2u : 8u;           /* bytes per frame at the source */
+	const unsigned int lane = threadIdx.x & 63u;
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	const size_t total_bytes = nframes * FB;
+	const unsigned int w = lane / nc, c = lane - w * nc;
+	/* windows: wave-iteration i covers windows i * wpw ... */
+	for (size_t k0 = wave * wpw; k0 < k1; k0 += nwaves * wpw) {
+		const size_t k = k0 + w;
+		if (w >= wpw || k >= k1)
+			continue;
+		const long long f0 = (long long)k * period - (long long)(len - 1u);       /* first frame of the window */
+		const size_t b0 = (size_t)(f0 < 0 ? 0 : f0) * FB, b1 = ((size_t)k * period + 1u) * FB;
+		const size_t a = (b0 & ~(size_t)15) + (size_t)c * 16u;
+		if (a >= b1 || a + 16u > total_bytes)
+			continue;                                   /* (a block's last bytes: the tail pass below) */
+		const uint4 v = *(const uint4 *)(src + a);
+		if (U8) {
+			const unsigned int q[4] = {v.x, v.y, v.z, v.w};
+			float4 *o = (float4 *)(dst + a);            /* byte a of the source is float a of the block */
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				float4 r;
+				r.x = ((float)(q[i] & 255u) - 128.0f) / 128.0f;
+				r.y = ((float)((q[i] >> 8) & 255u) - 128.0f) / 128.0f;
+				r.z = ((float)((q[i] >> 16) & 255u) - 128.0f) / 128.0f;
+				r.w = ((float)(q[i] >> 24) - 128.0f) / 128.0f;
+				o[i] = r;
+			}
+		} else {
+			*(uint4 *)((uint8_t *)dst + a) = v;
+		}
+	}
+	/* the tail [tail_first, nframes): frame by frame (its start need not be 16-byte aligned at the source) */
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+	for (size_t f = tail_first + tid; f < nframes; f += nthreads) {
+		if (U8) {
+			const uchar2 b = ((const uchar2 *)src)[f];
+			((float2 *)dst)[f] = make_float2(((float)b.x - 128.0f) / 128.0f, ((float)b.y - 128.0f) / 128.0f);
+		} else {
+			((float2 *)dst)[f] = ((const float2 *)src)[f];
+		}
+	}
+}
+
+hipError_t wrk_stage_windows(hipStream_t st, const void *src_mapped, bool u8, float *dst, size_t nframes, unsigned int period,
+                             unsigned int len, size_t tail_frames)
+{
+	if (!nframes)
+		return hipSuccess;
+	const unsigned int fb = u8 ? 2u : 8u;
+	const unsigned int nc = (len * fb + 15u + 15u) / 16u;              /* chunks of the aligned span of a window */
+	if (nc > 64u)
+		return hipErrorInvalidValue;
+	const unsigned int wpw = 64u / nc;
+	const size_t k1 = nframes / period + ((nframes % period) ? 1u : 0u);  /* (a window that ends in the next block starts in this one) */
+	const size_t tail_first = tail_frames >= nframes ? 0 : nframes - tail_frames;
+	/* PCIe-bound: a few hundred workgroups keep megabytes of reads in flight; see k_u8_to_f32_x16 about parking more */
+	const size_t waves = (k1 + wpw - 1) / wpw;
+	unsigned int wgs = (unsigned int)((waves + 3) / 4);
+	if (wgs > 512u)
+		wgs = 512u;
+	if (wgs < 1u)
+		wgs = 1u;
+	if (u8)
+		k_stage_windows<true><<<wgs, 256, 0, st>>>((const uint8_t *)src_mapped, dst, nframes, period, len, k1, tail_first, nc, wpw);
+	else
+		k_stage_windows<false><<<wgs, 256, 0, st>>>((const uint8_t *)src_mapped, dst, nframes, period, len, k1, tail_first, nc, wpw);
+	return hipGetLastError();
+}
+
 hipError_t wrk_u8_to_f32(hipStream_t st, const uint8_t *in, float *out, size_t count)
 {
 	if (!count)

@@ -23,15 +23,22 @@
 #include <algorithm>
 #include <inttypes.h>
 
+#include <stdlib.h>
+
 #include "debug.h"
 #include "dspblock.h"
 
 namespace {
+/* WEBRADIO_WALL=1 (measurement only): every process() is bracketed -- not a sample of them -- with the MONOTONIC
+ * clock, so that the profiler getters say where a run()'s wall time goes (the process-CPU clock also counts the HIP
+ * runtime's own threads and does not see the time spent waiting for the GPU) */
+const bool g_wall = getenv("WEBRADIO_WALL") && atoi(getenv("WEBRADIO_WALL")) != 0;
+
 uint64_t cpuNanoseconds()
 {
 	/* the reference brackets process() with the process-CPU clock (dspblock.cxx:188) */
 	timespec ts;
-	clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+	clock_gettime(g_wall ? CLOCK_MONOTONIC : CLOCK_PROCESS_CPUTIME_ID, &ts);
 	return (uint64_t)ts.tv_sec * 1000000000ULL + (uint64_t)ts.tv_nsec;
 }
 }
@@ -185,8 +192,8 @@ bool DspBlock::runFrames(const vector<sample_t> &inBuffer, unsigned int inframes
 	 * the host does its work elsewhere (the tuner batch, or a kernel it only enqueues) and is
 	 * booked as zero; the others are timed on their first 16 calls and on every 16th after that,
 	 * weighted 16 -- the getters (nsPerFrame..., main.cxx:117-121) keep their meaning. */
-	const bool timed = !_elide && (_calls < 16 || (_calls & 15) == 0);
-	const uint64_t weight = _calls < 16 ? 1 : 16;
+	const bool timed = g_wall || (!_elide && (_calls < 16 || (_calls & 15) == 0));
+	const uint64_t weight = (g_wall || _calls < 16) ? 1 : 16;
 	++_calls;
 	const uint64_t t0 = timed ? cpuNanoseconds() : 0;
 	if (!process(inBuffer, _out)) {

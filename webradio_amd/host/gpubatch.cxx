@@ -97,7 +97,14 @@ struct SourceStage {
 	std::vector<Pinned> pinned;
 	const float *cur;           /* the staged block: in `buf`, or `buf2` */
 	bool rawStaged;             /* the block now staged came from the source's raw bytes: its float vector was not read */
-	SourceStage() : second(false), epoch(0), host(NULL), floats(0), dev(NULL), cur(NULL), rawStaged(false) {}
+	/* sparse staging (stagedWindows / stagedTail): of the source's block of `sparseEpoch` only the windows
+	 * [k * sparsePeriod - (sparseLen - 1), k * sparsePeriod] and the last `sparseTail` frames lie in `buf` */
+	unsigned long sparseEpoch;
+	unsigned int sparsePeriod, sparseLen;
+	size_t sparseTail;
+	size_t tailWanted;          /* the longest tail a consumer has asked for so far (a SpectrumSink: its frame + hop) */
+	SourceStage() : second(false), epoch(0), host(NULL), floats(0), dev(NULL), cur(NULL), rawStaged(false), sparseEpoch(0),
+	                sparsePeriod(0), sparseLen(0), sparseTail(0), tailWanted(0) {}
 	~SourceStage() { unpin(); }
 	/* the page locks must go before the memory does: freed but still registered, it is handed out
 	 * again by the allocator and a later copy out of it fails ("invalid argument") */
@@ -191,6 +198,153 @@ wr_dev *deviceFor(const DspBlock *block)
 	return device(src->gpuIndex());
 }
 
+static std::mutex g_stageLock;
+
+/* The source's current block staged in `pieces` equal parts, part `p` (0, 1, ... in order) now: part p crosses PCIe on the
+ * upload stream -- as bytes where the source still holds them (RawU8Block), converted on the device -- while the caller has
+ * the parts before it worked on.  Returns the device address of the part inside the staged block, which after the last
+ * part is the same staged block stagedBlock() makes in one piece (the SpectrumSink then finds it there).  NULL: this block
+ * cannot be staged in parts (host memory that cannot be page-locked, no memory): before part 0 nothing has happened and the
+ * caller takes the one-piece path. */
+static const float *stagePiece(DspSource *src, wr_dev *dev, const vector<sample_t> &host, unsigned int pieces, unsigned int p)
+{
+	std::lock_guard<std::mutex> g(g_stageLock);
+	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
+	if (!st) {
+		st = new SourceStage();
+		src->setGpuStage(st);
+		src->setGpuCleanup(releaseSource);
+		src->setGpuBeforeRun(beforeSourceRun);
+		src->setGpuBeforeStop(beforeSourceStop);
+	}
+	const size_t bytes = host.size() * sizeof(float);
+	const RawU8Block *rawsrc = dynamic_cast<const RawU8Block *>(src);
+	size_t rawFrames = 0;
+	const uint8_t *rawBytes = rawsrc ? rawsrc->rawU8(&rawFrames) : NULL;
+	const bool raw = rawBytes && rawFrames * 2 == host.size() && !envUnsigned("WEBRADIO_NO_U8_STAGING", 0);
+	if (p == 0) {
+		if (st->epoch == src->epoch() && st->host == host.data() && st->floats == host.size())
+			return NULL;                                /* somebody staged the whole block already */
+		if (!raw && !src->hostBlockValid())
+			return NULL;
+		if (!(raw ? st->pin(dev, rawBytes, host.size()) : st->pin(dev, host.data(), bytes)))
+			return NULL;
+		st->dev = dev;
+		if (!raw)
+			st->second = !st->second;                   /* float blocks alternate between two device copies (see stagedBlock) */
+		DevBuf &dst = (!raw && st->second) ? st->buf2 : st->buf;
+		if (!dst.reserve(dev, bytes))
+			return NULL;
+		st->cur = (const float *)dst.ptr;
+		st->rawStaged = raw;
+		st->epoch = 0;                                  /* not complete until the last part is on its way */
+	}
+	const size_t part = host.size() / pieces, off = part * p;      /* floats */
+	float *dstp = const_cast<float *>(st->cur) + off;
+	const int rc = raw ? wr_u8_to_f32_from_host(dev, rawBytes + off, dstp, part)
+	                   : wr_dev_upload_ahead(dev, dstp, host.data() + off, part * sizeof(float));
+	if (rc != WR_OK) {
+		LOG_ERROR("staging part %u of %u of the source block failed: %s\n", p, pieces, wr_last_error());
+		return NULL;
+	}
+	if (p + 1 == pieces) {
+		st->epoch = src->epoch();
+		st->host = host.data();
+		st->floats = host.size();
+	}
+	return dstp;
+}
+
+static bool sparseEnabled()
+{
+	static const bool on = envUnsigned("WEBRADIO_SPARSE", 1) != 0;
+	return on;
+}
+
+/* Sparse staging of the source's current block (wr_stage_windows_from_host): of a block whose every receiver decimates by
+ * `period` through a channel filter of `length` taps only the frames under the taps -- 64 of every 400 at BASELINE config 2 --
+ * and the tail cross PCIe, read by a kernel on the device's own stream, in order with the tuner's launches behind it; there
+ * is no transfer to wait for and no second stream to hand over from.  period = 0: the tail alone (a SpectrumSink's frame).
+ * Returns the address the WHOLE block would have on the device (the frames not staged keep what the buffer held), or NULL when
+ * this block cannot be staged that way (host memory that cannot be page-locked, windows too long for the kernel): the caller
+ * stages the whole block. */
+static const float *stagedSparse(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out, unsigned int period,
+                                 unsigned int length, size_t tail)
+{
+	DspSource *src = TunerBatch::rootSource(consumer);
+	if (!sparseEnabled() || !src || host.empty() || host.data() != src->currentBlock().data())
+		return NULL;
+	wr_dev *dev = deviceFor(consumer);
+	if (!dev)
+		return NULL;
+	std::lock_guard<std::mutex> g(g_stageLock);
+	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
+	if (!st) {
+		st = new SourceStage();
+		src->setGpuStage(st);
+		src->setGpuCleanup(releaseSource);
+		src->setGpuBeforeRun(beforeSourceRun);
+		src->setGpuBeforeStop(beforeSourceStop);
+	}
+	const size_t nframes = host.size() / 2;
+	if (tail > nframes)
+		tail = nframes;
+	if (!period && tail > st->tailWanted)
+		st->tailWanted = tail;                          /* the next block's window pass brings it along */
+	if (st->epoch == src->epoch() && st->host == host.data() && st->floats == host.size() && st->dev == dev) {
+		if (dev_out)
+			*dev_out = dev;
+		return st->cur;                                 /* the whole block is there already */
+	}
+	const bool have = st->sparseEpoch == src->epoch() && st->host == host.data() && st->floats == host.size() && st->dev == dev;
+	if (have && (!period || (st->sparsePeriod == period && st->sparseLen == length)) && st->sparseTail >= tail) {
+		if (dev_out)
+			*dev_out = dev;
+		return st->cur;
+	}
+	if (have && period && st->sparsePeriod)
+		return NULL;                                    /* two consumers with different windows: the whole block then */
+	const RawU8Block *rawsrc = dynamic_cast<const RawU8Block *>(src);
+	size_t rawFrames = 0;
+	const uint8_t *rawBytes = rawsrc ? rawsrc->rawU8(&rawFrames) : NULL;
+	const bool raw = rawBytes && rawFrames == nframes && !envUnsigned("WEBRADIO_NO_U8_STAGING", 0);
+	if (!raw && !src->hostBlockValid())
+		return NULL;
+	const void *from = raw ? (const void *)rawBytes : (const void *)host.data();
+	const size_t bytes = host.size() * sizeof(float);
+	if (((uintptr_t)from & 15u) || (period && length > (raw ? 480u : 120u)))
+		return NULL;
+	if (!st->pin(dev, from, raw ? host.size() : bytes) || !st->buf.reserve(dev, bytes))
+		return NULL;
+	if (period && st->tailWanted > tail)
+		tail = st->tailWanted > nframes ? nframes : st->tailWanted;
+	if (wr_stage_windows_from_host(dev, from, raw ? 1 : 0, (float *)st->buf.ptr, nframes, period ? period : (unsigned int)nframes + 1u,
+	                               period ? length : 1u, tail) != WR_OK) {
+		LOG_ERROR("sparse staging of the source block failed: %s\n", wr_last_error());
+		return NULL;
+	}
+	st->dev = dev;
+	st->host = host.data();
+	st->floats = host.size();
+	st->cur = (const float *)st->buf.ptr;
+	st->rawStaged = raw;
+	st->epoch = 0;                                      /* (not the whole block) */
+	if (!have || period) {
+		st->sparsePeriod = period;
+		st->sparseLen = period ? length : 0;
+	}
+	st->sparseTail = (have && st->sparseTail > tail) ? st->sparseTail : tail;
+	st->sparseEpoch = src->epoch();
+	if (dev_out)
+		*dev_out = dev;
+	return st->cur;
+}
+
+const float *stagedTail(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out, size_t tail_frames)
+{
+	return stagedSparse(consumer, host, dev_out, 0, 0, tail_frames);
+}
+
 const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out,
                          bool only_if_present)
 {
@@ -200,8 +354,7 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 	wr_dev *dev = deviceFor(consumer);
 	if (!dev)
 		return NULL;
-	static std::mutex stageLock;
-	std::lock_guard<std::mutex> g(stageLock);
+	std::lock_guard<std::mutex> g(g_stageLock);
 	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
 	if (!st && only_if_present)
 		return NULL;
@@ -321,8 +474,12 @@ TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
 	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateDepth(envUnsigned("WEBRADIO_AUDIO_LATE", 0) >= 2 ? 2u : 1u),
-	  _lateQueued(false), _silence(false), _lateSeq(0)
+	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _quantum(0), _delivered(false)
 {
+	if (_pieces < 1 || _late)
+		_pieces = 1;
+	if (_pieces > 8)
+		_pieces = 8;
 }
 
 TunerBatch::~TunerBatch()
@@ -437,7 +594,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 			batch->_tuner = NULL;
 			return NULL;
 		}
-		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 2 + batch->_lateDepth : 2);
+		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 2 + batch->_lateDepth : 1 + (batch->_pieces > 1 ? batch->_pieces : 1));
 		batch->_lateQueued = false;
 		batch->_lateSeq = 0;
 	}
@@ -574,6 +731,59 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		_ringHeld = false;
 		_audioSlots = 0;
 	}
+	_delivered = false;
+	/* On time (the default: a block's audio is handed on within the run() that brought the block) the block goes through
+	 * in P equal parts: part p + 1 crosses PCIe while part p's kernels run, part p's audio comes back -- and is put where
+	 * the audio filters' consumers will read it -- while part p + 1 computes.  What run() then waits for after the link
+	 * has delivered the block is one part's kernels and transfer, not the block's (r03: transfer, kernels, audio copy
+	 * and hand-out in series, 0.43 ms a C2 block of bytes; the bits do not depend on how a stream is cut into blocks:
+	 * tests/test_gpu_tuner.py::test_block_split_invariance). */
+	/* (r04) Where every receiver decimates alike and by at least twice its channel filter's length, only the frames under
+	 * the taps are brought over (stagedSparse): a sixth of the block at BASELINE config 2 -- and no transfer to wait for. */
+	unsigned int sp = 0, sl = 0;
+	if (!pushed && sparseWindows(&sp, &sl)) {
+		wr_dev *sdev = NULL;
+		const float *staged = stagedSparse(_channels[0]->mixer, tunerBuffer, &sdev, sp, sl, sl - 1u);
+		if (staged && sdev == _dev) {
+			/* on time, the staged block goes through in P parts all the same: a part's audio is put where the audio
+			 * filters' consumers will read it while the parts behind it compute (collectParts) */
+			const unsigned int parts = piecesFor(nframes);
+			for (unsigned int p = 0; p < parts; p++)
+				if (wr_tuner_submit(_tuner, staged + (size_t)2 * (nframes / parts) * p, nframes / parts, WR_DEVICE) != WR_OK) {
+					LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
+					return false;
+				}
+			if (parts == 1)
+				return afterSubmit(false);
+			++_lateSeq;
+			wr_tuner_flush(_tuner);
+			traceAdd(_source, 'S');
+			return collectParts(parts);
+		}
+	}
+	unsigned int P = pushed ? 1u : piecesFor(nframes);
+	if (P > 1) {
+		for (unsigned int p = 0; p < P; p++) {
+			const float *part = stagePiece(_source, _dev, tunerBuffer, P, p);
+			if (!part) {
+				if (p == 0) {
+					P = 1;                      /* cannot be staged in parts: the one-piece path below */
+					break;
+				}
+				return false;
+			}
+			if (wr_tuner_submit(_tuner, part, nframes / P, WR_DEVICE) != WR_OK) {
+				LOG_ERROR("wr_tuner_submit (part %u of %u): %s\n", p, P, wr_last_error());
+				return false;
+			}
+		}
+	}
+	if (P > 1) {
+		++_lateSeq;
+		wr_tuner_flush(_tuner);                 /* the last part's demodulator + audio filter: nothing rides behind it */
+		traceAdd(_source, 'S');
+		return collectParts(P);
+	}
 	/* cheapest way to get the block to the GPU: (1) a device copy some other consumer of the
 	 * source already made this block, (2) the source's raw bytes (2 per frame, converted in
 	 * the kernel's load stage), (3) stage the float block once for everybody */
@@ -600,6 +810,38 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
+	return afterSubmit(pushed);
+}
+
+/* do all receivers read the source block through windows of one shape -- the same decimation, the same channel-filter
+ * length -- and sparsely enough for sparse staging to pay (a window at most every second filter length)? */
+bool TunerBatch::sparseWindows(unsigned int *period, unsigned int *length)
+{
+	if (_channels.empty())
+		return false;
+	unsigned int d = 0, l = 0;
+	for (size_t n = 0; n < _channels.size(); n++) {
+		const LowPass *f = _channels[n]->chanFilter;
+		if (!f->isRunning() || _channels[n]->slot < 0)
+			return false;
+		const unsigned int dn = f->decimation(), ln = f->firLength();
+		if (n == 0) {
+			d = dn;
+			l = ln;
+		} else if (dn != d || ln != l) {
+			return false;
+		}
+	}
+	if (l < 2 || d < 2 * l)
+		return false;
+	*period = d;
+	*length = l;
+	return true;
+}
+
+/* the block has been submitted (enqueued): bookkeeping, and this run()'s audio */
+bool TunerBatch::afterSubmit(bool pushed)
+{
 	++_lateSeq;                            /* blocks submitted so far */
 	if (pushed)                            /* a filter change may have moved a channel to another rate group */
 		for (size_t n = 0; n < _channels.size(); n++) {
@@ -687,6 +929,107 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 	return true;
 }
 
+/* lcm with a ceiling: anything this large stands for "do not split" */
+static unsigned long lcmCapped(unsigned long a, unsigned long b)
+{
+	if (!a || !b)
+		return 0;
+	unsigned long x = a, y = b;
+	while (y) {
+		const unsigned long t = x % y;
+		x = y;
+		y = t;
+	}
+	const unsigned long long l = (unsigned long long)(a / x) * b;
+	return l > (1ull << 40) ? 0 : (unsigned long)l;
+}
+
+/* in how many equal parts a block of `nframes` goes through (submitOnce): as many as WEBRADIO_PIECES allows (default 2: each further part costs a launch and a transfer of
+ * its own, ~30 us, more than its overlap saves -- profiles/r04_host_pieces.txt;
+ * 1 turns it off) such that every part is a whole number of audio frames of every receiver, all receivers decimate alike
+ * (one rate group: the tuner's pinned audio ring then carries every part's audio) and a part stays large enough for the
+ * link and the kernels to work at their pace (WEBRADIO_PIECE_MIN_FRAMES, default 500 000) */
+unsigned int TunerBatch::piecesFor(unsigned int nframes)
+{
+	if (_pieces <= 1 || _late || _channels.empty() || !nframes)
+		return 1;
+	unsigned long q = 1;
+	unsigned int d[3] = {0, 0, 0};
+	for (size_t n = 0; n < _channels.size(); n++) {
+		const Channel *c = _channels[n];
+		if (c->slot < 0 || !c->chanFilter->isRunning() || !c->audioFilter->isRunning())
+			return 1;
+		const unsigned int e[3] = {c->chanFilter->decimation(), c->chanFilter2 ? c->chanFilter2->decimation() : 1u,
+		                           c->audioFilter->decimation()};
+		if (n == 0)
+			memcpy(d, e, sizeof(d));
+		else if (memcmp(d, e, sizeof(d)))
+			return 1;
+		q = lcmCapped(q, (unsigned long)e[0] * e[1] * e[2]);
+		if (!q)
+			return 1;
+	}
+	static const unsigned int minFrames = envUnsigned("WEBRADIO_PIECE_MIN_FRAMES", 500000);
+	for (unsigned int p = _pieces; p > 1; p--)
+		if (nframes % (p * q) == 0 && nframes / p >= minFrames)
+			return p;
+	return 1;
+}
+
+/* the audio of the P parts just submitted, in order: each part's rows are copied out of the tuner's pinned ring as soon as
+ * they are there -- straight into the audio filters' output vectors where those already have the block's size (the steady
+ * state: LowPass::process then has nothing left to copy), else into _audio for audio() to slice -- while the parts behind
+ * it are still being worked on */
+bool TunerBatch::collectParts(unsigned int P)
+{
+	size_t off = 0, total = 0;
+	bool direct = true;
+	for (unsigned int p = 0; p < P; p++) {
+		const float *ptr = NULL;
+		size_t stride = 0, frames = 0;
+		unsigned int slots = 0;
+		unsigned long long seq = 0;
+		if (wr_tuner_audio_ring_acquire(_tuner, &ptr, &stride, &frames, &slots, &seq) != WR_OK) {
+			LOG_ERROR("audio of part %u of %u: %s\n", p, P, wr_last_error());
+			return false;
+		}
+		if (p == 0) {
+			total = frames * P;
+			for (size_t n = 0; n < _channels.size() && direct; n++)
+				direct = _channels[n]->slot >= 0 && (unsigned int)_channels[n]->slot < slots &&
+				         _channels[n]->audioFilter->DspBlock::_out.size() == total;
+			if (!direct)
+				_audio.resize((size_t)slots * total + 1);
+			_audioSlots = slots;
+		}
+		if (frames * P != total || slots != _audioSlots) {
+			wr_tuner_audio_ring_release(_tuner);
+			LOG_ERROR("part %u of %u came back with %zu frames, the first with %zu\n", p, P, frames, total / P);
+			return false;
+		}
+		if (direct) {
+			for (size_t n = 0; n < _channels.size(); n++)
+				memcpy(_channels[n]->audioFilter->DspBlock::_out.data() + off, ptr + (size_t)_channels[n]->slot * stride,
+				       frames * sizeof(float));
+		} else {
+			for (unsigned int sl = 0; sl < slots; sl++)
+				memcpy(_audio.data() + (size_t)sl * total + off, ptr + (size_t)sl * stride, frames * sizeof(float));
+		}
+		wr_tuner_audio_ring_release(_tuner);
+		off += frames;
+	}
+	_ringHeld = false;
+	_audioFrames = total;
+	if (direct) {
+		_delivered = true;
+	} else {
+		_audioPtr = _audio.data();
+		_audioStride = total;
+	}
+	_submitOk = true;
+	return true;
+}
+
 bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 {
 	/* under the batch lock: withdraw() / unfuseChainOf() may run on an HTTP thread (a consumer connected
@@ -696,6 +1039,8 @@ bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)
 		return false;
 	if (out.empty())
 		return true;
+	if (_delivered && out.size() == _audioFrames && out.data() == ch->audioFilter->DspBlock::_out.data())
+		return true;                            /* collectParts put it there while the block's last parts were computing */
 	if (_late && _silence) {
 		memset(out.data(), 0, out.size() * sizeof(float));
 		return true;

@@ -57,6 +57,12 @@ bool hostBlockValid(const DspBlock *block);
  * come first on the device's stream and the audio does not wait behind the spectrum's copy and transform (the batch
  * submits once per block whoever asks first).  No batch, or not the source's current block: nothing happens. */
 void submitBatchFirst(const DspBlock *consumer, const vector<sample_t> &host);
+/* For a consumer that reads only the END of the source's block (the SpectrumSink: the most recent complete frame and what
+ * follows it): the block's device address with at least its last `tail_frames` frames staged -- the whole staged block
+ * where somebody staged it, else just that tail, brought over by the sparse staging kernel (a block whose receivers all
+ * read it through sparse windows never crosses PCIe whole).  NULL: not fed straight from a source, or it cannot be done
+ * (the caller falls back to stagedBlock). */
+const float *stagedTail(const DspBlock *consumer, const vector<sample_t> &host, wr_dev **dev_out, size_t tail_frames);
 
 
 /* WEBRADIO_TRACE=1: what the tuner batches did, in order -- 'S' a block submitted (enqueued, nothing
@@ -123,6 +129,10 @@ private:
 	~TunerBatch();
 	bool ensureTuner(unsigned int nframes);
 	bool pushParams(Channel *ch);
+	unsigned int piecesFor(unsigned int nframes);
+	bool sparseWindows(unsigned int *period, unsigned int *length);
+	bool afterSubmit(bool pushed);
+	bool collectParts(unsigned int parts);
 
 	DspSource *_source;
 	wr_dev *_dev;
@@ -142,6 +152,9 @@ private:
 	bool _lateQueued;                 /* a block has been submitted whose audio has not been handed out yet */
 	bool _silence;                    /* late mode, first block: nothing to hand out yet */
 	unsigned long long _lateSeq;      /* blocks submitted so far */
+	unsigned int _pieces;             /* WEBRADIO_PIECES: parts an on-time block is put through in (see submitOnce) */
+	unsigned long _quantum;
+	bool _delivered;                  /* this block's audio already lies in the audio filters' output vectors */
 	std::mutex _lock;
 };
 

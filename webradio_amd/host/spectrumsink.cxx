@@ -68,8 +68,13 @@ bool SpectrumSink::process(const vector<sample_t> &inBuffer, vector<sample_t> &o
 	/* the receivers of the same tuner go first on the device's stream: their audio is what run() waits for */
 	wrhost::submitBatchFirst(this, inBuffer);
 	/* fed straight from the tuner: use the device copy every GPU consumer of it shares */
+	/* ... of which the transform reads the most recent complete frame and keeps what follows it (wr_spectrum_push): the
+	 * last fftSize + hop frames are all that has to be there */
 	wr_dev *sdev = NULL;
-	const float *staged = wrhost::stagedBlock(this, inBuffer, &sdev);
+	const size_t nframes = inBuffer.size() / 2, tail = (size_t)_fftSize + (_hop ? _hop : _fftSize);
+	const float *staged = nframes > 2 * tail ? wrhost::stagedTail(this, inBuffer, &sdev, tail) : NULL;
+	if (!(staged && sdev == _dev))
+		staged = wrhost::stagedBlock(this, inBuffer, &sdev);
 	if (!(staged && sdev == _dev) && !wrhost::hostBlockValid(this)) {
 		LOG_ERROR("SpectrumSink: the source left its block on the device and the device copy is not there\n");
 		return false;
