@@ -299,8 +299,8 @@ def host_fed_secondary():
         return None
     rows = []
     for src in ("u8", "f32"):
-        for late in ("1", "0"):
-            env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_AUDIO_LATE=late)
+        for late, sparse in (("1", "1"), ("0", "1"), ("0", "0")):
+            env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_AUDIO_LATE=late, WEBRADIO_SPARSE=sparse)
             try:
                 r = subprocess.run([exe, "256", "100", "4000000", src], env=env, capture_output=True, text=True, timeout=120)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -308,8 +308,11 @@ def host_fed_secondary():
             except Exception as e:                      # the secondary figures never fail the headline
                 rows.append({"source": src, "audio_late": int(late), "error": str(e)[:200]})
                 continue
-            rows.append({"source": d["source"], "audio": d["audio"], "ms_per_block": d["ms_per_block"],
-                         "msps_tuner_input": d["msps_tuner_input"], "blocks": d["blocks"]})
+            rows.append({"source": d["source"], "audio": d["audio"],
+                         "staging": "sparse: only the frames under the channel filters' taps (64 of every 400) and the block's "
+                                    "tail cross PCIe, read by a kernel (wr_stage_windows_from_host)" if sparse == "1"
+                                    else "the whole block crosses PCIe (WEBRADIO_SPARSE=0: r03's path)",
+                         "ms_per_block": d["ms_per_block"], "msps_tuner_input": d["msps_tuner_input"], "blocks": d["blocks"]})
     return {"workload": "C2 through the C++ host classes (Radio::run, 256 Receivers), block in host memory: PCIe inside the timing",
             "unit": "complex Msamples/s of tuner input", "runs": rows}
 

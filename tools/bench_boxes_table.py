@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""profiles/r04_bench_boxes.txt from the per-box files tools/bench_box.sh left in gpurun_out/ (one fresh lease each):
+the driver's invocation `python bench.py --steps 20 --warmup 5` on the boxes of the pool."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rows = []
+for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r04_box_*.json"))):
+    try:
+        j = json.loads([l for l in open(path) if l.startswith("{")][-1])
+    except Exception:
+        continue
+    hf = {(r.get("source", "")[:3], r.get("audio", "")[:7], r.get("staging", "")[:6]): r.get("ms_per_block")
+          for r in (j.get("secondary", {}).get("host_fed") or {}).get("runs", [])}
+    rows.append((os.path.basename(path)[8:-5], j["value"] / 1e3, j["roofline"]["kernel_ms"] * 1e3, j["roofline"]["frac"],
+                 j["value_one_block_per_launch"] / 1e3, j["secondary"]["c3"]["ms_per_block"] * 1e3,
+                 j["secondary"]["c3"]["roofline"]["frac"], hf.get(("u8 ", "on time", "sparse")), hf.get(("f32", "on time", "sparse"))))
+out = ["python bench.py --steps 20 --warmup 5 --no-cpu-baseline, one fresh lease per row (tools/bench_box.sh; this table: tools/bench_boxes_table.py)",
+       "box (UTC)          Gsps    4-block launch us   frac    1 block/launch Gsps   C3 us/block  C3 frac   host on time ms: u8 / f32"]
+for r in rows:
+    out.append("%-16s %7.1f %12.1f %13.4f %12.1f %17.1f %9.4f      %s / %s" % r)
+if rows:
+    v = [r[1] for r in rows]
+    out.append("%d boxes: %.1f-%.1f Gsps, mean %.1f" % (len(v), min(v), max(v), sum(v) / len(v)))
+text = "\n".join(out) + "\n"
+sys.stdout.write(text)
+open(os.path.join(ROOT, "profiles", "r04_bench_boxes.txt"), "w").write(text)

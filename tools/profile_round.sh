@@ -5,7 +5,7 @@
 #                                            clock settling and the timed steps)
 #   gpurun_out/<round>_kernel_stats_timed.csv   the same trace, the timed region's launches only
 #   gpurun_out/<round>_pmc_fetch_size.txt / _pmc_write_size.txt   FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
-round=${1:-r03}
+round=${1:-r04}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R && python bench.py > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err
@@ -70,4 +70,6 @@ with open(R + '/gpurun_out/%s_pmc_%s.txt' % (r, c.lower()), 'w') as out:
         out.write('%s %s mean=%.1f KB per launch (n=%d)\n' % (k, c, sum(v) / len(v), len(v)))
 PY
 done
+# profiles/traffic.json (what bench.py quotes as roofline.traffic) from the two PMC dumps: no hand step
+python3 $R/tools/make_traffic.py $round
 cat $R/gpurun_out/${round}_bench.json | cut -c1-600; grep -E "k_tuner|k_fft" $R/gpurun_out/${round}_kernel_stats.csv; cat $R/gpurun_out/${round}_kernel_stats_timed.csv; cat $R/gpurun_out/${round}_pmc_*.txt
