@@ -91,12 +91,16 @@ def test_single_rank_time_shard_equals_sequential(oracle):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_two_ranks_gloo_ring_halo(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 3, 8], ids=["world2", "world3-ragged", "world8-a-node"])
+def test_ranks_gloo_ring_halo(tmp_path, oracle, world):
+    """The N > 1 path of BASELINE config 5 on CPU ranks over gloo: chunks dealt round-robin, every halo from the ring
+    neighbour, the max-over-ranks reduction -- at 2 ranks, at 3 (the chunks do not divide among the ranks: idle ranks still
+    take part in the ring) and at 8, the node's rank count (more ranks than chunks but one: most of them idle in round 2)."""
     import _proc
-    _proc.spawn_ranks(_worker, 2, (2, str(tmp_path)), timeout=150)
+    _proc.spawn_ranks(_worker, world, (world, str(tmp_path)), timeout=170)
     T, n = CFG["T"], CFG["nchunks"]
     parts = {}
-    for r in range(2):
+    for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         for k in d.files:
             parts[int(k)] = d[k]
