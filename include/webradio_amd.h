@@ -326,7 +326,10 @@ int wr_tuner_fetch_audio_all(wr_tuner *tuner, float *out_host, size_t out_capaci
  * so that the copy and the consumers overlap the next block's kernels.  Like the reference's
  * tuner ring (io/rtlsdrtuner.cxx:100-117) a full ring drops the NEW block's audio and counts
  * an overrun.  Blocks submitted while the tuner's channels do not all share one pair of
- * decimations are not queued (fetch per channel then).  depth 0 frees the ring. */
+ * decimations are not queued (fetch per channel then).  depth 0 frees the ring.
+ * r04: a deferred post stage writes its audio into the slot ITSELF (the slot is page-locked host memory mapped into the
+ * device's address space; the kernel stores every sample there as well as in device memory), so the block is in the ring
+ * when its launch has run and no copy is enqueued behind it ($WR_RING_DIRECT=0: the copy, as before). */
 int wr_tuner_audio_ring(wr_tuner *tuner, unsigned int depth);
 /* oldest block not yet released: waits for its copy, then channel slot s (wr_chan_slot) is at
  * (*audio_host) + s * (*chan_stride), *frames floats each; *seq counts submits from 0 (gaps =

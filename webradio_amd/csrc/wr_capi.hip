@@ -135,6 +135,7 @@ struct Group {
 	bool seek_pending = false;
 	unsigned long long seek_frame = 0;
 	float *z_hist = nullptr, *z_prev = nullptr, *z_dem = nullptr;
+	bool pend_direct = false;          /* that post stage writes its audio into the ring slot itself (ring_reserve) */
 	unsigned long long pend_seq = 0;   /* ring bookkeeping of that block */
 	size_t pend_k2 = 0;
 	unsigned int pend_slots = 0;
@@ -1028,7 +1029,8 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 
 static int tuner_quiesce(wr_tuner *t);
 static int tuner_flush(wr_tuner *t);
-static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used);
+static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used, bool direct);
+static float *ring_reserve(wr_tuner *t, Group *g, size_t k2, unsigned int used);
 
 static int tuner_launch_held(wr_tuner *t);
 
@@ -1426,7 +1428,7 @@ static int tuner_flush(wr_tuner *t)
 			continue;
 		HIP_TRY(wrk_tuner_post_args(t->dev->stream, g->post_args));
 		g->post_pending = false;
-		int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots);
+		int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots, g->pend_direct);
 		if (rc)
 			return rc;
 	}
@@ -1924,7 +1926,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 				if (g->post_pending) {
 					HIP_TRY(wrk_tuner_post_args(st, g->post_args));
 					g->post_pending = false;
-					int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots);
+					int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots, g->pend_direct);
 					if (rc)
 						return rc;
 				}
@@ -1960,7 +1962,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			if (!rode)
 				HIP_TRY(wrk_tuner_post_args(st, g->post_args));
 			g->post_pending = false;
-			int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots);
+			int rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots, g->pend_direct);
 			if (rc)
 				return rc;
 		}
@@ -1990,11 +1992,14 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 			g->pend_seq = seq;
 			g->pend_k2 = L.k2;
 			g->pend_slots = L.slots_used;
+			g->post_args.audio_host = ring_reserve(t, g, L.k2, L.slots_used);
+			g->post_args.host_stride = L.k2;            /* the ring's rows lie back to back (RingSlot::stride = frames) */
+			g->pend_direct = g->post_args.audio_host != nullptr;
 		} else {
 			HIP_TRY(wrk_tuner_post(st, Lp, Gp));
 		}
 		if (!defer) {
-			int rc = ring_push(t, g, seq, Lp.k2, L.slots_used);
+			int rc = ring_push(t, g, seq, Lp.k2, L.slots_used, false);
 			if (rc)
 				return rc;
 		}
@@ -2198,7 +2203,51 @@ static Group *single_group(wr_tuner *t)
 }
 
 /* queue the copy of one block's audio, right behind the kernel that produces it */
-static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used)
+static bool ring_direct_enabled()
+{
+	static const bool on = !(getenv("WR_RING_DIRECT") && atoi(getenv("WR_RING_DIRECT")) == 0);
+	return on;
+}
+
+/* r04: the post stage whose arguments are being put together (a deferred one: it is launched later, riding in the next
+ * block's launch or by a flush) may write its audio straight into the ring slot its block will be queued in -- the next
+ * one to fill, which stays the next one until that block's own ring_push: pushes come in block order and this group is
+ * the only one that pushes.  The audio is then in the ring when the launch has run; no device-to-host copy is enqueued
+ * behind it (50 us for the 2 MB of a C2 block, in series with everything else of an on-time block).  Returns the slot's
+ * device-side address, or NULL: no ring, several rate groups, the ring full right now (the block may still be queued by
+ * copy if a slot is free by then), or page-locked memory that cannot be had. */
+static float *ring_reserve(wr_tuner *t, Group *g, size_t k2, unsigned int used)
+{
+	if (t->ring.empty() || !ring_direct_enabled())
+		return nullptr;
+	std::lock_guard<std::mutex> lk(t->ring_lock);
+	if (single_group(t) != g || t->ring_count == t->ring.size())
+		return nullptr;
+	wr_tuner::RingSlot &r = t->ring[t->ring_head];
+	const size_t need = (size_t)used * k2;
+	if (!need)
+		return nullptr;
+	if (need > r.cap) {
+		(void)hipHostFree(r.host);
+		r.host = nullptr;
+		r.cap = 0;
+		const size_t want = (size_t)g->slots * g->k2max;
+		if (hipHostMalloc((void **)&r.host, (want ? want : 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			r.host = nullptr;
+			return nullptr;
+		}
+		r.cap = want;
+	}
+	void *mapped = nullptr;
+	if (hipHostGetDevicePointer(&mapped, r.host, 0) != hipSuccess || !mapped) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return (float *)mapped;
+}
+
+static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used, bool direct)
 {
 	if (t->ring.empty())
 		return WR_OK;
@@ -2218,9 +2267,10 @@ static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, u
 		const size_t want = (size_t)g->slots * g->k2max;
 		HIP_TRY(hipHostMalloc((void **)&r.host, (want ? want : 1) * sizeof(float), hipHostMallocDefault));
 		r.cap = want;
+		direct = false;                         /* (cannot happen: ring_reserve sized the slot) */
 	}
 	hipStream_t st = t->dev->stream;
-	if (need) {
+	if (need && !direct) {
 		if (k2 == g->k2max)                     /* rows back to back (the usual block size): one linear copy */
 			HIP_TRY(hipMemcpyAsync(r.host, g->dev.audio, need * sizeof(float), hipMemcpyDeviceToHost, st));
 		else
@@ -2406,7 +2456,7 @@ extern "C" int wr_tuner_seek(wr_tuner *t, unsigned long long frame)
 			/* a post stage still waiting for the next submit would write ITS end-of-block state over ours */
 			HIP_TRY(wrk_tuner_post_args(st, g->post_args));
 			g->post_pending = false;
-			if ((rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots)) != WR_OK)
+			if ((rc = ring_push(t, g, g->pend_seq, g->pend_k2, g->pend_slots, g->pend_direct)) != WR_OK)
 				return rc;
 		}
 		const size_t S = g->slots;

@@ -146,6 +146,10 @@ struct WrPostArgs {
 	const float *gain;           /* [slots] af_gain factors, or NULL: all 1 */
 	const float *squelch;        /* [slots] squelch thresholds (power of the demodulator's input, mean over the
 	                                d2 frames behind an audio frame), or NULL: all open */
+	float       *audio_host;     /* r04: page-locked HOST memory (a slot of the tuner's audio ring, mapped) that gets every
+	                                audio sample too, rows `host_stride` floats apart -- the block's audio is in the ring when
+	                                the launch has run, no device-to-host copy behind it; NULL: device memory only */
+	size_t       host_stride;
 };
 /* `post` (optional): the post stage of the PREVIOUS block, run by extra workgroups of the same
  * launch beside this block's DDC (only taken up by the ROTATE / uniform-taps kernel; *post_taken

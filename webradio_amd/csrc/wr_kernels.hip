@@ -726,9 +726,12 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 			const unsigned int sl = e / POST_TK, kk = e - sl * POST_TK;
 			const unsigned int so = g * 64u + sl;
 			const size_t k = kbase + kk;
-			if (k < A.k2 && modes[sl] >= 0)
-				A.audio[(size_t)so * A.k2max + k] = audio_out(tile[kk * 65u + sl], A.gain, A.squelch, chan_iq, slots, so, k, D2,
-				                                              A.scale);
+			if (k < A.k2 && modes[sl] >= 0) {
+				const float v = audio_out(tile[kk * 65u + sl], A.gain, A.squelch, chan_iq, slots, so, k, D2, A.scale);
+				A.audio[(size_t)so * A.k2max + k] = v;
+				if (A.audio_host)                       /* (uniform: a kernel argument) */
+					A.audio_host[(size_t)so * A.host_stride + k] = v;
+			}
 		}
 		TLP(3);
 	}
@@ -2587,6 +2590,8 @@ WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G)
 	A.groups = L.slots_used / 64;
 	A.gain = L.use_gain ? G.gain : nullptr;
 	A.squelch = L.use_squelch ? G.squelch : nullptr;
+	A.audio_host = nullptr;
+	A.host_stride = 0;
 	return A;
 }
 
