@@ -196,6 +196,25 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+def reference_cpu_baseline(blocks, channels):
+    """cpu_baseline with kind "reference" (r04): the reference's OWN DownConverter / LowPass / Demodulator classes --
+    /root/reference's sources compiled into oracle/_ref/libwr_ref_chain.so where they lay, which travels to the GPU box
+    prebuilt -- on the host cores, through oracle/ref_cpu_baseline.py in a process of its own (its FFTW calls, two 64-point
+    transforms per receiver at start(), go to the image's hipFFTW and so to the system's HIP runtime; this process holds
+    torch's).  None when that library is not there or the run fails: the caller then times the port."""
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "ref_cpu_baseline.py")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libwr_ref_chain.so")) or os.environ.get("WR_BENCH_CPU_PORT"):
+        return None
+    try:
+        r = subprocess.run([sys.executable, script, str(int(blocks)), str(int(channels))], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=600)
+        d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+        return d if "value" in d and d["value"] > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, ifs, blocks):
     """The oracle's Receiver chains (a faithful scalar port of the reference CPU path:
     full-rate mixer, block copy, 64-tap FIRs, atan2f) over the same synthetic stream:
@@ -800,7 +819,15 @@ def main():
             if hf is not None:
                 out["secondary"]["host_fed"] = hf
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, ifs, args.cpu_blocks)
+            # the reference's own classes on the host cores where oracle/_ref is there (kind "reference"), with the
+            # oracle's port beside it; the port alone (kind "port") otherwise
+            port = cpu_baseline(cfg, ifs, args.cpu_blocks)
+            ref = reference_cpu_baseline(args.cpu_blocks, args.channels)
+            if ref:
+                ref["port"] = port
+                out["cpu_baseline"] = ref
+            else:
+                out["cpu_baseline"] = port
     else:
         out = None
 

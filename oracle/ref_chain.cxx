@@ -206,3 +206,177 @@ int ref_spectrum(unsigned int fs, unsigned int fft_size, const float *iq, size_t
 }
 
 }  // extern "C"
+
+/* ---- the reference CPU path as a timed baseline (bench.py: cpu_baseline.kind = "reference") --------------------------
+ * T pipeline threads, each with its own tuner and its own subset of the receivers (the reference pipeline itself is
+ * single-threaded, radio.cxx:56-59: one run() pumps every receiver of a front end in turn), all fed the same block.
+ * The tuner hands its block out the way RtlSdrTuner::process does (io/rtlsdrtuner.cxx:265-285): it SWAPS a filled vector
+ * into the output, it does not copy 32 MB per block. */
+#include <pthread.h>
+#include <time.h>
+
+namespace {
+
+class SwapSource : public DspSource {
+public:
+	SwapSource() : DspSource("swap", "SwapSource") {}
+	std::vector<float> spare;
+protected:
+	bool init() { return true; }
+	void deinit() {}
+	bool process(const std::vector<sample_t> &, std::vector<sample_t> &out) {
+		if (spare.size() != out.size())
+			return false;
+		out.swap(spare);              /* both vectors hold the block: the one swapped out is the one handed out before */
+		return true;
+	}
+};
+
+class SumSink : public DspBlock {
+public:
+	SumSink() : DspBlock("sum", "SumSink"), sum(0.0), frames(0) {}
+	double sum;
+	size_t frames;
+protected:
+	bool init() { return true; }
+	void deinit() {}
+	bool process(const std::vector<sample_t> &in, std::vector<sample_t> &) {
+		for (size_t n = 0; n < in.size(); n++)
+			sum += in[n] < 0 ? -in[n] : in[n];
+		frames += in.size();
+		return true;
+	}
+};
+
+struct BenchThread {
+	pthread_t tid;
+	unsigned int fs, cpb, crate, apb, arate, nblocks;
+	int mode;
+	std::vector<int> ifs;
+	const float *iq;
+	size_t nframes;
+	pthread_barrier_t *ready, *go;
+	double sum;
+	size_t frames;
+	int rc;
+};
+
+/* FFTW's planner is not thread-safe (and the reference never plans from two threads): start() and stop() -- LowPass::init's
+ * fftwf_plan_dft_1d / fftwf_execute, deinit's fftwf_destroy_plan / fftwf_cleanup -- one thread at a time; both are untimed */
+pthread_mutex_t g_plan_lock = PTHREAD_MUTEX_INITIALIZER;
+
+void *bench_thread(void *p)
+{
+	BenchThread *b = (BenchThread *)p;
+	b->rc = 0;
+	SwapSource src;
+	std::vector<DownConverter *> dc;
+	std::vector<LowPass *> f1, f2;
+	std::vector<Demodulator *> dm;
+	std::vector<SumSink *> sk;
+	src.setSampleRate(b->fs);
+	src.setChannels(2);
+	src.setBlockSize(2 * b->nframes);
+	src.spare.assign(b->iq, b->iq + 2 * b->nframes);
+	for (size_t c = 0; c < b->ifs.size(); c++) {          /* radio.cxx:68-83 */
+		dc.push_back(new DownConverter("dc"));
+		f1.push_back(new LowPass("chan"));
+		dm.push_back(new Demodulator("demod"));
+		f2.push_back(new LowPass("audio"));
+		sk.push_back(new SumSink());
+		dc[c]->setIF(b->ifs[c]);
+		f1[c]->setPassband(b->cpb);
+		f1[c]->setOutputSampleRate(b->crate);
+		dm[c]->setMode((Demodulator::Mode)b->mode);
+		f2[c]->setPassband(b->apb);
+		f2[c]->setOutputSampleRate(b->arate);
+		src.connect(dc[c]);
+		dc[c]->connect(f1[c]);
+		f1[c]->connect(dm[c]);
+		dm[c]->connect(f2[c]);
+		f2[c]->connect(sk[c]);
+	}
+	pthread_mutex_lock(&g_plan_lock);
+	if (!src.start())
+		b->rc = -1;
+	pthread_mutex_unlock(&g_plan_lock);
+	if (b->rc == 0 && !src.run())                          /* one untimed block: buffers sized, pages touched */
+		b->rc = -2;
+	if (b->rc == 0)                                        /* the vector swapped out on that first call was the runtime's own, */
+		src.spare.assign(b->iq, b->iq + 2 * b->nframes);   /* zero-filled one: from now on both hold the block */
+	pthread_barrier_wait(b->ready);
+	pthread_barrier_wait(b->go);
+	for (unsigned int n = 0; b->rc == 0 && n < b->nblocks; n++)
+		if (!src.run())
+			b->rc = -3;
+	pthread_barrier_wait(b->ready);                        /* (reused: everybody has finished) */
+	pthread_mutex_lock(&g_plan_lock);
+	src.stop();
+	pthread_mutex_unlock(&g_plan_lock);
+	b->sum = 0;
+	b->frames = 0;
+	for (size_t c = 0; c < sk.size(); c++) {
+		b->sum += sk[c]->sum;
+		b->frames += sk[c]->frames;
+		delete dc[c]; delete f1[c]; delete dm[c]; delete f2[c]; delete sk[c];
+	}
+	return 0;
+}
+
+double mono()
+{
+	timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* seconds of wall time `nthreads` pipeline threads take to put `nblocks` blocks of `nframes` frames through the `nch`
+ * receivers dealt among them (receiver c on thread c mod nthreads); < 0: a start()/run() failed.  *audio_frames (optional):
+ * audio frames produced in all, *abs_sum: their absolute sum (so that nothing is optimised away, and for a look). */
+double ref_bench_receivers(unsigned int fs, const int *ifs, unsigned int nch, unsigned int chan_passband, unsigned int chan_rate,
+                           int mode, unsigned int audio_passband, unsigned int audio_rate, const float *iq, size_t nframes,
+                           unsigned int nblocks, unsigned int nthreads, size_t *audio_frames, double *abs_sum)
+{
+	if (!nthreads || !nch || nthreads > nch)
+		return -1.0;
+	pthread_barrier_t ready, go;
+	pthread_barrier_init(&ready, 0, nthreads + 1);
+	pthread_barrier_init(&go, 0, nthreads + 1);
+	std::vector<BenchThread> th(nthreads);
+	for (unsigned int t = 0; t < nthreads; t++) {
+		BenchThread &b = th[t];
+		b.fs = fs; b.cpb = chan_passband; b.crate = chan_rate; b.apb = audio_passband; b.arate = audio_rate;
+		b.mode = mode; b.nblocks = nblocks; b.iq = iq; b.nframes = nframes; b.ready = &ready; b.go = &go;
+		for (unsigned int c = t; c < nch; c += nthreads)
+			b.ifs.push_back(ifs[c]);
+		pthread_create(&b.tid, 0, bench_thread, &b);
+	}
+	pthread_barrier_wait(&ready);
+	const double t0 = mono();
+	pthread_barrier_wait(&go);
+	pthread_barrier_wait(&ready);
+	const double dt = mono() - t0;
+	double sum = 0;
+	size_t frames = 0;
+	int rc = 0;
+	for (unsigned int t = 0; t < nthreads; t++) {
+		pthread_join(th[t].tid, 0);
+		sum += th[t].sum;
+		frames += th[t].frames;
+		if (th[t].rc)
+			rc = th[t].rc;
+	}
+	pthread_barrier_destroy(&ready);
+	pthread_barrier_destroy(&go);
+	if (audio_frames)
+		*audio_frames = frames;
+	if (abs_sum)
+		*abs_sum = sum;
+	return rc ? (double)rc : dt;
+}
+
+}  // extern "C"

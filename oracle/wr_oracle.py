@@ -381,6 +381,9 @@ def ref_chain():
                                          C.POINTER(C.c_size_t)]
         R.ref_downconverter.restype = C.c_int
         R.ref_downconverter.argtypes = [C.c_uint, C.c_int, _fp, C.c_size_t, C.c_size_t, _fp]
+        R.ref_bench_receivers.restype = C.c_double
+        R.ref_bench_receivers.argtypes = [C.c_uint, C.POINTER(C.c_int), C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint,
+                                          _fp, C.c_size_t, C.c_uint, C.c_uint, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
         R.ref_spectrum.restype = C.c_int
         R.ref_spectrum.argtypes = [C.c_uint, C.c_uint, _fp, C.c_size_t, C.c_size_t, _fp]
         _ref_chain = R
@@ -425,3 +428,16 @@ def ref_spectrum_db(fs, fft_size, iq, block_frames):
     rc = ref_chain().ref_spectrum(fs, fft_size, _p(iq), iq.size // 2, block_frames, _p(db))
     assert rc == 0, rc
     return db
+
+
+def ref_bench_receivers(input_rate, ifs, chan_passband, chan_rate, mode, audio_passband, audio_rate, iq, nblocks, nthreads):
+    """seconds `nthreads` pipeline threads of the REAL reference take for `nblocks` blocks (see oracle/ref_chain.cxx);
+    returns (seconds, audio frames produced, absolute sum of the audio)"""
+    iq = _f32(iq)
+    ifs = np.ascontiguousarray(ifs, dtype=np.int32)
+    frames, s = C.c_size_t(), C.c_double()
+    dt = ref_chain().ref_bench_receivers(input_rate, ifs.ctypes.data_as(C.POINTER(C.c_int)), ifs.size, chan_passband, chan_rate,
+                                         mode, audio_passband, audio_rate, _p(iq), iq.size // 2, nblocks, nthreads,
+                                         C.byref(frames), C.byref(s))
+    assert dt > 0, dt
+    return dt, frames.value, s.value
