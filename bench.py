@@ -479,8 +479,8 @@ def run_c5(args, torch, dist, rank, world, device_index):
         step(i)
     tuner.flush()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0         # (the closing barrier's own latency is nobody's step: see timed_steps)
     barrier()
-    elapsed = time.perf_counter() - t0
     launches, ddc_ms = tuner.profile_read()
     tuner.profile(False)
     if dist is not None:
@@ -666,9 +666,9 @@ def main():
         # include/webradio_amd.h): have the last one's run too, inside the timed region
         tuner.flush()
         torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        got, ms = tuner.profile_read()
+        dt = time.perf_counter() - t0          # this rank's K steps, from the common start to its own last kernel's end ...
+        barrier()                              # ... the ranks meet again, and the job's time is the MAX over them (below):
+        got, ms = tuner.profile_read()         # a collective's own latency (RCCL: tens of us) is not part of anybody's steps
         tuner.profile(False)
         return dt, got, ms
 
