@@ -127,3 +127,30 @@ TAPS_TOL = 1e-7          # the 64-point inverse DFT: rocFFT's f32 butterflies vs
 CHAN_TOL = 1e-6          # channel IQ (the oracle's own bar for the fast NCO modes)
 AUDIO_TOL = 1e-5
 DB_TOL = 0.02            # dB, on bins within 60 dB of the frame's peak (f32 FFT rounding dominates below)
+
+
+# ---- full-size cases, LIVE only (the inputs are regenerated on the box; nothing of this size is committed) -------------
+# BASELINE config 2 at its full block size and config 5's parameters: a few of the 256 receivers through the reference's
+# own chain, the whole 256-receiver tuner through the HIP path.
+def _c2_if(c, if0=-39_843_750, step=312_500):
+    return if0 + c * step
+
+
+FULL = {
+    "c2_full": dict(fs=100_000_000, cpb=6_400_000, crate=250_000, mode=FM, apb=8_000, arate=50_000, block=4_000_000, blocks=1,
+                    channels=256, if0=-39_843_750, if_step=312_500, probe=[0, 5, 129, 254],
+                    carriers=[(_c2_if(0), 0.11, 700, 3.0), (_c2_if(5), 0.12, 900, 2.0), (_c2_if(129), 0.1, 1_100, 4.0),
+                              (_c2_if(254), 0.09, 500, 2.5), (_c2_if(77), 0.1, 0, 0.0)], seed=41),
+    "c5_chunks": dict(fs=1_000_000_000, cpb=64_000_000, crate=250_000, mode=FM, apb=8_000, arate=50_000, block=560_000, blocks=2,
+                      channels=256, if0=-398_437_500, if_step=3_125_000, probe=[3, 200],
+                      carriers=[(-398_437_500 + 3 * 3_125_000, 0.2, 3_000, 2.0), (-398_437_500 + 200 * 3_125_000, 0.2, 4_000, 2.0)],
+                      seed=42),
+}
+
+
+def full_input(c):
+    return synth_iq(c["block"] * c["blocks"], c["fs"], c["carriers"], 0.004, c["seed"])
+
+
+def full_ifs(c):
+    return [c["if0"] + i * c["if_step"] for i in range(c["channels"])]

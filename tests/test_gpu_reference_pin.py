@@ -137,6 +137,47 @@ def test_live_spectrum(live, oracle, dev, gold, name):
         assert np.abs(gold["spec_" + name] - want)[strong].max() <= 1e-4
 
 
+@pytest.fixture(scope="module")
+def live_full(oracle, tmp_path_factory):
+    if not os.path.exists(oracle.REF_CHAIN_LIB):
+        pytest.skip("oracle/_ref/libwr_ref_chain.so not built (needs /root/reference at build time)")
+    import sys
+    import _proc
+    out = str(tmp_path_factory.mktemp("refchain") / "full.npz")
+    _proc.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_reference_chain_golden.py"), "--full", out],
+              timeout=280, env=dict(os.environ, WEBRADIO_QUIET="1"))
+    return np.load(out)
+
+
+@pytest.mark.parametrize("name", sorted(refcases.FULL))
+def test_full_size_tuner_against_the_live_reference(live_full, dev, name):
+    """BASELINE config 2 at its full size (256 receivers, one 4 000 000-frame block off 100 Msps) and config 5's parameters
+    (1 Gsps, D1 = 4000, two blocks): the whole tuner through the HIP path in its default mode, a few of its receivers through
+    the reference's OWN DownConverter -> LowPass -> Demodulator -> LowPass on the same input -- channel IQ within 1e-6, FM
+    audio within 1e-5 (the probed receivers hold carriers)."""
+    c = refcases.FULL[name]
+    iq = refcases.full_input(c)
+    assert np.array_equal(refcases.sha(iq), live_full["sha_full_" + name])
+    ifs = refcases.full_ifs(c)
+    n = c["block"]
+    t = Tuner(dev, c["fs"], c["channels"], n, capi.WR_NCO_ROTATE)
+    chans = [t.add_receiver(f, c["cpb"], c["crate"], c["mode"], c["apb"], c["arate"]) for f in ifs]
+    got = {ch: ([], []) for ch in c["probe"]}
+    for b in range(c["blocks"]):
+        t.submit_host(iq[2 * n * b: 2 * n * (b + 1)])
+        for ch in c["probe"]:
+            got[ch][0].append(t.fetch(chans[ch], capi.WR_STAGE_CHAN_IQ, 2 * n))
+            got[ch][1].append(t.fetch(chans[ch], capi.WR_STAGE_AUDIO, n))
+    t.destroy()
+    for ch in c["probe"]:
+        w_chan, w_audio = live_full["full_%s_%d_chan" % (name, ch)], live_full["full_%s_%d_audio" % (name, ch)]
+        g_chan, g_audio = np.concatenate(got[ch][0]), np.concatenate(got[ch][1])
+        assert g_chan.shape == w_chan.shape and g_audio.shape == w_audio.shape and w_audio.size > 0
+        assert np.abs(g_chan - w_chan).max() <= refcases.CHAN_TOL, (ch, float(np.abs(g_chan - w_chan).max()))
+        assert np.abs(g_audio - w_audio).max() <= refcases.AUDIO_TOL, (ch, float(np.abs(g_audio - w_audio).max()))
+        assert np.abs(w_audio).max() > 1e-3
+
+
 @pytest.mark.parametrize("name", sorted(refcases.CHAINS))
 def test_hip_path_against_committed_reference_vectors(dev, name):
     """No oracle/_ref needed: the HIP path against what the reference produced when the vectors were made."""
