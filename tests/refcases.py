@@ -154,3 +154,8 @@ def full_input(c):
 
 def full_ifs(c):
     return [c["if0"] + i * c["if_step"] for i in range(c["channels"])]
+
+
+# BASELINE config 3 at its full size: the waterfall of one 4 000 000-frame block (65536 points every 32768 frames, 121 rows);
+# these rows of it through the reference's own SpectrumSink, fed the row's 65536 frames
+C3_FULL = dict(case="c2_full", n=65_536, hop=32_768, rows=[0, 1, 57, 120])

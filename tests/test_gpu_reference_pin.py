@@ -178,6 +178,31 @@ def test_full_size_tuner_against_the_live_reference(live_full, dev, name):
         assert np.abs(w_audio).max() > 1e-3
 
 
+def test_full_size_waterfall_against_the_live_reference(live_full, dev):
+    """BASELINE config 3 at its full size: the 121-row waterfall of a 4 000 000-frame block (65536-point frames every 32768
+    frames, wr_spectrum_batch_db: k_fft64k_pass1/2), four of its rows against the reference's own SpectrumSink fed the row's
+    65536 frames (the reference itself does not overlap: SURVEY section 0)."""
+    import torch
+    c3 = refcases.C3_FULL
+    c = refcases.FULL[c3["case"]]
+    iq = refcases.full_input(c)
+    nrows = (c["block"] - c3["n"]) // c3["hop"] + 1
+    assert nrows == 121
+    x = torch.from_numpy(iq).cuda()
+    out = torch.empty(nrows * c3["n"], dtype=torch.float32, device="cuda")
+    s = Spectrum(dev, c3["n"], c3["hop"])
+    s.batch_db(x, nrows, out)
+    torch.cuda.synchronize()
+    rows = out.cpu().numpy().reshape(nrows, c3["n"])
+    s.destroy()
+    for r in c3["rows"]:
+        want = live_full["c3_row_%d" % r]
+        strong = want >= want.max() - 60.0
+        assert strong.sum() >= 3
+        assert np.abs(rows[r] - want)[strong].max() <= refcases.DB_TOL, r
+        assert int(np.argmax(rows[r])) == int(np.argmax(want))
+
+
 @pytest.mark.parametrize("name", sorted(refcases.CHAINS))
 def test_hip_path_against_committed_reference_vectors(dev, name):
     """No oracle/_ref needed: the HIP path against what the reference produced when the vectors were made."""

@@ -87,6 +87,42 @@ def main():
         s.destroy()
         print("  %-10s %.2e ; %.2e   (%d strong bins)  %d / %d / %d" % (name, np.abs(oo.get() - want)[strong].max(),
               np.abs(got - want)[strong].max(), int(strong.sum()), int(np.argmax(want)), int(np.argmax(oo.get())), int(np.argmax(got))))
+    # full-size cases (live only): BASELINE configs 2, 5 (parameters) and 3
+    full_path = os.path.join(os.path.dirname(live_path), "full.npz")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "golden", "make_reference_chain_golden.py"), "--full", full_path],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400)
+    full = np.load(full_path)
+    print("\nFull size, the whole 256-receiver tuner on the HIP path (ROTATE) against probed receivers of the reference's own chain: max |chan IQ - ref| / max |audio - ref|")
+    for name, c in sorted(refcases.FULL.items()):
+        iq = refcases.full_input(c)
+        ifs = refcases.full_ifs(c)
+        n = c["block"]
+        t = Tuner(dev, c["fs"], c["channels"], n, capi.WR_NCO_ROTATE)
+        chans = [t.add_receiver(f, c["cpb"], c["crate"], c["mode"], c["apb"], c["arate"]) for f in ifs]
+        got = {ch: ([], []) for ch in c["probe"]}
+        for b in range(c["blocks"]):
+            t.submit_host(iq[2 * n * b: 2 * n * (b + 1)])
+            for ch in c["probe"]:
+                got[ch][0].append(t.fetch(chans[ch], capi.WR_STAGE_CHAN_IQ, 2 * n))
+                got[ch][1].append(t.fetch(chans[ch], capi.WR_STAGE_AUDIO, n))
+        t.destroy()
+        print("  %-10s %d frames x %d block(s): " % (name, n, c["blocks"]) + "; ".join(
+            "rx %d: %.1e / %.1e" % (ch, np.abs(np.concatenate(got[ch][0]) - full["full_%s_%d_chan" % (name, ch)]).max(),
+                                    np.abs(np.concatenate(got[ch][1]) - full["full_%s_%d_audio" % (name, ch)]).max()) for ch in c["probe"]))
+    c3 = refcases.C3_FULL
+    c = refcases.FULL[c3["case"]]
+    iq = refcases.full_input(c)
+    nrows = (c["block"] - c3["n"]) // c3["hop"] + 1
+    x = torch.from_numpy(iq).cuda()
+    out = torch.empty(nrows * c3["n"], dtype=torch.float32, device="cuda")
+    s = Spectrum(dev, c3["n"], c3["hop"])
+    s.batch_db(x, nrows, out)
+    torch.cuda.synchronize()
+    rows = out.cpu().numpy().reshape(nrows, c3["n"])
+    s.destroy()
+    print("  C3 waterfall, %d rows of 65536 points, rows %s against the reference's SpectrumSink: max |dB - ref| on strong bins: %s" % (
+        nrows, c3["rows"], ", ".join("%.1e" % np.abs(rows[r] - full["c3_row_%d" % r])[full["c3_row_%d" % r] >= full["c3_row_%d" % r].max() - 60.0].max()
+                                    for r in c3["rows"])))
     dev.close()
 
 
