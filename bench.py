@@ -467,7 +467,19 @@ def run_c5(args, torch, dist, rank, world, device_index):
     if args.settle_ms > 0:                              # clocks: see --settle-ms
         torch.cuda.synchronize()
         t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        while True:
+            # Every step holds a halo exchange with the ring neighbour, so all ranks must take the SAME number of steps:
+            # whether to go on is decided together (a MAX over the ranks' own clocks), never by a rank on its own.
+            # (r03 let each rank look at its own clock: two ranks a millisecond apart at the 150 ms mark left one of them
+            # in an exchange nobody answered -- about one run in twenty over gloo, until the collective's 30-minute
+            # timeout: the hang that cost GPUTEST_r03 its time limit; profiles/r04_spawn_runs.txt caught it.)
+            more = (time.perf_counter() - t_settle) * 1e3 < args.settle_ms
+            if dist is not None:
+                flag = torch.tensor([1 if more else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = bool(flag.item())
+            if not more:
+                break
             for _ in range(50):
                 step(done)
                 done += 1
