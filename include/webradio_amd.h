@@ -140,7 +140,11 @@ int wr_dev_download(wr_dev *dev, void *dst_host, const void *src_dev, size_t byt
 /* For callers that upload the same host buffer block after block (DspSource's output vector,
  * dspblock.h:118, 130-137): page-lock it once, then enqueue the copy and carry on -- the DMA runs
  * beside the caller's own work.  The buffer must not be written until wr_dev_wait_uploads()
- * (or wr_dev_sync) returns, and must be unregistered before it is freed. */
+ * (or wr_dev_sync) returns, and must be unregistered before it is freed.
+ * Register memory that OWNS its pages -- a mapping of its own, as the allocator gives any large vector; page-aligned with
+ * its last page to itself if it is carved out of something larger.  A registered range that shares a page with other
+ * allocations, or whose address the allocator hands out again, can collide with the page locks the HIP runtime takes on
+ * the fly for copies into pageable memory: on ROCm 7.2 that aborts the process (profiles/r04_abort_hunt.txt). */
 int wr_dev_host_register(wr_dev *dev, void *host, size_t bytes);
 int wr_dev_host_unregister(wr_dev *dev, void *host);
 int wr_dev_upload_async(wr_dev *dev, void *dst_dev, const void *src_host, size_t bytes);

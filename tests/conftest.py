@@ -17,8 +17,8 @@ NG2_MODULES = ("test_gpu_tuner", "test_gpu_timeshard", "test_gpu_ring", "test_gp
 
 # Oracle-parity modules first, process-spawning contract tests last: under `-x` a hiccup in a launcher test must not
 # cost the parity run (GPUTEST_r03).
-ORDER = ["test_gpu_blocks", "test_gpu_tuner", "test_gpu_spectrum", "test_gpu_f4", "test_gpu_fuzz", "test_gpu_ring",
-         "test_gpu_timeshard", "test_gpu_host", "test_gpu_c_client", "test_gpu_bench"]
+ORDER = ["test_gpu_blocks", "test_gpu_tuner", "test_gpu_reference_pin", "test_gpu_spectrum", "test_gpu_stage", "test_gpu_f4",
+         "test_gpu_fuzz", "test_gpu_ring", "test_gpu_timeshard", "test_gpu_host", "test_gpu_c_client", "test_gpu_bench"]
 
 PER_TEST_LIMIT_S = 300.0        # no test takes a tenth of this; see the watchdog below
 
@@ -32,7 +32,8 @@ def pytest_collection_modifyitems(config, items):
     def key(item):
         name = item.module.__name__.split(".")[-1]
         return ORDER.index(name) if name in ORDER else -1        # CPU-side modules keep their place at the front
-    items.sort(key=key)                                            # stable: order within a module is kept
+    if not os.environ.get("WR_TEST_KEEP_ORDER"):                   # (a hunt for an order-dependent failure wants its own order)
+        items.sort(key=key)                                        # stable: order within a module is kept
     for item in items:
         if item.get_closest_marker("timeout") is None:
             item.add_marker(pytest.mark.timeout(PER_TEST_LIMIT_S))  # pytest-timeout, where it is installed
@@ -98,6 +99,57 @@ def dev():
     d = Device(0)
     yield d
     d.close()
+
+
+# ---- host memory that tests page-lock (wr_dev_host_register) ---------------------------------------------------------------
+# One anonymous mapping made when this file is imported -- before the process has copied anything to or from the GPU -- and
+# never unmapped: every buffer a test registers is a page-aligned piece of it with a guard page behind, handed out once.
+# Why: a registered numpy array from the heap shares its first and last page with whatever the allocator puts beside it, and
+# its address is handed out again after the test; the HIP runtime page-locks the destination of every copy into pageable
+# memory on the fly and keeps those locks for a while.  One run in a dozen of the sequence test_gpu_stage -> test_gpu_blocks
+# ABORTED inside a copy into a fresh numpy array next to registered ones (profiles/r04_gate_loop.txt, pass 1).  Pages that
+# are only ever ours, at addresses no earlier allocation has had, cannot collide with any of that.
+_POOL_BYTES = 256 << 20
+_pool = None
+_pool_used = 0
+
+
+def _pinned_pool():
+    global _pool
+    if _pool is None:
+        import mmap
+        _pool = mmap.mmap(-1, _POOL_BYTES)
+    return _pool
+
+
+_pinned_pool()
+
+
+@pytest.fixture
+def page_locked(dev):
+    """page_locked(count, dtype) -> a zero-filled numpy array in page-aligned memory of its own, registered with the
+    device (wr_dev_host_register); unregistered again when the test ends (after the device has gone idle)."""
+    import ctypes as C
+    import numpy as np
+    made = []
+
+    def make(count, dtype=np.uint8):
+        global _pool_used
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        span = (nbytes + 4095) // 4096 * 4096 + 4096                     # + a guard page nobody else gets
+        assert _pool_used + span <= _POOL_BYTES, "tests/conftest.py: the page-locked pool is exhausted"
+        arr = np.frombuffer(_pinned_pool(), dtype=np.uint8, count=nbytes, offset=_pool_used).view(dtype)
+        _pool_used += span
+        arr[...] = 0
+        assert dev.lib.wr_dev_host_register(dev.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes) == 0, dev.lib.wr_last_error()
+        made.append(arr)
+        return arr
+
+    yield make
+    dev.sync()
+    dev.lib.wr_dev_wait_uploads(dev.h)
+    for arr in made:
+        dev.lib.wr_dev_host_unregister(dev.h, arr.ctypes.data_as(C.c_void_p))
 
 
 @pytest.fixture(scope="session")

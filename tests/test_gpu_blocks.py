@@ -147,7 +147,7 @@ def test_u8_ingest(dev, oracle):
     dev.free(dout)
 
 
-def test_u8_ingest_from_page_locked_host_memory(dev, oracle):
+def test_u8_ingest_from_page_locked_host_memory(dev, oracle, page_locked):
     """wr_u8_to_f32_from_host: the bytes cross PCIe on the library's own stream (DMA + conversion kernel) and the
     device's stream waits for them.  Blocks alternate between two device buffers and two host buffers the way the host
     runtime stages a RawU8Block source (gpubatch.cxx), one size that is not a multiple of 16, the same buffer twice in a
@@ -156,9 +156,7 @@ def test_u8_ingest_from_page_locked_host_memory(dev, oracle):
     import ctypes as C
     rng = np.random.default_rng(11)
     n = 1_000_003
-    hosts = [np.zeros(n, np.uint8), np.zeros(n, np.uint8)]
-    for h in hosts:
-        capi.check(dev.lib.wr_dev_host_register(dev.h, capi.ptr(h), h.size))
+    hosts = [page_locked(n, np.uint8), page_locked(n, np.uint8)]          # (registered; tests/conftest.py says where they live)
     douts = [dev.malloc(n * 4), dev.malloc(n * 4)]
     try:
         for b in range(7):
@@ -175,22 +173,18 @@ def test_u8_ingest_from_page_locked_host_memory(dev, oracle):
         assert dev.lib.wr_u8_to_f32_from_host(dev.h, capi.ptr(other), C.c_void_p(douts[0]), 64) == capi.WR_ERR_ARG
     finally:
         dev.sync()
-        for h in hosts:
-            dev.lib.wr_dev_host_unregister(dev.h, capi.ptr(h))
         for d in douts:
             dev.free(d)
 
 
-def test_upload_ahead_alternating_buffers(dev):
+def test_upload_ahead_alternating_buffers(dev, page_locked):
     """wr_dev_upload_ahead: the copy runs on the library's upload stream and the device's stream waits for it.  Blocks
     alternate between two device buffers (what the host runtime does with a float source's block vector), each is read
     back on the device's stream before the next call, the same buffer twice in a row works too."""
     import ctypes as C
     rng = np.random.default_rng(12)
     n = 300_001
-    hosts = [np.zeros(n, np.float32), np.zeros(n, np.float32)]
-    for h in hosts:
-        capi.check(dev.lib.wr_dev_host_register(dev.h, capi.ptr(h), h.nbytes))
+    hosts = [page_locked(n, np.float32), page_locked(n, np.float32)]
     douts = [dev.malloc(n * 4), dev.malloc(n * 4)]
     try:
         for b in range(8):
@@ -204,8 +198,6 @@ def test_upload_ahead_alternating_buffers(dev):
     finally:
         dev.sync()
         capi.check(dev.lib.wr_dev_wait_uploads(dev.h))
-        for h in hosts:
-            dev.lib.wr_dev_host_unregister(dev.h, capi.ptr(h))
         for d in douts:
             dev.free(d)
 

@@ -52,7 +52,9 @@ def _run(libname, tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
     cap = nblocks * (block // (rate // crate) // (crate // arate)) + 16
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32), modes=np.array(modes, np.int32),
              params=np.array([rate, block, cpb, crate, apb, arate, retune[0], retune[1], cap, fft], np.int64))
-    e = dict(os.environ, WEBRADIO_QUIET="1")
+    # (the tests' blocks are small; the runtime page-locks a source block only from 1 MB on: here from the first byte, so that
+    # the staging paths a 100 Msps tuner takes -- DMA from page-locked memory, sparse staging -- are the ones run)
+    e = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0")
     e.update(env or {})
     # a fresh process per run: the host runtime keeps per-process device contexts and env switches
     _proc.run([sys.executable, "-c", RUNNER, lib, inp, out], env=e)
@@ -250,7 +252,7 @@ def test_stop_start_keeps_phase_and_two_front_ends(tmp_path, oracle):
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([rate, block, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], mode, restart_at, cap], np.int64))
     _proc.run([sys.executable, "-c", RESTART_RUNNER, lib, inp, out],
-                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
+                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0", WEBRADIO_NCO_EXACT="1"))
     r = np.load(out)
     assert int(r["rc"]) == 0 and int(r["left"]) == 0
     got = r["audio"]
@@ -299,7 +301,7 @@ def test_stop_set_rate_and_block_size_start(tmp_path, oracle):
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([r1, b1, r2, b2, n1, n2, mode, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], cap], np.int64))
     _proc.run([sys.executable, "-c", RERATE_RUNNER, lib, inp, out],
-                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
+                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0", WEBRADIO_NCO_EXACT="1"))
     r = np.load(out)
     assert int(r["rc"]) == 0 and int(r["left"]) == 0
     for c, f in enumerate(ifs):
@@ -347,7 +349,7 @@ def test_late_audio_keeps_both_front_ends_in_flight(tmp_path, oracle):
     res = {}
     for late in ("0", "1", "2"):
         _proc.run([sys.executable, "-c", TRACED_RUNNER, lib, inp, out],
-                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1",
+                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0", WEBRADIO_NCO_EXACT="1", WEBRADIO_TRACE="1",
                                        WEBRADIO_AUDIO_LATE=late))
         r = np.load(out)
         assert int(r["rc"]) == 0 and int(r["left"]) == 0
@@ -411,7 +413,7 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
     for env, tol in (({"WEBRADIO_NCO_EXACT": "1"}, 4.8e-7), ({}, 1e-5),
                      ({"WEBRADIO_NCO_EXACT": "1", "WEBRADIO_NO_U8_STAGING": "1"}, 4.8e-7)):
         _proc.run([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
-                              env=dict(os.environ, WEBRADIO_QUIET="1", **env))
+                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0", **env))
         r = np.load(out)
         assert int(r["rc"]) == 0 and int(r["left"]) == 0
         assert r["audio"].size == g["audio"].size
@@ -421,7 +423,7 @@ def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
     # (silence first, the last block's audio dropped at stop())
     for late in ("1", "2"):
         _proc.run([sys.executable, "-c", FILE_RUNNER, lib, path, out] + [str(a) for a in args],
-                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1", WEBRADIO_AUDIO_LATE=late))
+                              env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0", WEBRADIO_NCO_EXACT="1", WEBRADIO_AUDIO_LATE=late))
         r = np.load(out)
         assert int(r["rc"]) == 0 and int(r["left"]) == 0 and r["audio"].size == g["audio"].size
         per = g["audio"].size // 4 * int(late)
@@ -456,7 +458,7 @@ def test_setters_from_another_thread_while_running(tmp_path):
     iq = synth.fm_stream(30 * block, rate, [50_000, -75_000], amp=0.3)
     inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     np.savez(inp, iq=iq, params=np.array([rate, block, 12, CFG["crate"], CFG["arate"]], np.int64))
-    _proc.run([sys.executable, "-c", STRESS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
+    _proc.run([sys.executable, "-c", STRESS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0"),
                           timeout=240)
     r = np.load(out)
     assert int(r["calls"]) > 1000 and int(r["left"]) == 0
@@ -503,7 +505,7 @@ def test_multistage_decimation_chain_on_device(tmp_path, oracle):
     lib = os.path.join(CXXT, "libwr_host_pipeline.so")
     inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
     np.savez(inp, iq=iq, params=np.array([fs, block, f_if, mode, apb, arate], np.int64), rates=np.array(rates), pbs=np.array(pbs))
-    _proc.run([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1"),
+    _proc.run([sys.executable, "-c", MS_RUNNER, lib, inp, out], env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0"),
                           timeout=240)
     r = np.load(out)
     got = r["audio"]
@@ -608,7 +610,7 @@ def test_second_consumer_inside_a_fused_chain(tmp_path, oracle):
     np.savez(inp, iq=iq, ifs=np.array(ifs, np.int32),
              params=np.array([rate, block, mode, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"], tap_at, cap, tcap], np.int64))
     _proc.run([sys.executable, "-c", TAP_RUNNER, lib, inp, out],
-                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_NCO_EXACT="1"))
+                          env=dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_PIN_MIN_BYTES="0", WEBRADIO_NCO_EXACT="1"))
     r = np.load(out)
     assert int(r["rc"]) == 0 and int(r["left"]) == 0
     blocks = [iq[2 * b * block: 2 * (b + 1) * block] for b in range(nblk)]

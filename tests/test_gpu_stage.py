@@ -13,11 +13,6 @@ from webradio_amd.device import Tuner
 pytestmark = pytest.mark.gpu
 
 
-def _pinned(dev, arr):
-    assert dev.lib.wr_dev_host_register(dev.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes) == 0, dev.lib.wr_last_error()
-    return arr
-
-
 def _needed(nframes, period, length, tail):
     need = np.zeros(nframes, bool)
     for k in range(nframes // period + 1):
@@ -32,14 +27,16 @@ def _needed(nframes, period, length, tail):
 @pytest.mark.parametrize("nframes,period,length,tail", [(40_000, 400, 64, 63), (100_000, 4000, 64, 1200), (8_192, 130, 64, 64),
                                                        (20_000, 400, 32, 700), (30_001, 333, 64, 100), (1_000, 2_000, 64, 63),
                                                        (640, 64, 64, 640)])
-def test_windows_and_tail_land_where_the_whole_block_puts_them(dev, u8, nframes, period, length, tail):
+def test_windows_and_tail_land_where_the_whole_block_puts_them(dev, page_locked, u8, nframes, period, length, tail):
     import torch
     rng = np.random.default_rng(nframes + period)
     if u8:
-        host = _pinned(dev, rng.integers(0, 256, 2 * nframes + 64, dtype=np.uint8)[: 2 * nframes])
+        host = page_locked(2 * nframes, np.uint8)
+        host[:] = rng.integers(0, 256, 2 * nframes, dtype=np.uint8)
         want = ((host.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)).astype(np.float32)
     else:
-        host = _pinned(dev, rng.standard_normal(2 * nframes).astype(np.float32))
+        host = page_locked(2 * nframes, np.float32)
+        host[:] = rng.standard_normal(2 * nframes).astype(np.float32)
         want = host
     assert host.ctypes.data % 16 == 0
     out = torch.full((2 * nframes,), float("nan"), device="cuda")
@@ -54,7 +51,6 @@ def test_windows_and_tail_land_where_the_whole_block_puts_them(dev, u8, nframes,
     assert np.array_equal(got[staged].view(np.uint32), w[staged].view(np.uint32))        # and nothing staged is wrong
     if period >= 4 * length and nframes >= 8 * period:
         assert staged.mean() < 0.5                                                       # it IS sparse
-    dev.lib.wr_dev_host_unregister(dev.h, host.ctypes.data_as(C.c_void_p))
 
 
 def test_argument_checks(dev):
@@ -70,7 +66,7 @@ def test_argument_checks(dev):
 
 
 @pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32"])
-def test_tuner_fed_from_a_sparsely_staged_block(dev, u8):
+def test_tuner_fed_from_a_sparsely_staged_block(dev, page_locked, u8):
     """Three consecutive blocks at C2's ratios (D1 = 400, 64 taps): the audio of a tuner whose blocks were staged sparsely is
     the audio of the same tuner fed the whole blocks -- the kernel reads nothing the sparse stage left out."""
     import torch
@@ -82,7 +78,9 @@ def test_tuner_fed_from_a_sparsely_staged_block(dev, u8):
         full = ((raw.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)).astype(np.float32)
     else:
         raw, full = iq, iq
-    raw = _pinned(dev, raw.copy())
+    src = page_locked(raw.size, raw.dtype)
+    src[:] = raw
+    raw = src
     want, got = [], []
     for sparse in (False, True):
         t = Tuner(dev, fs, 8, n, capi.WR_NCO_ROTATE)
@@ -102,6 +100,5 @@ def test_tuner_fed_from_a_sparsely_staged_block(dev, u8):
         t.destroy()
         (got if sparse else want).append(np.concatenate(rows, axis=1))
     dev.lib.wr_dev_wait_uploads(dev.h)
-    dev.lib.wr_dev_host_unregister(dev.h, raw.ctypes.data_as(C.c_void_p))
     assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
     assert np.isfinite(got[0]).all() and np.abs(got[0]).max() > 1e-3

@@ -123,6 +123,15 @@ struct SourceStage {
 				return true;
 		if (envUnsigned("WEBRADIO_NO_PINNING", 0))
 			return false;
+		/* Small blocks are not page-locked: the allocator serves them from the heap, where a registered range shares
+		 * its first and last page with its neighbours and its address is soon handed out again -- and on this ROCm a
+		 * registered range that overlaps memory the runtime page-locks on the fly (the destination of any copy into
+		 * pageable memory) can abort the process (r04: profiles/r04_abort_hunt.txt).  Large vectors get a mapping of
+		 * their own from the allocator; small ones are copied through the runtime's staging buffers, which at their
+		 * size costs nothing that matters. */
+		static const size_t minBytes = envUnsigned("WEBRADIO_PIN_MIN_BYTES", 1u << 20);
+		if (bytes < minBytes)
+			return false;
 		for (size_t n = 0; n < pinned.size(); n++)
 			if (pinned[n].ptr == p) {                      /* same address, grown: register afresh */
 				wr_dev_wait_uploads(d);                    /* (a copy out of it may still be in flight) */
