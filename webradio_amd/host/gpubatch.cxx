@@ -5,6 +5,8 @@
  */
 #include "gpubatch.h"
 
+#include <stdint.h>
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -131,6 +133,14 @@ struct SourceStage {
 		 * size costs nothing that matters. */
 		static const size_t minBytes = envUnsigned("WEBRADIO_PIN_MIN_BYTES", 1u << 20);
 		if (bytes < minBytes)
+			return false;
+		/* ... and of the large ones only those that start where a mapping of their own starts: glibc hands out a
+		 * request above its mmap threshold as a private mapping with the user pointer 16 bytes into its first page
+		 * (an aligned_alloc / mmap / hipHostMalloc'ed buffer starts ON a page); once the threshold has grown -- it
+		 * follows the largest mapped block freed so far, up to 32 MB -- even megabytes come from the heap, in the
+		 * middle of a page somebody else also lives on.  WEBRADIO_PIN_ANY=1 lifts the check. */
+		static const bool pinAny = envUnsigned("WEBRADIO_PIN_ANY", 0) != 0 || minBytes == 0;
+		if (!pinAny && ((uintptr_t)p & 4095u) > 64u)
 			return false;
 		for (size_t n = 0; n < pinned.size(); n++)
 			if (pinned[n].ptr == p) {                      /* same address, grown: register afresh */
