@@ -81,6 +81,7 @@ def parse():
                     help="start the ranks from this process even at --gpus 1 (tests: the launch path itself -- file-store "
                          "rendezvous, watchdog, RCCL at world size 1)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)    # tests: this rank exits 3 after the rendezvous
+    ap.add_argument("--settle-skew-ms", type=float, default=0.0, help=argparse.SUPPRESS)   # tests: rank r's settle clock runs r x this ahead
     ap.add_argument("--spawn-timeout", type=float, default=1500.0,
                     help="N > 1 without a launcher: seconds the ranks this process starts may take before it kills them "
                          "and exits 124 with their stderr")
@@ -473,7 +474,7 @@ def run_c5(args, torch, dist, rank, world, device_index):
             # (r03 let each rank look at its own clock: two ranks a millisecond apart at the 150 ms mark left one of them
             # in an exchange nobody answered -- about one run in twenty over gloo, until the collective's 30-minute
             # timeout: the hang that cost GPUTEST_r03 its time limit; profiles/r04_spawn_runs.txt caught it.)
-            more = (time.perf_counter() - t_settle) * 1e3 < args.settle_ms
+            more = (time.perf_counter() - t_settle) * 1e3 + rank * args.settle_skew_ms < args.settle_ms
             if dist is not None:
                 flag = torch.tensor([1 if more else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)

@@ -95,6 +95,18 @@ def test_c5_workload_line_and_two_rank_ring():
     assert abs(j["value"] - 2 * j["config"]["chunk_frames"] * 3 / (j["ms_per_step"] * 3 / 1e3) / 1e6) / j["value"] < 1e-3
 
 
+def test_c5_ranks_take_the_same_number_of_settle_steps():
+    """Every C5 step holds a halo exchange with the neighbour, so the ranks must agree on how many untimed settle steps they
+    take.  r03 let each rank decide by its own clock: two ranks a moment apart at the mark deadlocked about one run in twenty
+    (the hang that cost GPUTEST_r03 its time limit, profiles/r04_spawn_runs_before_fix.txt).  Here rank 1's settle clock is
+    made to run 30 ms ahead of rank 0's: they disagree at every look, and the job still ends -- the decision is collective."""
+    out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5", "--steps", "3", "--warmup",
+                        "1", "--backend", "gloo", "--settle-ms", "60", "--settle-skew-ms", "30", "--spawn-timeout", "120",
+                        "--rdzv-timeout", "40"], cwd=ROOT, env=_plain_env(), timeout=170)
+    j = _line(out)
+    assert j["n_gpus"] == 2 and j["steps"] == 3
+
+
 def test_plain_invocation_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the driver's call style) starts the two
     ranks itself and reports n_gpus = 2 -- it used to run one GPU and say n_gpus 1.  gloo: the test box
