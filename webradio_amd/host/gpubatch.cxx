@@ -493,7 +493,7 @@ TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
 	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateDepth(envUnsigned("WEBRADIO_AUDIO_LATE", 0) >= 2 ? 2u : 1u),
-	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _quantum(0), _delivered(false)
+	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false)
 {
 	if (_pieces < 1 || _late)
 		_pieces = 1;

@@ -153,7 +153,6 @@ private:
 	bool _silence;                    /* late mode, first block: nothing to hand out yet */
 	unsigned long long _lateSeq;      /* blocks submitted so far */
 	unsigned int _pieces;             /* WEBRADIO_PIECES: parts an on-time block is put through in (see submitOnce) */
-	unsigned long _quantum;
 	bool _delivered;                  /* this block's audio already lies in the audio filters' output vectors */
 	std::mutex _lock;
 };
