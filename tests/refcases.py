@@ -139,6 +139,7 @@ def _c2_if(c, if0=-39_843_750, step=312_500):
 FULL = {
     "c2_full": dict(fs=100_000_000, cpb=6_400_000, crate=250_000, mode=FM, apb=8_000, arate=50_000, block=4_000_000, blocks=1,
                     channels=256, if0=-39_843_750, if_step=312_500, probe=[0, 5, 129, 254],
+                    modes={5: AM, 129: USB, 254: LSB},          # (every other receiver: FM)
                     carriers=[(_c2_if(0), 0.11, 700, 3.0), (_c2_if(5), 0.12, 900, 2.0), (_c2_if(129), 0.1, 1_100, 4.0),
                               (_c2_if(254), 0.09, 500, 2.5), (_c2_if(77), 0.1, 0, 0.0)], seed=41),
     "c5_chunks": dict(fs=1_000_000_000, cpb=64_000_000, crate=250_000, mode=FM, apb=8_000, arate=50_000, block=560_000, blocks=2,
@@ -159,3 +160,7 @@ def full_ifs(c):
 # BASELINE config 3 at its full size: the waterfall of one 4 000 000-frame block (65536 points every 32768 frames, 121 rows);
 # these rows of it through the reference's own SpectrumSink, fed the row's 65536 frames
 C3_FULL = dict(case="c2_full", n=65_536, hop=32_768, rows=[0, 1, 57, 120])
+
+
+def full_mode(c, ch):
+    return c.get("modes", {}).get(ch, c["mode"])

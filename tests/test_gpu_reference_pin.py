@@ -154,14 +154,14 @@ def test_full_size_tuner_against_the_live_reference(live_full, dev, name):
     """BASELINE config 2 at its full size (256 receivers, one 4 000 000-frame block off 100 Msps) and config 5's parameters
     (1 Gsps, D1 = 4000, two blocks): the whole tuner through the HIP path in its default mode, a few of its receivers through
     the reference's OWN DownConverter -> LowPass -> Demodulator -> LowPass on the same input -- channel IQ within 1e-6, FM
-    audio within 1e-5 (the probed receivers hold carriers)."""
+    audio within 1e-5 (the probed receivers hold carriers; three of the C2 probes demodulate AM, USB and LSB)."""
     c = refcases.FULL[name]
     iq = refcases.full_input(c)
     assert np.array_equal(refcases.sha(iq), live_full["sha_full_" + name])
     ifs = refcases.full_ifs(c)
     n = c["block"]
     t = Tuner(dev, c["fs"], c["channels"], n, capi.WR_NCO_ROTATE)
-    chans = [t.add_receiver(f, c["cpb"], c["crate"], c["mode"], c["apb"], c["arate"]) for f in ifs]
+    chans = [t.add_receiver(f, c["cpb"], c["crate"], refcases.full_mode(c, i), c["apb"], c["arate"]) for i, f in enumerate(ifs)]
     got = {ch: ([], []) for ch in c["probe"]}
     for b in range(c["blocks"]):
         t.submit_host(iq[2 * n * b: 2 * n * (b + 1)])

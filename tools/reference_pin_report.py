@@ -98,7 +98,7 @@ def main():
         ifs = refcases.full_ifs(c)
         n = c["block"]
         t = Tuner(dev, c["fs"], c["channels"], n, capi.WR_NCO_ROTATE)
-        chans = [t.add_receiver(f, c["cpb"], c["crate"], c["mode"], c["apb"], c["arate"]) for f in ifs]
+        chans = [t.add_receiver(f, c["cpb"], c["crate"], refcases.full_mode(c, i), c["apb"], c["arate"]) for i, f in enumerate(ifs)]
         got = {ch: ([], []) for ch in c["probe"]}
         for b in range(c["blocks"]):
             t.submit_host(iq[2 * n * b: 2 * n * (b + 1)])
