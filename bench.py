@@ -582,6 +582,10 @@ def main():
     if args.watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.backend == "nccl":
+        # RCCL between processes needs dmabuf IPC on this host driver (the task's environment exports it; a launcher that
+        # scrubbed the environment must not cost the job): before the HIP runtime comes up
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     from webradio_amd import capi, synth
     from webradio_amd.device import Device, Tuner
