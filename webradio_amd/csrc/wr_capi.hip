@@ -1948,9 +1948,10 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		bool rode = false;
 		if (g->l1 > WR_FIR_LENGTH)
 			/* a channel filter of 128 or 256 taps: the plain kernel with the reference's arithmetic (wr_kernels.hip:
-			 * k_tuner_ddc_long), which also rolls phase and mixed history; such a group never defers its post stage */
+			 * k_tuner_ddc_long), which also rolls phase and mixed history; r04: its ROTATE form carries the previous block's post stage like the 64-tap kernel */
 			HIP_TRY(wrk_tuner_ddc_long(st, L, g->dev, g->l1, d->table, d->num_cus,
-			                           t->nco_mode != WR_NCO_EXACT && g->long_uniform && long_rot_enabled(), g->long_one, d->hi_cs, d->lo_cs));
+			                           t->nco_mode != WR_NCO_EXACT && g->long_uniform && long_rot_enabled(), g->long_one, d->hi_cs, d->lo_cs,
+			                           g->post_pending ? &g->post_args : nullptr, &rode));
 		else
 			HIP_TRY(wrk_tuner_ddc(st, L, Gs, t->nco_mode == WR_NCO_ROTATE ? d->table_turn : d->table, d->hi_cs, d->lo_cs,
 			                      d->num_cus, g->post_pending ? &g->post_args : nullptr, &rode));
@@ -1981,7 +1982,10 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		/* demodulator output wanted (wr_tuner_keep_stages) or an unusual audio decimation: demod
 		 * and audio filter as two kernels with the demod rows in HBM, at once.  Otherwise one
 		 * fused pass -- deferred to the next launch where that launch can carry it. */
-		const bool defer = !two_kernels && !g->d1b && g->l1 <= WR_FIR_LENGTH && L.k1 && t->defer_post &&
+		/* (r04: a group with a long channel filter defers too where its launch can carry a post stage: the ROTATE kernel,
+		 * every lane group on one long filter) */
+		const bool long_rides = g->l1 > WR_FIR_LENGTH && g->long_uniform && long_rot_enabled();
+		const bool defer = !two_kernels && !g->d1b && (g->l1 <= WR_FIR_LENGTH || long_rides) && L.k1 && t->defer_post &&
 		                   t->nco_mode == WR_NCO_ROTATE;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, Lp, Gp));

@@ -163,7 +163,7 @@ hipError_t wrk_tuner_ddc(hipStream_t st, const WrTunerLaunch &L, const WrGroupDe
  * nco mode); also rolls the group's state (phase, mixed history) into the other set */
 hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
                               const float *table_dev, int num_cus, bool rotate, bool rotate_one_filter, const float *hi_dev,
-                              const float *lo_dev);
+                              const float *lo_dev, const WrPostArgs *post = nullptr, bool *post_taken = nullptr);
 hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G);
 /* second channel-filter stage: k1a first-stage frames of chan_iq[cb] -> k1a / d1b frames of chan_iq2[cb];
  * history from iq2_hist[p2], next history into iq2_hist[p2 ^ 1] */

@@ -1703,18 +1703,76 @@ k_tuner_ddc_long(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_
  * One wave per (k, lane group); the wave's window in LDS, the next segment's frame requested before this segment's chain. */
 /* NG: lane groups per wave (2 when the whole rate group has ONE filter and an even number of lane groups: the two
  * recurrences share the window and every one of its LDS reads, and fill each other's issue gaps -- see k_tuner_ddc) */
-template <unsigned int NG>
-__global__ void __launch_bounds__(256)
+/* end-of-block state of a rate group with a long channel filter: the last len - 1 MIXED frames of every channel exactly as
+ * LowPass::block keeps them (lowpass.cxx:138-142; the reference's arithmetic, downconverter.cxx:100-110) and the phase after
+ * the block, into the other state set.  Element e of `total` = (len - 1) * slots; `first` / `stride`: this thread's share. */
+__device__ __forceinline__ void
+long_roll_body(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes, unsigned int len,
+               unsigned int slots, const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
+               const int *__restrict__ flags, unsigned int *__restrict__ phase_next,
+               const float2 *__restrict__ mixhist, float2 *__restrict__ mixhist_next, const float *__restrict__ table,
+               size_t first, size_t stride)
+{
+	const unsigned int hl = len - 1u;
+	const size_t total = (size_t)hl * slots;
+	for (size_t e = first; e < total; e += stride) {
+		const unsigned int r = (unsigned int)(e / slots), s = (unsigned int)(e - (size_t)r * slots);
+		const bool active = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
+		const long long f = (long long)nframes - (long long)hl + r;         /* frame of this block, or of an earlier one */
+		float2 m = make_float2(0.0f, 0.0f);
+		if (active) {
+			if (f >= 0) {
+				const float2 x = input_frame(cur, cur_u8, (size_t)f);
+				const v2f cs = nco<WR_NCO_EXACT>(phase[s] + (unsigned int)f * step[s], table, nullptr, nullptr);
+				m = make_float2(x.x * cs.x + x.y * cs.y, x.y * cs.x - x.x * cs.y);  /* downconverter.cxx:109-110 */
+			} else {
+				m = mixhist[(size_t)(hl + f) * slots + s];                        /* a block shorter than the history */
+			}
+		}
+		mixhist_next[e] = m;
+		if (r == 0)
+			phase_next[s] = active ? phase[s] + (unsigned int)nframes * step[s] : phase[s];
+	}
+}
+
+/* r04: workgroups of LONG_ROT_WAVES waves, and -- PD2 != 0 -- the post stage of the PREVIOUS block in extra workgroups
+ * [n_ddc, gridDim.x) of the same launch, as k_tuner_ddc carries it (post_role: demodulator + audio filter with audio
+ * decimation PD2; the two share nothing but the kernel boundary before the launch).  LDS is dynamic: the tables, windows and
+ * tap segments of the DDC waves, or the post role's stage and tile, whichever a workgroup is. */
+#define LONG_ROT_WAVES 8u
+#define LONG_ROT_LDS   ((2u * WR_SPLIT_N + LONG_ROT_WAVES * 2u * 64u) * 8u + LONG_ROT_WAVES * 64u * 4u)
+template <unsigned int NG, unsigned int PD2>
+__global__ void __launch_bounds__(LONG_ROT_WAVES * 64u)
 k_tuner_ddc_long_rot(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t k1,
                      unsigned int d1, unsigned int len, unsigned int slots, unsigned int groups,
                      const unsigned int *__restrict__ phase, const unsigned int *__restrict__ step,
                      const int *__restrict__ flags, const float4 *__restrict__ rot, const float *__restrict__ taps,
                      const float2 *__restrict__ hi_cs, const float2 *__restrict__ lo_cs, float2 *__restrict__ chan_iq,
-                     const float2 *__restrict__ mixhist)
+                     const float2 *__restrict__ mixhist, unsigned int n_ddc, WrPostArgs post, unsigned int n_post,
+                     size_t nframes, unsigned int *__restrict__ phase_next, float2 *__restrict__ mixhist_next,
+                     const float *__restrict__ table)
 {
-	__shared__ v2f hi_l[WR_SPLIT_N], lo_l[WR_SPLIT_N];
-	__shared__ v2f winl[4][2][64];
-	__shared__ float hseg[4][64];
+	extern __shared__ float long_rot_lds[];
+	if (blockIdx.x >= n_ddc + n_post) {
+		/* the workgroups behind the post ones: the block's state roll (it reads this state set and writes the other: nothing
+		 * the DDC waves of this launch touch) -- a launch of its own until r04 */
+		const unsigned int w = blockIdx.x - n_ddc - n_post, nw = gridDim.x - n_ddc - n_post;
+		long_roll_body(cur, cur_u8, nframes, len, slots, phase, step, flags, phase_next, mixhist, mixhist_next, table,
+		               (size_t)w * blockDim.x + threadIdx.x, (size_t)nw * blockDim.x);
+		return;
+	}
+	if (PD2 != 0u && blockIdx.x >= n_ddc) {
+		wave_prio(3u);
+		constexpr unsigned int NEED = (POST_TK - 1u) * (PD2 ? PD2 : 1u) + WR_FIR_LENGTH;
+		const unsigned int idx = blockIdx.x - n_ddc;
+		float *stage = long_rot_lds;
+		post_role<(PD2 ? PD2 : 1u), false>(post, idx % (post.ntiles + 1u), idx / (post.ntiles + 1u), stage,
+		                                    stage + NEED * 64u, (int *)(stage + NEED * 64u + POST_TK * 65u));
+		return;
+	}
+	v2f *hi_l = (v2f *)long_rot_lds, *lo_l = hi_l + WR_SPLIT_N;
+	v2f (*winl)[2][64] = (v2f (*)[2][64])(lo_l + WR_SPLIT_N);
+	float (*hseg)[64] = (float (*)[64])(winl + LONG_ROT_WAVES);
 	for (unsigned int e = threadIdx.x; e < WR_SPLIT_N; e += blockDim.x) {
 		const float2 hv = hi_cs[e], lv = lo_cs[e];
 		hi_l[e] = (v2f){hv.x, hv.y};
@@ -1725,7 +1783,7 @@ k_tuner_ddc_long_rot(const float2 *__restrict__ cur, const uchar2 *__restrict__ 
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const unsigned int segs = len / 64u, hl = len - 1u, gsets = groups / NG;
 	const size_t units = k1 * gsets;
-	for (size_t u = (size_t)blockIdx.x * 4u + wave; u < units; u += (size_t)gridDim.x * 4u) {
+	for (size_t u = (size_t)blockIdx.x * LONG_ROT_WAVES + wave; u < units; u += (size_t)n_ddc * LONG_ROT_WAVES) {
 		const unsigned int gs = (unsigned int)(u % gsets);
 		const size_t k = u / gsets;
 		unsigned int s[NG], p0[NG], st[NG], fstep[NG];
@@ -1831,66 +1889,80 @@ k_ddc_long_roll(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u
                 const int *__restrict__ flags, unsigned int *__restrict__ phase_next,
                 const float2 *__restrict__ mixhist, float2 *__restrict__ mixhist_next, const float *__restrict__ table)
 {
-	const unsigned int hl = len - 1u;
-	const size_t total = (size_t)hl * slots;
-	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-		const unsigned int r = (unsigned int)(e / slots), s = (unsigned int)(e - (size_t)r * slots);
-		const bool active = (flags[s] & PHASE_FLAG_ACTIVE) != 0;
-		const long long f = (long long)nframes - (long long)hl + r;         /* frame of this block, or of an earlier one */
-		float2 m = make_float2(0.0f, 0.0f);
-		if (active) {
-			if (f >= 0) {
-				const float2 x = input_frame(cur, cur_u8, (size_t)f);
-				const v2f cs = nco<WR_NCO_EXACT>(phase[s] + (unsigned int)f * step[s], table, nullptr, nullptr);
-				m = make_float2(x.x * cs.x + x.y * cs.y, x.y * cs.x - x.x * cs.y);  /* downconverter.cxx:109-110 */
-			} else {
-				m = mixhist[(size_t)(hl + f) * slots + s];                        /* a block shorter than the history */
-			}
-		}
-		mixhist_next[e] = m;
-		if (r == 0)
-			phase_next[s] = active ? phase[s] + (unsigned int)nframes * step[s] : phase[s];
-	}
+	long_roll_body(cur, cur_u8, nframes, len, slots, phase, step, flags, phase_next, mixhist, mixhist_next, table,
+	               (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGroupDev &G, unsigned int len,
                               const float *table_dev, int num_cus, bool rotate, bool rotate_one_filter, const float *hi_dev,
-                              const float *lo_dev)
+                              const float *lo_dev, const WrPostArgs *post, bool *post_taken)
 {
+	if (post_taken)
+		*post_taken = false;
 	if (!L.slots_used)
 		return hipSuccess;
 	const unsigned int groups = L.slots_used / 64u;
 	/* `rotate` (a tolerance nco mode, one filter per lane group): only the frames whose window reaches into the previous
 	 * block take the reference's arithmetic, the others k_tuner_ddc_long_rot */
 	size_t k_exact = L.k1;
-	bool exact_done = false;
+	bool exact_done = false, rolled = false;
 	if (rotate && L.k1) {
 		const size_t units_r = L.k1 * groups;
-		unsigned int wgs_r = (unsigned int)((units_r + 3) / 4);
-		const unsigned int cap_r = (unsigned int)num_cus * 8u;
-		if (wgs_r > cap_r)
-			wgs_r = cap_r;
 		exact_done = true;
 		k_exact = 0;
 		const bool two = rotate_one_filter && groups % 2u == 0;
 		const hipEvent_t e0 = (L.ev_start && L.ev_stop) ? (hipEvent_t)L.ev_start : nullptr;
 		const hipEvent_t e1 = (L.ev_start && L.ev_stop) ? (hipEvent_t)L.ev_stop : nullptr;
-		if (two) {
-			wgs_r = (unsigned int)((units_r / 2 + 3) / 4);
-			if (wgs_r > cap_r)
-				wgs_r = cap_r;
-			hipExtLaunchKernelGGL(k_tuner_ddc_long_rot<2u>, dim3(wgs_r), dim3(256), 0, st, e0, e1, 0u,
-			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len, L.slots, groups,
-			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
-			                      (const float4 *)G.rot, (const float *)G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
-			                      (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
-		} else {
-			hipExtLaunchKernelGGL(k_tuner_ddc_long_rot<1u>, dim3(wgs_r), dim3(256), 0, st, e0, e1, 0u,
-			                      (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len, L.slots, groups,
-			                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags,
-			                      (const float4 *)G.rot, (const float *)G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev,
-			                      (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp]);
+		/* the previous block's post stage rides in this launch where the kernel is built for its audio decimation */
+		const bool ride = post && post->k1 && post->groups && wrk_tuner_post_supported(post->d2);
+		unsigned int wgs_r = (unsigned int)(((two ? units_r / 2 : units_r) + LONG_ROT_WAVES - 1u) / LONG_ROT_WAVES);
+		/* persistent: 32 waves per CU as before -- or 24 and one workgroup slot per CU left to the post workgroups, which
+		 * come and go beside the DDC ones (as in k_tuner_ddc) instead of queueing up behind them */
+		const unsigned int cap8 = (unsigned int)num_cus * (ride ? 3u : 4u);
+		if (wgs_r > cap8)
+			wgs_r = cap8;
+		const unsigned int d2r = ride ? post->d2 : 0u;
+		const unsigned int post_wgs = ride ? (post->ntiles + 1u) * post->groups : 0u;
+		const WrPostArgs pa = ride ? *post : WrPostArgs();
+		const size_t roll_total = (size_t)(len - 1u) * L.slots;
+		const unsigned int roll_wgs = (unsigned int)((roll_total + LONG_ROT_WAVES * 64u - 1u) / (LONG_ROT_WAVES * 64u) > 256u
+		                                             ? 256u : (roll_total + LONG_ROT_WAVES * 64u - 1u) / (LONG_ROT_WAVES * 64u));
+		rolled = true;
+		size_t lds = LONG_ROT_LDS;
+		if (ride) {
+			const size_t need = ((size_t)((POST_TK - 1u) * d2r + WR_FIR_LENGTH) * 64u + POST_TK * 65u + 64u) * sizeof(float);
+			if (need > lds)
+				lds = need;
+			if (post_taken)
+				*post_taken = true;
 		}
+#define LONG_ROT_LAUNCH(NG_, PD2_) \
+		hipExtLaunchKernelGGL((k_tuner_ddc_long_rot<NG_, PD2_>), dim3(wgs_r + post_wgs + roll_wgs), dim3(LONG_ROT_WAVES * 64u), (uint32_t)lds, st, \
+		                      e0, e1, 0u, (const float2 *)L.cur, (const uchar2 *)L.cur_u8, L.k1, L.d1, len, L.slots, groups, \
+		                      (const unsigned int *)G.phase[L.sp], (const unsigned int *)G.step, (const int *)G.flags, \
+		                      (const float4 *)G.rot, (const float *)G.taps1L, (const float2 *)hi_dev, (const float2 *)lo_dev, \
+		                      (float2 *)G.chan_iq[L.cb], (const float2 *)G.mixhist[L.sp], wgs_r, pa, post_wgs, L.nframes, \
+		                      G.phase[L.sp ^ 1], (float2 *)G.mixhist[L.sp ^ 1], table_dev)
+#define LONG_ROT_BY_D2(NG_) \
+		switch (d2r) { \
+		case 0: LONG_ROT_LAUNCH(NG_, 0u); break; \
+		case 1: LONG_ROT_LAUNCH(NG_, 1u); break; \
+		case 2: LONG_ROT_LAUNCH(NG_, 2u); break; \
+		case 3: LONG_ROT_LAUNCH(NG_, 3u); break; \
+		case 4: LONG_ROT_LAUNCH(NG_, 4u); break; \
+		case 5: LONG_ROT_LAUNCH(NG_, 5u); break; \
+		case 6: LONG_ROT_LAUNCH(NG_, 6u); break; \
+		case 8: LONG_ROT_LAUNCH(NG_, 8u); break; \
+		case 10: LONG_ROT_LAUNCH(NG_, 10u); break; \
+		default: return hipErrorInvalidValue; \
+		}
+		if (two) {
+			LONG_ROT_BY_D2(2u)
+		} else {
+			LONG_ROT_BY_D2(1u)
+		}
+#undef LONG_ROT_BY_D2
+#undef LONG_ROT_LAUNCH
 	}
 	const bool prof_exact = L.ev_start && L.ev_stop && !exact_done;
 	const size_t units = exact_done ? 0 : k_exact * groups;
@@ -1910,6 +1982,8 @@ hipError_t wrk_tuner_ddc_long(hipStream_t st, const WrTunerLaunch &L, const WrGr
 			                                      L.slots, groups, G.phase[L.sp], G.step, G.flags, G.taps1L,
 			                                      (const float2 *)G.mixhist[L.sp], table_dev, (float2 *)G.chan_iq[L.cb]);
 	}
+	if (rolled)
+		return hipGetLastError();                           /* the ROTATE launch rolled the state itself */
 	const size_t total = (size_t)(len - 1u) * L.slots;
 	const unsigned int rwgs = (unsigned int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
 	if (L.ev_start && L.ev_stop && !L.k1) {
