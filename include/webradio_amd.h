@@ -201,6 +201,7 @@ int wr_u8_to_f32_from_host(wr_dev *dev, const uint8_t *in_host_registered, float
  * the SAME positions of the float block at `out_dev`; the frames in between are left as they are.  At BASELINE config 2
  * (length 64, period 400) that is a sixth of the block over PCIe.  The kernel reads the host memory itself, on the device's
  * stream (in order with the tuner's launches behind it); counts as an upload in flight like the call above.
+ * Windows of any length up to 4096 frames (a window longer than a wave takes rounds).
  * A submit that follows must use the same `length` and `period` for ALL its receivers. */
 int wr_stage_windows_from_host(wr_dev *dev, const void *in_host_registered, int is_u8, float *out_dev, size_t nframes,
                                unsigned int period, unsigned int length, size_t tail_frames);

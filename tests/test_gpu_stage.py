@@ -26,7 +26,7 @@ def _needed(nframes, period, length, tail):
 @pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32"])
 @pytest.mark.parametrize("nframes,period,length,tail", [(40_000, 400, 64, 63), (100_000, 4000, 64, 1200), (8_192, 130, 64, 64),
                                                        (20_000, 400, 32, 700), (30_001, 333, 64, 100), (1_000, 2_000, 64, 63),
-                                                       (640, 64, 64, 640)])
+                                                       (640, 64, 64, 640), (60_000, 1_000, 256, 255), (50_000, 900, 128, 300)])
 def test_windows_and_tail_land_where_the_whole_block_puts_them(dev, page_locked, u8, nframes, period, length, tail):
     import torch
     rng = np.random.default_rng(nframes + period)
@@ -62,7 +62,7 @@ def test_argument_checks(dev):
     assert b"page-locked" in lib.wr_last_error()
     assert lib.wr_stage_windows_from_host(None, None, 0, None, 0, 100, 64, 0) == capi.WR_ERR_ARG
     assert lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), 0, capi.ptr(out), 512, 0, 64, 63) == capi.WR_ERR_ARG
-    assert lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), 0, capi.ptr(out), 512, 100, 256, 63) == capi.WR_ERR_ARG
+    assert lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), 0, capi.ptr(out), 512, 100, 5000, 63) == capi.WR_ERR_ARG
 
 
 @pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32"])

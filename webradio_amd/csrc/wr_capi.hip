@@ -799,8 +799,8 @@ extern "C" int wr_stage_windows_from_host(wr_dev *d, const void *in_host, int is
 {
 	if (!d || (nframes && (!in_host || !out_dev)) || !period || !length)
 		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: bad argument");
-	if (length > (is_u8 ? 480u : 120u))
-		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: windows of %u frames are too long for one wave", length);
+	if (length > 4096u)
+		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: windows of %u frames", length);
 	if (((uintptr_t)in_host | (uintptr_t)out_dev) & 15u)
 		return fail(WR_ERR_ARG, "wr_stage_windows_from_host: both buffers must be 16-byte aligned");
 	if (dev_bind(d))

@@ -2267,9 +2267,11 @@ __global__ void __launch_bounds__(256) k_stage_windows(const uint8_t *__restrict
 	const unsigned int lane = threadIdx.x & 63u;
 	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
 	const size_t total_bytes = nframes * FB;
-	const unsigned int w = lane / nc, c = lane - w * nc;
+	const unsigned int ncl = nc > 64u ? 64u : nc;       /* lanes a window gets (a window longer than 64 chunks: in rounds) */
+	const unsigned int w = lane / ncl, c0 = lane - w * ncl;
 	/* windows: wave-iteration i covers windows i * wpw ... */
-	for (size_t k0 = wave * wpw; k0 < k1; k0 += nwaves * wpw) {
+	for (size_t k0 = wave * wpw; k0 < k1; k0 += nwaves * wpw)
+	for (unsigned int c = c0; c < nc; c += ncl) {
 		const size_t k = k0 + w;
 		if (w >= wpw || k >= k1)
 			continue;
@@ -2314,9 +2316,7 @@ hipError_t wrk_stage_windows(hipStream_t st, const void *src_mapped, bool u8, fl
 		return hipSuccess;
 	const unsigned int fb = u8 ? 2u : 8u;
 	const unsigned int nc = (len * fb + 15u + 15u) / 16u;              /* chunks of the aligned span of a window */
-	if (nc > 64u)
-		return hipErrorInvalidValue;
-	const unsigned int wpw = 64u / nc;
+	const unsigned int wpw = nc > 64u ? 1u : 64u / nc;
 	const size_t k1 = nframes / period + ((nframes % period) ? 1u : 0u);  /* (a window that ends in the next block starts in this one) */
 	const size_t tail_first = tail_frames >= nframes ? 0 : nframes - tail_frames;
 	/* PCIe-bound: a few hundred workgroups keep megabytes of reads in flight; see k_u8_to_f32_x16 about parking more */

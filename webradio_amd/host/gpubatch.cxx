@@ -331,7 +331,7 @@ static const float *stagedSparse(const DspBlock *consumer, const vector<sample_t
 		return NULL;
 	const void *from = raw ? (const void *)rawBytes : (const void *)host.data();
 	const size_t bytes = host.size() * sizeof(float);
-	if (((uintptr_t)from & 15u) || (period && length > (raw ? 480u : 120u)))
+	if ((uintptr_t)from & 15u)
 		return NULL;
 	if (!st->pin(dev, from, raw ? host.size() : bytes) || !st->buf.reserve(dev, bytes))
 		return NULL;
