@@ -43,7 +43,7 @@ extern "C" {
                                     blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream, incl.
                                     wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
                                     wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
-                                    4: wr_tune, wr_stage_windows_from_host added.  Nothing of an earlier version changed or removed */
+                                    4: wr_tune, wr_stage_windows_from_host, wr_tuner_last_staging added.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
@@ -287,7 +287,14 @@ int wr_chan_set_state(wr_tuner *tuner, int chan, unsigned int phase, const float
 /* DspSource::run for this tuner (dsp/dspblock.h:134, radio.cxx:56-59): push one
  * block of `nframes` IQ frames through every channel.  where = WR_HOST: iq is host
  * memory, copied to the device first; WR_DEVICE: iq is already in HBM and is read
- * in place (it must stay valid until the stream has passed this call). Async. */
+ * in place (it must stay valid until the stream has passed this call). Async.
+ * r04: a WR_HOST block in PAGE-LOCKED memory (wr_dev_host_register, hipHostMalloc) whose receivers all decimate alike
+ * by at least twice their channel filter's length is staged sparsely -- only the frames under the taps and the block's
+ * tail cross PCIe, read by a kernel on the device's stream (see wr_stage_windows_from_host); like any copy out of
+ * page-locked memory it is asynchronous: the block must stay untouched until wr_dev_wait_uploads / wr_dev_sync.
+ * $WR_HOST_SPARSE=0: the whole block, as before.  wr_tuner_last_staging says how the last WR_HOST block travelled:
+ * 0 none yet, 1 copied whole, 2 staged sparsely. */
+int wr_tuner_last_staging(wr_tuner *tuner, int *how);
 int wr_tuner_submit(wr_tuner *tuner, const float *iq, size_t nframes, int where);
 /* the same for a block in the RTL-SDR byte format (unsigned 8-bit interleaved IQ, what
  * RtlSdrTuner::dataReady receives, io/rtlsdrtuner.cxx:86-117): the (u8 - 128)/128

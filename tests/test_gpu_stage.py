@@ -102,3 +102,38 @@ def test_tuner_fed_from_a_sparsely_staged_block(dev, page_locked, u8):
     dev.lib.wr_dev_wait_uploads(dev.h)
     assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
     assert np.isfinite(got[0]).all() and np.abs(got[0]).max() > 1e-3
+
+
+@pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32"])
+def test_host_submit_out_of_page_locked_memory_is_staged_sparsely(dev, page_locked, u8):
+    """wr_tuner_submit / wr_tuner_submit_u8 with WR_HOST: a block in page-locked memory goes through the sparse staging kernel
+    (D1 = 400, 64 taps), one in pageable memory through the copy -- the same audio bit for bit, block after block."""
+    fs, n = 2_000_000, 80_000
+    ifs = [(-4 + c) * 6250 + 1234 for c in range(8)]
+    iq = synth.fm_stream(3 * n, fs, ifs[::2], fm_base=30.0, beta=2.0)
+    if u8:
+        data = np.clip(np.round(127.5 + 127.0 * iq), 0, 255).astype(np.uint8)
+    else:
+        data = iq
+    locked = page_locked(data.size, data.dtype)
+    locked[:] = data
+    outs = []
+    for src in (data, locked):
+        t = Tuner(dev, fs, 8, n, capi.WR_NCO_ROTATE)
+        chans = [t.add_receiver(f, 128_000, 5_000, capi.WR_FM, 160, 1_000) for f in ifs]
+        rows = []
+        for b in range(3):
+            blk = src[2 * n * b: 2 * n * (b + 1)]
+            if u8:
+                capi.check(dev.lib.wr_tuner_submit_u8(t.h, blk.ctypes.data_as(C.c_void_p), n, capi.WR_HOST))
+            else:
+                capi.check(dev.lib.wr_tuner_submit(t.h, blk.ctypes.data_as(C.c_void_p), n, capi.WR_HOST))
+            dev.sync()
+            how = C.c_int()
+            capi.check(dev.lib.wr_tuner_last_staging(t.h, C.byref(how)))
+            assert how.value == (2 if src is locked else 1)          # sparsely staged / copied whole
+            rows.append(np.stack([t.fetch(ch, capi.WR_STAGE_AUDIO, n) for ch in chans]))
+        t.destroy()
+        outs.append(np.concatenate(rows, axis=1))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.isfinite(outs[1]).all() and np.abs(outs[1]).max() > 1e-3

@@ -167,6 +167,7 @@ struct wr_tuner {
 	std::vector<Chan> chans;
 	std::vector<Group *> groups;
 	float *in_stage;           /* [max_block_frames][2] for WR_HOST submits */
+	int last_staging = 0;      /* how the last WR_HOST block travelled: 0 none yet, 1 copied whole, 2 staged sparsely */
 	float *in_hist[2];         /* [63][2] ping-pong: last 63 IQ frames of the previous block */
 	int in_par;
 	bool submitted;
@@ -814,6 +815,12 @@ extern "C" int wr_stage_windows_from_host(wr_dev *d, const void *in_host, int is
 	}
 	HIP_TRY(wrk_stage_windows(d->stream, mapped, is_u8 != 0, out_dev, nframes, period, length, tail_frames));
 	return upload_mark(d, d->stream);                  /* the host buffer is free again when the kernel has read it */
+}
+
+static bool host_sparse_enabled()
+{
+	static const bool on = !(getenv("WR_HOST_SPARSE") && atoi(getenv("WR_HOST_SPARSE")) == 0);
+	return on;
 }
 
 static bool lazy_seek_enabled()
@@ -1834,10 +1841,42 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 	if (where == WR_HOST) {
 		if (!t->in_stage)
 			HIP_TRY(hipMalloc((void **)&t->in_stage, t->max_block_frames * 2 * sizeof(float)));
-		if (nframes)
+		/* r04: a block in PAGE-LOCKED host memory whose receivers all read it through sparse windows of one shape -- the same
+		 * decimation, the same channel-filter length, a window at most every second filter length -- never crosses PCIe
+		 * whole: the staging kernel brings over the frames under the taps and the tail (wr_stage_windows_from_host says
+		 * which), as floats whatever the source format.  Pageable memory, mixed shapes, dense windows: the copy, as before. */
+		bool sparse = false;
+		if (nframes && host_sparse_enabled() && !(((uintptr_t)iq | (uintptr_t)t->in_stage) & 15u)) {
+			unsigned int sd = 0, sl = 0;
+			bool same = true;
+			for (const Group *g : t->groups) {
+				if (g->active <= 0)
+					continue;
+				if (!sd) {
+					sd = g->d1;
+					sl = g->l1;
+				} else if (g->d1 != sd || g->l1 != sl) {
+					same = false;
+				}
+			}
+			void *mapped = nullptr;
+			if (same && sd && sd >= 2u * sl && nframes >= 4u * (size_t)sd &&
+			    hipHostGetDevicePointer(&mapped, const_cast<void *>(iq), 0) == hipSuccess && mapped) {
+				HIP_TRY(wrk_stage_windows(st, mapped, u8, t->in_stage, nframes, sd, sl, sl - 1u));
+				if (int rc = upload_mark(d, st))            /* (wr_dev_wait_uploads: the kernel has read the host block) */
+					return rc;
+				sparse = true;
+			} else {
+				(void)hipGetLastError();
+			}
+		}
+		if (nframes && !sparse)
 			HIP_TRY(hipMemcpyAsync(t->in_stage, iq, nframes * 2 * (u8 ? sizeof(uint8_t) : sizeof(float)),
 			                       hipMemcpyHostToDevice, st));
 		src = t->in_stage;
+		t->last_staging = sparse ? 2 : 1;
+		if (sparse)
+			u8 = false;                          /* the staged block holds floats */
 	}
 	const float *cur = u8 ? nullptr : (const float *)src;
 	const uint8_t *cur_u8 = u8 ? (const uint8_t *)src : nullptr;
@@ -2046,6 +2085,14 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		c.phaseL += (unsigned int)nframes * c.stepL;
 	}
 	t->submitted = true;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_last_staging(wr_tuner *t, int *how)
+{
+	if (!t || !how)
+		return fail(WR_ERR_ARG, "wr_tuner_last_staging: bad argument");
+	*how = t->last_staging;
 	return WR_OK;
 }
 
