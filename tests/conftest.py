@@ -103,7 +103,8 @@ def dev():
 
 # ---- host memory that tests page-lock (wr_dev_host_register) ---------------------------------------------------------------
 # One anonymous mapping made when this file is imported -- before the process has copied anything to or from the GPU -- and
-# never unmapped: every buffer a test registers is a page-aligned piece of it with a guard page behind, handed out once.
+# never unmapped: every buffer a test registers is a page-aligned piece of it with a guard page behind (a test's pieces
+# go back to the pool when it is over: the pool's pages are never anybody else's).
 # Why: a registered numpy array from the heap shares its first and last page with whatever the allocator puts beside it, and
 # its address is handed out again after the test; the HIP runtime page-locks the destination of every copy into pageable
 # memory on the fly and keeps those locks for a while.  One run in a dozen of the sequence test_gpu_stage -> test_gpu_blocks
@@ -131,7 +132,9 @@ def page_locked(dev):
     device (wr_dev_host_register); unregistered again when the test ends (after the device has gone idle)."""
     import ctypes as C
     import numpy as np
+    global _pool_used
     made = []
+    mark = _pool_used                                                   # (handed back when the test is over: see below)
 
     def make(count, dtype=np.uint8):
         global _pool_used
@@ -150,6 +153,7 @@ def page_locked(dev):
     dev.lib.wr_dev_wait_uploads(dev.h)
     for arr in made:
         dev.lib.wr_dev_host_unregister(dev.h, arr.ctypes.data_as(C.c_void_p))
+    _pool_used = mark              # the pieces go back to the pool: pages that were only ever the pool's, unregistered, idle
 
 
 @pytest.fixture(scope="session")

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _needed(nframes, period, length, tail):
     need = np.zeros(nframes, bool)
-    for k in range(nframes // period + 1):
+    for k in range((nframes - 1) // period + 1):          # the output frames of THIS block: their windows end inside it
         lo, hi = max(0, k * period - (length - 1)), min(nframes - 1, k * period)
         if lo <= hi:
             need[lo:hi + 1] = True
@@ -137,3 +137,36 @@ def test_host_submit_out_of_page_locked_memory_is_staged_sparsely(dev, page_lock
         outs.append(np.concatenate(rows, axis=1))
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     assert np.isfinite(outs[1]).all() and np.abs(outs[1]).max() > 1e-3
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("WR_FUZZ_SEEDS", "16"))))
+def test_random_window_shapes(dev, page_locked, seed):
+    """Seeded fuzz of the staging kernel: random block lengths (ragged against the period), periods, window lengths (longer
+    than a wave's 64 chunks too), tails (longer than the block too) and both source formats -- every frame the taps reach
+    and the tail are there bit for bit, nothing staged is wrong."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    u8 = bool(rng.integers(0, 2))
+    length = int(rng.choice([2, 16, 63, 64, 65, 128, 256, 500, 1024]))
+    period = int(rng.integers(1, 6)) * length + int(rng.integers(0, 700))
+    nframes = int(rng.integers(1, 40)) * period + int(rng.integers(0, period)) + 8
+    tail = int(rng.choice([0, 1, length - 1, length + 17, nframes, nframes + 5]))
+    if u8:
+        host = page_locked(2 * nframes, np.uint8)
+        host[:] = rng.integers(0, 256, 2 * nframes, dtype=np.uint8)
+        want = ((host.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)).astype(np.float32)
+    else:
+        host = page_locked(2 * nframes, np.float32)
+        host[:] = rng.standard_normal(2 * nframes).astype(np.float32)
+        want = host
+    out = torch.full((2 * nframes,), float("nan"), device="cuda")
+    assert dev.lib.wr_stage_windows_from_host(dev.h, host.ctypes.data_as(C.c_void_p), int(u8), capi.ptr(out), nframes, period,
+                                              length, tail) == 0, dev.lib.wr_last_error()
+    assert dev.lib.wr_dev_wait_uploads(dev.h) == 0
+    got = out.cpu().numpy().reshape(-1, 2)
+    need = _needed(nframes, period, length, min(tail, nframes))
+    w = want.reshape(-1, 2)
+    what = (u8, nframes, period, length, tail)
+    assert np.array_equal(got[need].view(np.uint32), w[need].view(np.uint32)), what
+    staged = ~np.isnan(got[:, 0])
+    assert np.array_equal(got[staged].view(np.uint32), w[staged].view(np.uint32)), what

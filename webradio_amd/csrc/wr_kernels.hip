@@ -2318,6 +2318,10 @@ hipError_t wrk_stage_windows(hipStream_t st, const void *src_mapped, bool u8, fl
 	const unsigned int nc = (len * fb + 15u + 15u) / 16u;              /* chunks of the aligned span of a window */
 	const unsigned int wpw = nc > 64u ? 1u : 64u / nc;
 	const size_t k1 = nframes / period + ((nframes % period) ? 1u : 0u);  /* (a window that ends in the next block starts in this one) */
+	/* (the window pass moves whole 16-byte chunks and leaves a block's last, partial one to the tail pass: the tail is at
+	 * least those 8 frames, whatever the caller asked for) */
+	if (tail_frames < 8)
+		tail_frames = 8;
 	const size_t tail_first = tail_frames >= nframes ? 0 : nframes - tail_frames;
 	/* PCIe-bound: a few hundred workgroups keep megabytes of reads in flight; see k_u8_to_f32_x16 about parking more */
 	const size_t waves = (k1 + wpw - 1) / wpw;
