@@ -170,3 +170,35 @@ def test_waterfall_row_for_the_ui(dev, oracle):
     db, pal = z.waterfall_row(512)
     assert (db == -10000.0).all() and (pal == 0).all()
     z.destroy()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("WR_FUZZ_SEEDS", "10"))))
+def test_random_device_pushes_with_only_the_tail_staged(dev, oracle, seed):
+    """Seeded fuzz of wr_spectrum_push(WR_DEVICE): random frame sizes, hops and push lengths (shorter than a frame, ragged,
+    many frames long); of every push of fftSize + hop frames or more only the last fftSize + hop frames are real, the rest
+    NaN -- what the host runtime's stagedTail hands the SpectrumSink.  Frame count and the most recent frame against the
+    oracle fed the whole stream, push after push."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([64, 256, 1024, 4096]))
+    h = int(rng.choice([n, n // 2, n // 4, 3 * n // 4]))
+    sizes = [int(rng.choice([1, n // 3 + 1, n - 1, n, n + h - 1, n + h, 2 * n + 5, 7 * h + 3, 12 * n + int(rng.integers(0, n))]))
+             for _ in range(8)]
+    iq = synth.fm_stream(sum(sizes), 2_400_000, [250_000, -400_000], amp=0.3, seed=seed)
+    s = Spectrum(dev, n, h)
+    pos = 0
+    for sz in sizes:
+        part = np.array(iq[2 * pos: 2 * (pos + sz)])
+        if sz >= n + h:
+            part[: 2 * (sz - (n + h))] = np.nan
+        p = dev.upload(part)
+        s.push_device(p, sz)
+        dev.sync()
+        dev.free(p)
+        pos += sz
+        nfr = (pos - n) // h + 1 if pos >= n else 0
+        assert s.frames_done() == nfr, (n, h, sizes)
+        if nfr:
+            o = oracle.Spectrum(n)
+            o.process(iq[2 * (nfr - 1) * h: 2 * ((nfr - 1) * h + n)])
+            _check(s.get_db(), s.get_bins(), o.get(), o.bins())
+    s.destroy()
