@@ -170,3 +170,55 @@ def test_random_window_shapes(dev, page_locked, seed):
     assert np.array_equal(got[need].view(np.uint32), w[need].view(np.uint32)), what
     staged = ~np.isnan(got[:, 0])
     assert np.array_equal(got[staged].view(np.uint32), w[staged].view(np.uint32)), what
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("WR_FUZZ_SEEDS", "8"))))
+def test_random_host_submits_sparse_against_copied(dev, page_locked, seed):
+    """Seeded fuzz of the C ABI's own sparse staging: random rates (sparse and dense windows), channel-filter lengths (64, 128),
+    receiver counts, ragged block lengths and both source formats; every block submitted once from pageable memory (copied
+    whole) and once from page-locked memory (staged sparsely where the windows allow) -- the same audio bit for bit, and
+    wr_tuner_last_staging says which way each block went."""
+    rng = np.random.default_rng(9000 + seed)
+    u8 = bool(rng.integers(0, 2))
+    fs = 2_000_000
+    d1 = int(rng.choice([8, 100, 127, 200, 400, 1000]))
+    l1 = int(rng.choice([64, 64, 128]))
+    d2 = int(rng.choice([4, 5]))
+    nrx = int(rng.choice([1, 7, 64, 70]))
+    ifs = [int(rng.integers(-900_000, 900_000)) for _ in range(nrx)]
+    crate = fs // d1
+    if fs % d1 or crate % d2:
+        pytest.skip("rates not integer related for this draw")
+    blocks = [int(rng.integers(3, 12)) * d1 * d2 + int(rng.choice([0, 0, 1, d1 - 1, d1 * d2 - 1])) for _ in range(3)]
+    nmax = max(blocks)
+    iq = synth.fm_stream(sum(blocks), fs, ifs[:2], fm_base=30.0, beta=2.0, seed=seed)
+    data = np.clip(np.round(127.5 + 127.0 * iq), 0, 255).astype(np.uint8) if u8 else iq
+    locked = page_locked(data.size, data.dtype)
+    locked[:] = data
+    cpb = max(oracle_passband(fs), 64_000)
+    outs, ways = [], []
+    for src in (data, locked):
+        t = Tuner(dev, fs, nrx, nmax, capi.WR_NCO_ROTATE)
+        chans = [t.add_receiver(f, cpb, crate, capi.WR_FM, max(crate // 32, 1), crate // d2, fir_lengths=(l1, 64)) for f in ifs]
+        rows, pos, way, expect = [], 0, [], []
+        for n in blocks:
+            blk = src[2 * pos: 2 * (pos + n)]
+            # sparsely: page-locked, a window at most every second filter length, a few of them in the block, 16-byte aligned
+            expect.append(2 if (src is locked and d1 >= 2 * l1 and n >= 4 * d1 and blk.ctypes.data % 16 == 0) else 1)
+            fn = dev.lib.wr_tuner_submit_u8 if u8 else dev.lib.wr_tuner_submit
+            capi.check(fn(t.h, blk.ctypes.data_as(C.c_void_p), n, capi.WR_HOST))
+            dev.sync()
+            how = C.c_int()
+            capi.check(dev.lib.wr_tuner_last_staging(t.h, C.byref(how)))
+            way.append(how.value)
+            rows.append(np.stack([t.fetch(ch, capi.WR_STAGE_AUDIO, n) for ch in chans]))
+            pos += n
+        t.destroy()
+        outs.append(np.concatenate(rows, axis=1))
+        ways.append(way)
+        assert way == expect, (way, expect, d1, l1, blocks)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (u8, d1, l1, d2, nrx, blocks, ways)
+
+
+def oracle_passband(fs):
+    return fs // 16
