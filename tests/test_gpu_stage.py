@@ -181,7 +181,7 @@ def test_random_host_submits_sparse_against_copied(dev, page_locked, seed):
     rng = np.random.default_rng(9000 + seed)
     u8 = bool(rng.integers(0, 2))
     fs = 2_000_000
-    d1 = int(rng.choice([8, 100, 127, 200, 400, 1000]))
+    d1 = int(rng.choice([8, 100, 125, 200, 400, 1000]))
     l1 = int(rng.choice([64, 64, 128]))
     d2 = int(rng.choice([4, 5]))
     nrx = int(rng.choice([1, 7, 64, 70]))
