@@ -7,7 +7,7 @@ seeds=${1:-300}
 mkdir -p gpurun_out
 out=gpurun_out/r04_fuzz_long.txt
 {
-echo "WR_FUZZ_SEEDS=$seeds python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_f4.py -q -p no:cacheprovider   ($(date -u +%FT%TZ), head $(cat .gate_head 2>/dev/null))"
-WR_FUZZ_SEEDS=$seeds timeout 2200 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_f4.py -q -p no:cacheprovider -rA 2>&1 | grep -E "^(PASSED|FAILED|ERROR)|passed|failed" | sed -E 's/\[.*//' | sort | uniq -c
+echo "WR_FUZZ_SEEDS=$seeds python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_f4.py tests/test_gpu_stage.py tests/test_gpu_spectrum.py -q -p no:cacheprovider   ($(date -u +%FT%TZ), head $(cat .gate_head 2>/dev/null))"
+WR_FUZZ_SEEDS=$seeds timeout 2200 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_f4.py tests/test_gpu_stage.py tests/test_gpu_spectrum.py -q -p no:cacheprovider -rA 2>&1 | grep -E "^(PASSED|FAILED|ERROR)|passed|failed" | sed -E 's/\[.*//' | sort | uniq -c
 } > $out 2>&1
 tail -5 $out
