@@ -55,10 +55,15 @@ def parse():
     ap.add_argument("--resident-blocks", type=int, default=12,
                     help="consecutive blocks of the stream kept in HBM and cycled through (12 x 32 MB is "
                          "more than the 256 MB Infinity Cache holds, so every step reads its block from HBM)")
-    ap.add_argument("--blocks-per-launch", type=int, default=4,
-                    help="wr_tuner_set_blocks_per_launch: consecutive resident blocks the tuner holds and launches "
-                         "as one (a step stays one 40 ms block; audio is delivered per launch).  1 = every block "
-                         "its own launch, also measured and reported as secondary.c2_one_block_per_launch")
+    ap.add_argument("--no-stream", dest="stream", action="store_false",
+                    help="headline without wr_tuner_set_streaming: a kernel launch per step (or per --blocks-per-launch steps).  "
+                         "Default: the streaming launch -- the tuner's blocks go to ONE persistent launch through a doorbell, a "
+                         "block's audio is complete ~15 us after its last channel-rate frame whether or not another block follows "
+                         "(dspblock.cxx:169-212), same bits (tests/test_gpu_stream.py); the launch-per-block figures are "
+                         "reported as secondary.c2_one_launch_per_block / c2_four_blocks_per_launch")
+    ap.add_argument("--blocks-per-launch", type=int, default=1,
+                    help="only with --no-stream: wr_tuner_set_blocks_per_launch, consecutive resident blocks the tuner holds and "
+                         "launches as one (a step stays one 40 ms block; audio is delivered per launch, up to n - 1 blocks late)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="after the W warm-up steps, keep stepping (untimed) for this long before the timed region: an "
                          "MI355X that was idle starts a kernel stream at a reduced clock and takes ~50 ms of continuous "
@@ -626,22 +631,30 @@ def main():
     n = cfg["block_frames"]
     ifs = synth.c2_ifs(args.channels)
     # one independent tuner per GPU: its own stream of FM carriers, seed 12345 + tuner index
-    B = max(1, args.blocks_per_launch)
+    streaming = bool(args.stream) and args.nco == "rotate"
+    B = 1 if streaming else max(1, args.blocks_per_launch)
+    BMAX = max(B, 4)                            # (the secondary four-blocks-per-launch run needs the room)
     nb = max(1, args.resident_blocks)
-    nb = (nb + B - 1) // B * B                  # whole launches before the resident stream wraps
+    nb = (nb + BMAX - 1) // BMAX * BMAX         # whole launches before the resident stream wraps
     stream_iq = synth.fm_stream_torch(n * nb, cfg["input_rate"], ifs[::4], "cuda", seed=12345 + rank)
     blocks = [stream_iq[2 * n * b: 2 * n * (b + 1)] for b in range(nb)]
     stream = torch.cuda.current_stream().cuda_stream
     dev = Device(device_index, stream)
     nco = {"rotate": capi.WR_NCO_ROTATE, "split": capi.WR_NCO_SPLIT, "exact": capi.WR_NCO_EXACT}[args.nco]
-    tuner = Tuner(dev, cfg["input_rate"], args.channels, n * B, nco)
+    tuner = Tuner(dev, cfg["input_rate"], args.channels, n * BMAX, nco)
     for f in ifs:
         tuner.add_receiver(f, cfg["chan_passband"], cfg["chan_rate"], capi.WR_FM, cfg["audio_passband"],
                            cfg["audio_rate"])
     tuner.blocks_per_launch(B)
+    tuner.streaming(streaming)
+
+    def gpu_sync():
+        # an open streaming launch ends when it is told to (wr_tuner_flush), not by itself: close it before waiting
+        tuner.flush()
+        torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        gpu_sync()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -653,15 +666,17 @@ def main():
     # untimed: the same steps until the clocks have settled (see --settle-ms)
     settle_steps = 0
     if args.settle_ms > 0:
-        torch.cuda.synchronize()
+        gpu_sync()
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             for _ in range(100):
                 tuner.submit_device(blocks[step % nb], n)
                 step += 1
             settle_steps += 100
-            torch.cuda.synchronize()
-    def launches_of(steps):
+            gpu_sync()
+    def launches_of(steps, B=B, streaming=streaming):
+        if streaming:
+            return (steps + 4095) // 4096          # WR_STREAM_MAXJ blocks per streaming launch
         # the launches `steps` consecutive steps from the start of the resident stream make: a launch
         # closes when it holds B blocks or the next block does not follow on in memory (the wrap)
         count, held = 0, 0
@@ -705,20 +720,35 @@ def main():
     a = tuner.fetch(0, capi.WR_STAGE_AUDIO, n * B)
     assert a.size and a.size % (n // 400 // 5) == 0 and bool((a == a).all()) and float(abs(a).max()) > 0.0
 
-    # the same steps with every block a launch of its own (what a caller that wants each block's audio
-    # before submitting the next gets), outside the headline's timed region
-    one = None
-    if B > 1 and world == 1 and not args.no_secondary:
-        tuner.blocks_per_launch(1)
-        k1 = min(args.steps, 96)
-        for i in range(600):                     # ~25 ms of this launch shape before its timed steps
+    # the same job the other ways the library can run it, outside the headline's timed region: a kernel launch per block
+    # (r01-r04's like-for-like figure) and four held blocks per launch (r02-r04's headline: up to 120 ms of added audio latency)
+    def other_mode(stream_on, bpl, steps):
+        tuner.flush()
+        tuner.streaming(stream_on)
+        tuner.blocks_per_launch(bpl)
+        for i in range(600 // bpl * bpl):        # ~25 ms of this launch shape before its timed steps
             tuner.submit_device(blocks[i % nb], n)
-        dt1, got1, ms1 = timed_steps(k1, max(1, min(args.profile_stride, k1)))
-        one = {"blocks_per_launch": 1, "steps": k1, "ms_per_step": round(dt1 / k1 * 1e3, 5),
-               "value": round(float(n) * k1 / dt1 / 1e6, 2), "unit": "complex Msamples/s",
-               "kernel_ms": round(ms1, 5), "launches_timed": got1,
-               "roofline_frac": round((n * ALGO_BYTES_PER_SAMPLE / 1e9) / (ms1 / 1e3) / HBM_PEAK_GBPS, 5) if ms1 > 0 else None}
+        nl_ = launches_of(steps, bpl, stream_on)
+        dt1, got1, ms1 = timed_steps(steps, max(1, min(args.profile_stride, nl_)))
+        per = float(n) * steps / max(1, nl_)       # frames per launch
+        r = {"streaming": stream_on, "blocks_per_launch": bpl, "steps": steps, "ms_per_step": round(dt1 / steps * 1e3, 5),
+             "value": round(float(n) * steps / dt1 / 1e6, 2), "unit": "complex Msamples/s",
+             "kernel_ms": round(ms1, 5), "launches_timed": got1,
+             "roofline_frac": round((per * ALGO_BYTES_PER_SAMPLE / 1e9) / (ms1 / 1e3) / HBM_PEAK_GBPS, 5) if ms1 > 0 else None}
+        tuner.flush()
+        tuner.streaming(streaming)
         tuner.blocks_per_launch(B)
+        return r
+
+    one = four = streamed = None
+    if world == 1 and not args.no_secondary:
+        k1 = min(args.steps, 96) // 4 * 4 or 4
+        if streaming or B > 1:
+            one = other_mode(False, 1, k1)
+        if streaming or B != 4:
+            four = other_mode(False, 4, k1)
+        if not streaming and args.nco == "rotate":
+            streamed = other_mode(True, 1, k1)
 
     # BASELINE config 3 off the same resident stream, outside the timed region of the headline
     c3 = c1 = None
@@ -769,12 +799,18 @@ def main():
                 "channels": args.channels,
                 "block_frames": n,
                 "resident_blocks": nb,
+                "streaming": streaming,
+                "streaming_note": "wr_tuner_set_streaming(1): the K timed steps are K rings of the doorbell of ONE persistent "
+                                  "launch opened by the first of them and closed by wr_tuner_flush inside the timed region "
+                                  "(its ramp and tail are in `value`); every block's demod + audio filter run as soon as its "
+                                  "last channel-rate frame is out -- no added latency, same bits as a launch per block "
+                                  "(tests/test_gpu_stream.py)" if streaming else None,
                 "blocks_per_launch": B,
-                "blocks_per_launch_note": "wr_tuner_set_blocks_per_launch(%d): the tuner holds consecutive blocks and "
+                "blocks_per_launch_note": None if B == 1 else
+                                          "wr_tuner_set_blocks_per_launch(%d): the tuner holds consecutive blocks and "
                                           "launches them as one (bit-identical audio, tests/test_gpu_ring.py); a block's "
                                           "audio is available when its launch has run, up to %d blocks (%d ms of signal) "
-                                          "later than with one launch per block -- secondary.c2_one_block_per_launch "
-                                          "is the same job without it" % (B, B - 1, (B - 1) * 40),
+                                          "later than with one launch per block" % (B, B - 1, (B - 1) * 40),
                 "nco": args.nco,
                 "tuners_per_gpu": 1,
                 "parallelism": "one tuner per GPU, no collective",
@@ -786,7 +822,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_tuner_ddc (NCO mix + 64-tap decimating channel FIR, all channels; the previous block's demod + audio filter ride along in extra workgroups of the same launch)",
+                "kernel": ("k_tuner_stream (ONE persistent launch for the K steps: NCO mix + 64-tap decimating channel FIR of all channels "
+                           "in 2/3 of the resident workgroups, every block's demod + audio filter in the other third)") if streaming else
+                          "k_tuner_ddc (NCO mix + 64-tap decimating channel FIR, all channels; the previous block's demod + audio filter ride along in extra workgroups of the same launch)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -821,13 +859,16 @@ def main():
             },
         }
         if one is not None:
-            # the same job with every 40 ms block a launch of its own (no added audio latency): the like-for-like
-            # successor of the r01 figure
+            # the same job with every 40 ms block a kernel launch of its own: the like-for-like successor of the r01 figure
             out["value_one_block_per_launch"] = one["value"]
-        if world == 1 and (c3 is not None or one is not None):
+        if world == 1 and (c3 is not None or one is not None or four is not None or streamed is not None):
             out["secondary"] = {}
             if one is not None:
                 out["secondary"]["c2_one_block_per_launch"] = one
+            if four is not None:
+                out["secondary"]["c2_four_blocks_per_launch"] = four
+            if streamed is not None:
+                out["secondary"]["c2_streaming"] = streamed
             if c3 is not None:
                 out["secondary"]["c3"] = c3
             if c1 is not None:

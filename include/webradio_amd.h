@@ -39,11 +39,12 @@
 extern "C" {
 #endif
 
-#define WR_ABI_VERSION   4       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
+#define WR_ABI_VERSION   5       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
                                     blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream, incl.
                                     wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
                                     wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
-                                    4: wr_tune, wr_stage_windows_from_host, wr_tuner_last_staging added.  Nothing of an earlier version changed or removed */
+                                    4: wr_tune, wr_stage_windows_from_host, wr_tuner_last_staging added.
+                                    5: wr_tuner_set_streaming, wr_tuner_stream_info added.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
@@ -421,6 +422,29 @@ int wr_tuner_set_audio_scale(wr_tuner *tuner, float scale);
  * launch (start-up, the waves that finish early) are paid once per group: 32.8 -> 30.0 us per block
  * at BASELINE config 2 with nblocks = 4.  1 (the default) = off. */
 int wr_tuner_set_blocks_per_launch(wr_tuner *tuner, unsigned int nblocks);
+
+/* r05 -- the streaming launch.  The reference hands a block's output on within the run() that brought the block
+ * (dsp/dspblock.cxx:169-212) and its tuner thread swaps the next block in whenever it has one
+ * (io/rtlsdrtuner.cxx:265-285).  With `enable` != 0 the WR_DEVICE blocks of a tuner stop costing a kernel launch each:
+ * the first opens ONE persistent launch, every following block of the same size and format rings its doorbell (a
+ * descriptor and a counter in page-locked host memory -- wr_tuner_submit then returns after two stores), and the
+ * launch takes the block up where it stands.  A block's demodulator and audio filter start the moment its last
+ * channel-rate frame is out, whether or not another block follows, and its audio ring entry (wr_tuner_audio_ring)
+ * becomes ready then -- no wr_tuner_flush needed, the launch stays open.  Everything else that touches the tuner (a
+ * setter, a getter, wr_tuner_flush, a block of another size or out of host memory, a wait for the device's stream
+ * through this library) closes the launch first: it finishes the blocks it was given and ends.  The results are the same
+ * bits as with one launch per block.
+ *   Taken up by: WR_NCO_ROTATE tuners with one rate group, at most 1024 channels on ONE 64-tap channel filter, no
+ * second channel stage, an audio decimation of 1..6, 8 or 10, blocks of whole audio frames, no kept demodulator rows
+ * (wr_tuner_keep_stages), no launch marks.  Any other submit goes the ordinary way, silently: wr_tuner_stream_info
+ * tells which happened.
+ *   Rules for the caller: a block's memory stays untouched until the NEXT block's audio is complete (or the launch is
+ * closed and the stream waited for); before waiting for the device's stream by other means than this library
+ * (hipStreamSynchronize on a stream handed to wr_dev_open, torch.cuda.synchronize()) call wr_tuner_flush -- an open
+ * launch that nobody rings ends by itself only after half a second. */
+int wr_tuner_set_streaming(wr_tuner *tuner, int enable);
+/* `live`: a streaming launch is open right now; `launches`, `blocks`: opened / taken so far (any may be NULL) */
+int wr_tuner_stream_info(wr_tuner *tuner, int *live, unsigned long long *launches, unsigned long long *blocks);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
  * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75), with HIP events on the tuner's stream.

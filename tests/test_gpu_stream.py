@@ -1,0 +1,257 @@
+"""-m gpu: the streaming launch (include/webradio_amd.h wr_tuner_set_streaming; csrc/wr_stream_kernel.inc).
+
+One persistent launch takes a tuner's device blocks through a doorbell instead of a kernel launch per block.  What
+the reference fixes is the semantics -- a block's output leaves within its own run() (dsp/dspblock.cxx:169-212), the
+state a block leaves behind is the next block's (downconverter.cxx:103, lowpass.cxx:138-142,
+demodulator.cxx:110-113) -- so the tests hold the streamed path to the SAME BITS as one launch per block, which
+tests/test_gpu_tuner.py holds to the oracle and the live reference: every block's audio, the channel IQ of the last
+block, the per-channel state behind the stream, and whatever follows the stream."""
+import time
+
+import numpy as np
+import pytest
+
+from webradio_amd import capi, synth
+from webradio_amd.device import Tuner
+
+pytestmark = pytest.mark.gpu
+
+FS, N = 2_000_000, 40_000                     # D1 = 400, D2 = 5: BASELINE config 2's decimations in miniature
+
+
+def _ifs(nch):
+    return [(-(nch // 2) + c) * 6250 + 99 for c in range(nch)]
+
+
+def _tuner(dev, nch, modes=(capi.WR_FM, capi.WR_USB, capi.WR_AM, capi.WR_LSB), max_frames=N):
+    t = Tuner(dev, FS, nch, max_frames, capi.WR_NCO_ROTATE)
+    chans = [t.add_receiver(f, 128_000, 5_000, modes[c % len(modes)], 160, 1_000) for c, f in enumerate(_ifs(nch))]
+    return t, chans
+
+
+def _stream_dev(nblk, nch, n=N, seed=0):
+    import torch
+    iq = synth.fm_stream(nblk * n, FS, _ifs(nch)[::5], amp=0.1, fm_base=30.0, beta=2.0)
+    x = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    return x
+
+
+def _drain(t, count):
+    out = []
+    for b in range(count):
+        audio, seq = t.ring_acquire()
+        out.append((seq, audio.copy()))
+        t.ring_release()
+    return out
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("nch", [8, 70, 200])
+def test_streamed_blocks_give_the_same_bits(dev, nch):
+    """nblk consecutive blocks through one launch per block and through ONE streaming launch: the audio of every
+    block (by the ring), the last block's channel IQ, every channel's state behind the stream, and two further
+    blocks submitted the ordinary way after a retune."""
+    nblk = 7
+    x = _stream_dev(nblk + 2, nch)
+
+    def run(stream):
+        t, chans = _tuner(dev, nch)
+        t.audio_ring(nblk + 2)
+        t.streaming(stream)
+        for b in range(nblk):
+            t.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        if stream:
+            live, launches, blocks = t.stream_info()
+            assert live and launches == 1 and blocks == nblk
+        t.flush()
+        assert t.stream_info()[0] is False
+        got = _drain(t, nblk)
+        iq = np.stack([t.fetch(c, capi.WR_STAGE_CHAN_IQ, 2 * N) for c in chans[::3]])
+        state = [t.state(c) for c in chans]
+        t.streaming(False)
+        t.set_if(chans[1], _ifs(nch)[1] + 777)
+        for b in range(nblk, nblk + 2):
+            t.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        t.flush()
+        got += _drain(t, 2)
+        t.destroy()
+        return got, iq, state
+
+    one, iq1, st1 = run(False)
+    many, iq2, st2 = run(True)
+    assert [s for s, _ in one] == [s for s, _ in many] == list(range(nblk + 2))
+    for (_, a), (_, b) in zip(one, many):
+        assert a.shape == b.shape
+        assert np.array_equal(_bits(a[:nch]), _bits(b[:nch]))
+    assert float(np.abs(one[-1][1]).max()) > 0.0
+    assert np.array_equal(_bits(iq1), _bits(iq2))
+    for (p1, v1), (p2, v2) in zip(st1, st2):
+        assert p1 == p2 and np.array_equal(_bits(np.asarray(v1, np.float32)), _bits(np.asarray(v2, np.float32)))
+
+
+def test_whatever_touches_the_tuner_closes_the_launch(dev):
+    """A retune between two blocks, a fetch in the middle, a block of another size, a block out of host memory: each
+    closes the launch at ITS block boundary and the next eligible block opens another.  Same bits as the ordinary
+    path, call for call."""
+    nch, nblk = 70, 12
+    x = _stream_dev(nblk, nch)
+    host = x.cpu().numpy()
+
+    def run(stream):
+        t, chans = _tuner(dev, nch, modes=(capi.WR_USB, capi.WR_FM), max_frames=N)
+        t.streaming(stream)
+        out = []
+        pos = 0
+
+        def sub(frames, from_host=False):
+            nonlocal pos
+            if from_host:
+                t.submit_host(host[2 * pos: 2 * (pos + frames)])
+            else:
+                t.submit_device(x[2 * pos: 2 * (pos + frames)], frames)
+            pos += frames
+
+        sub(N); sub(N); sub(N)
+        t.set_if(chans[3], _ifs(nch)[3] + 1234)                 # staged: applies from the fourth block on
+        sub(N); sub(N)
+        out.append(t.fetch_audio_all().copy())                    # audio of the fifth block
+        sub(N // 2); out.append(t.fetch_audio_all().copy())       # another size (50 channel-rate frames: fewer than a streaming
+                                                                  # launch takes): the ordinary path
+        sub(N // 2); sub(N // 2)
+        out.append(t.fetch_audio_all().copy())
+        sub(N, from_host=True)
+        out.append(t.fetch_audio_all().copy())
+        sub(N); sub(N)
+        t.set_mode(chans[0], capi.WR_AM)
+        sub(N)
+        out.append(t.fetch_audio_all().copy())
+        info = t.stream_info()
+        t.destroy()
+        return out, info
+
+    a, _ = run(False)
+    b, info = run(True)
+    assert info[1] >= 4 and info[2] >= 8                          # launches opened, blocks they took
+    for u, v in zip(a, b):
+        assert u.shape == v.shape and np.array_equal(_bits(u), _bits(v))
+
+
+def test_a_blocks_audio_arrives_without_a_flush(dev):
+    """dspblock.cxx:169-212: a block's output leaves within its own run().  The ring entry of a streamed block
+    becomes ready when the launch's post stage has finished THAT block -- nothing has to follow it, nobody has to
+    flush -- and the launch stays open for the next block."""
+    nch, nblk = 70, 4
+    x = _stream_dev(nblk, nch)
+    want = []
+    t, _ = _tuner(dev, nch)
+    for b in range(nblk):
+        t.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        want.append(t.fetch_audio_all().copy())
+    t.destroy()
+    t, _ = _tuner(dev, nch)
+    t.audio_ring(2)
+    t.streaming(True)
+    for b in range(nblk):
+        t.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        audio, seq = t.ring_acquire()                             # waits for the block's audio, not for the stream
+        assert seq == b and np.array_equal(_bits(audio), _bits(want[b]))
+        t.ring_release()
+        assert t.stream_info() == (True, 1, b + 1)               # still the same launch
+    t.destroy()                                                   # closes it
+
+
+def test_an_idle_launch_ends_by_itself_and_the_host_knows(dev):
+    """Nobody rings, nobody closes: after WR_STREAM_IDLE_MS the launch ends on its own (a caller that waits for
+    the stream behind the library's back waits that long, not forever), and the next block -- the host does not ring
+    a launch it has left alone for a tenth of that time -- opens a new one.  Same bits."""
+    import torch
+    nch, nblk = 8, 3
+    x = _stream_dev(nblk, nch)
+    want = []
+    t, _ = _tuner(dev, nch)
+    for b in range(nblk):
+        t.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        want.append(t.fetch_audio_all().copy())
+    t.destroy()
+    t, _ = _tuner(dev, nch)
+    t.audio_ring(nblk)
+    t.streaming(True)
+    t.submit_device(x[0: 2 * N], N)
+    t0 = time.time()
+    torch.cuda.synchronize()                                      # behind the library's back
+    waited = time.time() - t0
+    assert 0.2 < waited < 5.0, waited
+    t.submit_device(x[2 * N: 4 * N], N)                           # stale: a new launch
+    assert t.stream_info()[1] == 2
+    time.sleep(0.25)                                              # stale again, the launch still open
+    t.submit_device(x[4 * N: 6 * N], N)
+    assert t.stream_info()[1] == 3
+    t.flush()
+    for b, (seq, audio) in enumerate(_drain(t, nblk)):
+        assert seq == b and np.array_equal(_bits(audio), _bits(want[b]))
+    t.destroy()
+
+
+def test_u8_blocks_stream_too(dev):
+    """the RTL-SDR byte format (io/rtlsdrtuner.cxx:106) converted in the launch's load stage, as k_tuner_ddc does"""
+    import torch
+    nch, nblk = 70, 5
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 256, size=2 * N * nblk, dtype=np.uint8)
+    x = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+
+    def run(stream):
+        t, _ = _tuner(dev, nch)
+        t.audio_ring(nblk)
+        t.streaming(stream)
+        for b in range(nblk):
+            t.submit_u8_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        t.flush()
+        got = _drain(t, nblk)
+        t.destroy()
+        return got
+
+    for (s1, a), (s2, b) in zip(run(False), run(True)):
+        assert s1 == s2 and np.array_equal(_bits(a), _bits(b))
+
+
+def test_streaming_at_c2_size(dev):
+    """bench.py's configuration: 256 receivers, 4 M-frame blocks off 100 Msps.  Ten resident blocks through a tuner
+    that launches each on its own and through ONE streaming launch: every audio sample of every receiver is the
+    same bits, and so is what a further block gives after the stream."""
+    import torch
+    c2 = synth.C2
+    fs, n = c2["input_rate"], c2["block_frames"]
+    ifs = synth.c2_ifs()
+    nblk = 10
+    x = synth.fm_stream_torch(n * nblk, fs, ifs[::4], "cuda")
+    torch.cuda.synchronize()
+
+    def run(stream):
+        t = Tuner(dev, fs, 256, n, capi.WR_NCO_ROTATE)
+        for f in ifs:
+            t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
+        t.audio_ring(nblk)
+        t.streaming(stream)
+        for b in range(nblk - 1):
+            t.submit_device(x[2 * n * b: 2 * n * (b + 1)], n)
+        t.flush()
+        out = [a for _, a in _drain(t, nblk - 1)]
+        t.streaming(False)
+        t.submit_device(x[2 * n * (nblk - 1): 2 * n * nblk], n)
+        out.append(t.fetch_audio_all().copy())
+        info = t.stream_info()
+        t.destroy()
+        return np.concatenate(out, axis=1), info
+
+    one, _ = run(False)
+    many, info = run(True)
+    assert info[1] == 1 and info[2] == nblk - 1
+    assert one.shape == many.shape == (256, nblk * n // 400 // 5)
+    assert np.array_equal(_bits(one), _bits(many))
+    assert float(np.abs(one[::4]).max()) > 0.0                  # the carrier channels carry audio

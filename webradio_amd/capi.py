@@ -16,7 +16,7 @@ WR_AM, WR_FM, WR_USB, WR_LSB = range(4)
 WR_STAGE_CHAN_IQ, WR_STAGE_DEMOD, WR_STAGE_AUDIO = 1, 2, 3
 WR_NCO_SPLIT, WR_NCO_EXACT, WR_NCO_ROTATE = 0, 1, 2
 WR_HOST, WR_DEVICE = 0, 1
-WR_ABI_VERSION = 4            # include/webradio_amd.h
+WR_ABI_VERSION = 5            # include/webradio_amd.h
 WR_FIR_LENGTH = 64
 WR_TABLE_SIZE = 65536
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "wr_tuner_keep_stages": (C.c_int, [_vp, _u32]),
     "wr_tuner_flush": (C.c_int, [_vp]),
     "wr_tuner_set_blocks_per_launch": (C.c_int, [_vp, _u32]),
+    "wr_tuner_set_streaming": (C.c_int, [_vp, C.c_int]),
+    "wr_tuner_stream_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "wr_tuner_seek": (C.c_int, [_vp, C.c_ulonglong]),
     "wr_tuner_audio_ring": (C.c_int, [_vp, _u32]),
     "wr_tuner_audio_ring_acquire": (C.c_int, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),

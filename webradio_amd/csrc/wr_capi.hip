@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -86,6 +87,10 @@ struct wr_dev {
 	uint8_t *up_raw[2];         /* where the DMA engine puts the bytes of a block (alternating) before the conversion kernel */
 	size_t up_raw_cap[2];
 	std::map<void *, size_t> *registered;   /* host ranges THIS library page-locked (wr_dev_host_register), under scratch_lock */
+	/* r05: the tuner whose streaming launch (wr_tuner_set_streaming) is running on `stream` right now, or NULL.  That
+	 * kernel ends when it is told to, not by itself: whoever is about to wait for the stream -- or to put work on it
+	 * that must not wait for the stream's idle deadline -- closes it first (dev_stream_sync, dev_settle_stream) */
+	wr_tuner *streaming = nullptr;
 };
 #define SCRATCH_GUARD(d) std::lock_guard<std::mutex> scratch_guard_(*(d)->scratch_lock)
 
@@ -194,6 +199,10 @@ struct wr_tuner {
 		size_t stride = 0, frames = 0;
 		unsigned int slots = 0;
 		unsigned long long seq = 0;
+		/* a block of a streaming launch: its audio is in the slot when WrStreamCtl::done of stream number `stream_gen`
+		 * has reached `stream_wait` (0: `done` is the event to wait for) */
+		unsigned int stream_wait = 0;
+		unsigned long long stream_gen = 0;
 	};
 	std::vector<RingSlot> ring;
 	unsigned int ring_head = 0, ring_count = 0;    /* next slot to fill, slots queued */
@@ -209,6 +218,28 @@ struct wr_tuner {
 	size_t held_frames = 0, held_each = 0;
 	unsigned int held_count = 0;
 	std::mutex ring_lock;                          /* producer (submit) vs consumer thread */
+	/* r05, wr_tuner_set_streaming: blocks in device memory go to ONE persistent launch (k_tuner_stream) through a
+	 * doorbell instead of a launch each; see wr_internal.h and stream_open / stream_bell / stream_close below */
+	struct Stream {
+		bool enabled = false;
+		bool live = false;                 /* a launch is running and takes blocks */
+		bool unchecked = false;            /* a closed launch whose outcome (WrStreamCtl::err, final_blocks) has not been read yet */
+		WrStreamCtl *ctl = nullptr;        /* page-locked, mapped */
+		WrStreamDesc *desc = nullptr;      /* page-locked, mapped, [WR_STREAM_MAXJ] */
+		WrStreamDev *sdev = nullptr;
+		float *ring = nullptr;             /* channel IQ between the DDC waves and the post stage */
+		size_t ring_floats = 0;
+		Group *g = nullptr;
+		unsigned int count = 0;            /* blocks rung into the live (or last) launch */
+		size_t nframes = 0;
+		bool u8 = false;
+		int parity0 = 0;
+		size_t k1 = 0, k2 = 0;
+		unsigned long long gen = 0;        /* launches opened so far */
+		unsigned long long blocks = 0;     /* blocks streamed so far, all launches */
+		std::chrono::steady_clock::time_point last_bell;
+		const float *last_iq = nullptr;    /* channel IQ of the last block of the last launch (wr_chan_fetch) */
+	} stream;
 };
 
 struct wr_spectrum {
@@ -224,6 +255,24 @@ struct wr_spectrum {
 
 /* ------------------------------------------------------------------ helpers -- */
 
+/* r05: a streaming launch (wr_tuner_set_streaming) runs until it is told to stop.  Everything that waits for the
+ * device's stream, frees device memory (hipFree waits for the device) or must not sit behind an idle launch closes it
+ * first; the close is a store to page-locked memory, the launch then finishes the blocks it has and ends. */
+static int stream_close(wr_tuner *t);
+static int stream_check(wr_tuner *t);
+static void stream_free(wr_tuner *t);
+static int dev_settle_stream(wr_dev *d)
+{
+	return d->streaming ? stream_close(d->streaming) : WR_OK;
+}
+static hipError_t dev_stream_sync(wr_dev *d)
+{
+	if (dev_settle_stream(d))
+		return hipErrorUnknown;
+	return hipStreamSynchronize(d->stream);
+}
+
+
 static int dev_bind(wr_dev *d)
 {
 	HIP_TRY(hipSetDevice(d->device));
@@ -235,7 +284,7 @@ static int dev_scratch(wr_dev *d, size_t floats)
 	if (d->scratch_floats >= floats)
 		return WR_OK;
 	if (d->scratch) {
-		HIP_TRY(hipStreamSynchronize(d->stream));
+		HIP_TRY(dev_stream_sync(d));
 		HIP_TRY(hipFree(d->scratch));
 		d->scratch = nullptr;
 		d->scratch_floats = 0;
@@ -415,7 +464,7 @@ extern "C" int wr_dev_close(wr_dev *d)
 	if (!d)
 		return WR_OK;
 	(void)hipSetDevice(d->device);
-	(void)hipStreamSynchronize(d->stream);
+	(void)dev_stream_sync(d);
 	(void)hipFree(d->table);
 	(void)hipFree(d->table_turn);
 	(void)hipFree(d->hi_cs);
@@ -453,7 +502,7 @@ extern "C" int wr_dev_sync(wr_dev *d)
 {
 	if (!d)
 		return fail(WR_ERR_ARG, "dev is NULL");
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -478,7 +527,7 @@ extern "C" int wr_dev_free(wr_dev *d, void *ptr_dev)
 		return fail(WR_ERR_ARG, "dev is NULL");
 	if (!ptr_dev)
 		return WR_OK;
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	HIP_TRY(hipFree(ptr_dev));
 	return WR_OK;
 }
@@ -490,7 +539,7 @@ extern "C" int wr_dev_upload(wr_dev *d, void *dst_dev, const void *src_host, siz
 	if (!bytes)
 		return WR_OK;
 	HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -619,7 +668,7 @@ extern "C" int wr_dev_download(wr_dev *d, void *dst_host, const void *src_dev, s
 	if (!bytes)
 		return WR_OK;
 	HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -676,7 +725,7 @@ extern "C" int wr_demod(wr_dev *d, int mode, const float *in_dev, size_t nframes
 		/* prev_i/q = last input frame (demodulator.cxx:110-111) */
 		HIP_TRY(hipMemcpyAsync(prev_io, in_dev + 2 * (nframes - 1), 2 * sizeof(float),
 		                       hipMemcpyDeviceToHost, d->stream));
-		HIP_TRY(hipStreamSynchronize(d->stream));
+		HIP_TRY(dev_stream_sync(d));
 	}
 	return WR_OK;
 }
@@ -778,7 +827,7 @@ extern "C" int wr_u8_to_f32_from_host(wr_dev *d, const uint8_t *in_host, float *
 	if (d->up_raw_cap[rb] < count) {
 		if (d->up_stream)
 			HIP_TRY(hipStreamSynchronize(d->up_stream));
-		HIP_TRY(hipStreamSynchronize(d->stream));
+		HIP_TRY(dev_stream_sync(d));
 		(void)hipFree(d->up_raw[rb]);
 		d->up_raw[rb] = nullptr;
 		d->up_raw_cap[rb] = 0;
@@ -1014,7 +1063,9 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 	if (!t)
 		return WR_OK;
 	(void)hipSetDevice(t->dev->device);
-	(void)hipStreamSynchronize(t->dev->stream);
+	(void)stream_close(t);
+	(void)dev_stream_sync(t->dev);
+	stream_free(t);
 	for (Group *g : t->groups)
 		group_free(g);
 	for (hipEvent_t e : t->ev)
@@ -1036,6 +1087,7 @@ extern "C" int wr_tuner_destroy(wr_tuner *t)
 
 static int tuner_quiesce(wr_tuner *t);
 static int tuner_flush(wr_tuner *t);
+static void stream_free(wr_tuner *t);
 static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used, bool direct);
 static float *ring_reserve(wr_tuner *t, Group *g, size_t k2, unsigned int used);
 
@@ -1046,7 +1098,7 @@ static int tuner_launch_held(wr_tuner *t);
  * getter sees the state after it. */
 static int settle_held(wr_tuner *t)
 {
-	if (!t || !t->held_count)
+	if (!t || (!t->held_count && !t->stream.live))
 		return WR_OK;
 	if (dev_bind(t->dev))
 		return WR_ERR_HIP;
@@ -1463,8 +1515,8 @@ static int tuner_quiesce(wr_tuner *t)
 	for (Group *g : t->groups)
 		if ((rc = seek_materialize(t, g)) != WR_OK)
 			return rc;
-	HIP_TRY(hipStreamSynchronize(t->dev->stream));
-	return WR_OK;
+	HIP_TRY(dev_stream_sync(t->dev));
+	return stream_check(t);
 }
 
 /* push the host shadow of one group's parameters to its device arrays */
@@ -1693,7 +1745,7 @@ static int prof_drain(wr_tuner *t, size_t keep)
 {
 	if (t->ev_used / 2 <= keep)
 		return WR_OK;
-	HIP_TRY(hipStreamSynchronize(t->dev->stream));
+	HIP_TRY(dev_stream_sync(t->dev));
 	for (size_t i = 0; i + 1 < t->ev_used; i += 2) {
 		float ms = 0.0f;
 		HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
@@ -1710,6 +1762,8 @@ extern "C" int wr_tuner_profile(wr_tuner *t, int enable)
 {
 	if (!t)
 		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (int rc = settle_held(t))                    /* (a streaming launch stamps its events when it is opened) */
+		return rc;
 	if (t->ev_used & 1)
 		t->ev_used--;                               /* a group left open: its start event is dropped */
 	t->profiling = enable != 0;
@@ -1724,6 +1778,8 @@ extern "C" int wr_tuner_profile_read(wr_tuner *t, unsigned int *launches, double
 		return fail(WR_ERR_ARG, "wr_tuner_profile_read: bad argument");
 	if (dev_bind(t->dev))
 		return WR_ERR_HIP;
+	if (int rc = settle_held(t))
+		return rc;
 	int rc = prof_drain(t, 0);
 	if (rc)
 		return rc;
@@ -1747,9 +1803,15 @@ extern "C" int wr_tuner_submit_u8(wr_tuner *t, const uint8_t *iq_u8, size_t nfra
 }
 
 static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8);
+static bool stream_follows(const wr_tuner *t, size_t nframes, int where, bool u8);
+static int stream_bell(wr_tuner *t, const void *iq);
+static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, bool *took);
+static Group *single_group(wr_tuner *t);
 
 static int tuner_launch_held(wr_tuner *t)
 {
+	if (t->stream.live)                                 /* (a streaming launch holds no blocks back: it is told that none follows) */
+		return stream_close(t);
 	if (!t->held_count)
 		return WR_OK;
 	const float *base = t->held_base;
@@ -1797,6 +1859,18 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		return fail(WR_ERR_ARG, "wr_tuner_submit: bad argument");
 	if (int rc = submit_precheck(t, nframes, where))
 		return rc;
+	if (t->stream.live) {
+		if (stream_follows(t, nframes, where, u8))
+			return stream_bell(t, iq);
+		if (int rc = stream_close(t))
+			return rc;
+	}
+	if (t->stream.enabled && where == WR_DEVICE && nframes) {
+		bool took = false;
+		const int rc = stream_open(t, iq, nframes, u8, &took);
+		if (rc || took)
+			return rc;
+	}
 	if (t->coalesce > 1 && where == WR_DEVICE && !u8 && nframes && block_can_be_held(t, nframes)) {
 		const float *p = (const float *)iq;
 		/* (a setter called since the last submit has sent the held blocks out already: settle_held) */
@@ -1881,6 +1955,7 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 	const float *cur = u8 ? nullptr : (const float *)src;
 	const uint8_t *cur_u8 = u8 ? (const uint8_t *)src : nullptr;
 
+	t->stream.last_iq = nullptr;             /* (the last block's channel IQ is in the group's own buffers again) */
 	bool hist_written = false;
 	bool marked = false, unmarked = false;   /* wr_tuner_mark_launches: launches that stamped the submit's event / that could not */
 	const unsigned long long seq = t->submit_seq++;
@@ -2088,6 +2163,393 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 	return WR_OK;
 }
 
+/* ------------------------------------------------------------------ the streaming launch -- */
+/*
+ * wr_tuner_set_streaming(tuner, 1): blocks submitted from DEVICE memory no longer cost a kernel launch each.  The
+ * first one opens a persistent launch (k_tuner_stream, wr_stream_kernel.inc), every following block of the same size
+ * rings its doorbell -- a descriptor and a counter in page-locked host memory -- and the launch takes it up where it
+ * stands: no ramp, no tail, no kernel boundary between blocks, and a block's demodulator + audio filter start the
+ * moment its last channel-IQ row is out (dsp/dspblock.cxx:169-212: a block's output leaves within its own run()).
+ * Anything else that touches the tuner -- a setter, a getter, a flush, a block of another size or from host memory, a
+ * wait for the device's stream through this library -- CLOSES the launch first: the host writes `stop`, the launch
+ * finishes the blocks it was given, rolls the state as one launch over all of them would have, and ends.  The host's
+ * own state is advanced by as many blocks at the close.  Same bits as one launch per block (tests/test_gpu_stream.py).
+ *
+ * Requirements, checked at the open (a submit that does not meet them goes the ordinary way): WR_NCO_ROTATE; one
+ * rate group; at most 1024 channels, all on ONE 64-tap channel filter; no second channel stage; an audio decimation
+ * the fused post stage has (1..6, 8, 10); whole audio frames per block; no kept demodulator rows, no seek pending, no
+ * launch marks.  A block's memory must stay untouched until the NEXT block's audio is complete (the first frames of
+ * a block read the last 63 of the one before in place).
+ *
+ * A caller that waits for the device's stream by other means (hipStreamSynchronize on a stream it handed to
+ * wr_dev_open, torch.cuda.synchronize()) should call wr_tuner_flush first: an open launch that nobody rings ends by
+ * itself only after WR_STREAM_IDLE_MS.
+ */
+#define WR_STREAM_IDLE_MS   500           /* the launch closes itself when the doorbell has been silent this long */
+#define WR_STREAM_STALE_MS  100           /* ... and the host does not ring a launch it has left alone this long: it opens a new one */
+#define WR_STREAM_WAIT_MS  2000           /* deadline of every other wait inside the launch (an error) */
+
+static unsigned long long *g_stream_tl = nullptr;
+extern "C" int wr_debug_stream_tl(unsigned long long *out, size_t n)
+{
+	if (!g_stream_tl)
+		return 1;
+	memcpy(out, g_stream_tl, n * sizeof(unsigned long long));
+	return 0;
+}
+
+static void stream_free(wr_tuner *t)
+{
+	wr_tuner::Stream &s = t->stream;
+	(void)hipHostFree(s.ctl);
+	(void)hipHostFree(s.desc);
+	(void)hipFree(s.sdev);
+	(void)hipFree(s.ring);
+	s.ctl = nullptr;
+	s.desc = nullptr;
+	s.sdev = nullptr;
+	s.ring = nullptr;
+	s.ring_floats = 0;
+}
+
+/* the outcome of a closed launch, once the device's stream has been waited for */
+static int stream_check(wr_tuner *t)
+{
+	wr_tuner::Stream &s = t->stream;
+	if (!s.unchecked)
+		return WR_OK;
+	s.unchecked = false;
+	if (s.ctl->err)
+		return fail(WR_ERR_HIP, "streaming launch: a wait inside the launch ran into its deadline (code %u)", s.ctl->err);
+	if (s.ctl->final_blocks != s.count)
+		return fail(WR_ERR_STATE, "streaming launch: %u blocks rung, %u processed%s", s.count, s.ctl->final_blocks,
+		            s.ctl->self_closed ? " (the launch had closed itself: the doorbell was silent too long)" : "");
+	return WR_OK;
+}
+
+/* a ring entry for block `idx` (from 0) of the live launch: its audio is complete when WrStreamCtl::done > idx */
+static float *stream_ring_entry(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, unsigned int used, unsigned int idx)
+{
+	if (t->ring.empty())
+		return nullptr;
+	float *mapped = ring_reserve(t, g, k2, used);
+	std::lock_guard<std::mutex> lk(t->ring_lock);
+	if (!mapped) {
+		if (single_group(t) == g && t->ring_count == t->ring.size())
+			++t->ring_overruns;                         /* io/rtlsdrtuner.cxx:100-117: the new block is dropped */
+		return nullptr;
+	}
+	wr_tuner::RingSlot &r = t->ring[t->ring_head];
+	r.stride = r.frames = k2;
+	r.slots = used;
+	r.seq = seq;
+	r.stream_wait = idx + 1u;
+	r.stream_gen = t->stream.gen;
+	t->ring_head = (t->ring_head + 1) % (unsigned int)t->ring.size();
+	++t->ring_count;
+	return mapped;
+}
+
+/* may the live launch take this block? */
+static bool stream_follows(const wr_tuner *t, size_t nframes, int where, bool u8)
+{
+	const wr_tuner::Stream &s = t->stream;
+	if (!s.live || !s.enabled || where != WR_DEVICE || nframes != s.nframes || u8 != s.u8 || s.count >= WR_STREAM_MAXJ)
+		return false;
+	if (s.g->dirty)
+		return false;
+	const auto idle = std::chrono::steady_clock::now() - s.last_bell;
+	return idle < std::chrono::milliseconds(WR_STREAM_STALE_MS);
+}
+
+static int stream_bell(wr_tuner *t, const void *iq)
+{
+	wr_tuner::Stream &s = t->stream;
+	const unsigned int j = s.count;
+	const unsigned long long seq = t->submit_seq++;
+	float *slot = stream_ring_entry(t, s.g, seq, s.k2, group_slots_used(s.g), j);
+	s.desc[j].cur = (unsigned long long)(uintptr_t)iq;
+	s.desc[j].audio_host = (unsigned long long)(uintptr_t)slot;
+	std::atomic_thread_fence(std::memory_order_release);      /* the descriptor before the count */
+	s.ctl->ready = j + 1u;
+	std::atomic_thread_fence(std::memory_order_seq_cst);
+	s.count = j + 1u;
+	++s.blocks;
+	s.last_bell = std::chrono::steady_clock::now();
+	return WR_OK;
+}
+
+static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, bool *took)
+{
+	*took = false;
+	wr_tuner::Stream &s = t->stream;
+	wr_dev *d = t->dev;
+	if (t->nco_mode != WR_NCO_ROTATE || !t->defer_post || t->mark_launches || (t->keep_mask & (1u << WR_STAGE_DEMOD)))
+		return WR_OK;
+	Group *g = single_group(t);
+	if (!g || g->l1 != WR_FIR_LENGTH || g->d1b || g->seek_pending || !wrk_tuner_post_supported(g->d2))
+		return WR_OK;
+	/* (64 channel-rate frames per block at least: a block's post stage takes its history from the block before) */
+	if (nframes < (size_t)WR_FIR_LENGTH * g->d1 || nframes % ((size_t)g->d1 * g->d2) || nframes / g->d1 > 0x3FFFFFFFu)
+		return WR_OK;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	if (int rc = tuner_launch_held(t))
+		return rc;
+	if (g->dirty)
+		if (int rc = group_upload(t, g))
+			return rc;
+	const unsigned int used = group_slots_used(g), groups = used / 64u;
+	if (!g->one_filter || !groups || groups > 16u)
+		return WR_OK;
+	if (int rc = dev_settle_stream(d))                      /* another tuner's launch on this device */
+		return rc;
+	if (s.unchecked) {
+		/* the launch before this one must be over before its doorbell is reused */
+		HIP_TRY(dev_stream_sync(d));
+		if (int rc = stream_check(t))
+			return rc;
+	}
+	if (g->post_pending)                                    /* the post stage of a block that went the ordinary way */
+		if (int rc = tuner_flush(t))
+			return rc;
+	const size_t k1 = nframes / g->d1, k2 = k1 / g->d2;
+	unsigned int n_ddc = 0, n_post = 0;
+	HIP_TRY(wrk_stream_geometry(g->d2, groups, d->num_cus, &n_ddc, &n_post));
+	if (!n_ddc || !n_post)
+		return WR_OK;
+	if (getenv("WR_STREAM_NPOST")) {                        /* (development: another split of the resident workgroups) */
+		const unsigned int np = (unsigned int)atoi(getenv("WR_STREAM_NPOST"));
+		if (np >= 1u && np < n_ddc + n_post - 8u) {
+			n_ddc = n_ddc + n_post - np;
+			n_post = np;
+		}
+	}
+	if (!s.ctl) {
+		HIP_TRY(hipHostMalloc((void **)&s.ctl, sizeof(WrStreamCtl), hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostMalloc((void **)&s.desc, sizeof(WrStreamDesc) * WR_STREAM_MAXJ, hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipMalloc((void **)&s.sdev, sizeof(WrStreamDev)));
+	}
+	const size_t ring_floats = (size_t)WR_STREAM_RING * k1 * g->slots * 2u;
+	if (ring_floats > s.ring_floats) {
+		HIP_TRY(dev_stream_sync(d));
+		(void)hipFree(s.ring);
+		s.ring = nullptr;
+		s.ring_floats = 0;
+		HIP_TRY(hipMalloc((void **)&s.ring, ring_floats * sizeof(float)));
+		s.ring_floats = ring_floats;
+	}
+	void *ctl_dev = nullptr, *desc_dev = nullptr;
+	HIP_TRY(hipHostGetDevicePointer(&ctl_dev, s.ctl, 0));
+	HIP_TRY(hipHostGetDevicePointer(&desc_dev, s.desc, 0));
+	hipStream_t st = d->stream;
+
+	/* the launch's view of the group: what tuner_submit_now hands k_tuner_ddc and the post stage for one block */
+	WrTunerLaunch L;
+	L.cur = u8 ? nullptr : (const float *)iq;
+	L.cur_u8 = u8 ? (const uint8_t *)iq : nullptr;
+	L.hist = t->in_hist[t->in_par];
+	L.hist_next = t->in_hist[t->in_par ^ 1];
+	L.parity = g->parity;
+	L.sp = g->sp;
+	L.cb = g->cb;
+	L.nframes = nframes;
+	L.d1 = g->d1;
+	L.d2 = g->d2;
+	L.slots = g->slots;
+	L.slots_used = used;
+	L.k1 = k1;
+	L.k2 = k2;
+	L.k2max = g->k2max;
+	L.nco_mode = t->nco_mode;
+	L.uniform_mask = g->uniform_mask;
+	L.uniform2_mask = g->uniform2_mask;
+	L.fewsets_mask = g->fewsets_mask;
+	L.one_filter = 1;
+	memcpy(L.nsets, g->nsets, sizeof(L.nsets));
+	L.audio_scale = t->audio_scale;
+	L.use_gain = g->use_gain ? 1 : 0;
+	L.use_squelch = g->use_squelch ? 1 : 0;
+	L.ev_start = L.ev_stop = nullptr;
+
+	WrStreamArgs A;
+	memset(&A, 0, sizeof(A));
+	A.ctl = (WrStreamCtl *)ctl_dev;
+	A.desc_host = (const WrStreamDesc *)desc_dev;
+	A.sdev = s.sdev;
+	A.idle_ticks = (unsigned long long)WR_STREAM_IDLE_MS * 100000ull;      /* the constant clock runs at 100 MHz */
+	A.wait_ticks = (unsigned long long)WR_STREAM_WAIT_MS * 100000ull;
+	A.n_ddc = n_ddc;
+	A.n_post = n_post;
+	A.dbg = getenv("WR_STREAM_DBG") ? (unsigned int)atoi(getenv("WR_STREAM_DBG")) : 0u;
+	if (A.dbg & 16u) {
+		static unsigned long long *tlbuf = nullptr;
+		if (!tlbuf)
+			HIP_TRY(hipHostMalloc((void **)&tlbuf, 8192 * 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+		memset(tlbuf, 0, 8192 * 8 * sizeof(unsigned long long));
+		void *tld = nullptr;
+		HIP_TRY(hipHostGetDevicePointer(&tld, tlbuf, 0));
+		A.tl = (unsigned long long *)tld;
+		g_stream_tl = tlbuf;
+	}
+	A.nframes = nframes;
+	A.k1 = (unsigned int)k1;
+	A.d1 = g->d1;
+	A.is_u8 = u8 ? 1u : 0u;
+	A.slots = g->slots;
+	A.groups = groups;
+	for (unsigned int gi = 0; gi < groups; ++gi)
+		(gi < 8u ? A.gmap0 : A.gmap1) |= (unsigned long long)gi << ((gi & 7u) * 8u);
+	A.kslow = (WR_HIST + g->d1 - 1u) / g->d1;
+	if (A.kslow > k1)
+		A.kslow = (unsigned int)k1;
+	A.hist = L.hist;
+	A.hist_next = L.hist_next;
+	A.phase = g->dev.phase[g->sp];
+	A.step = g->dev.step;
+	A.phase_next = g->dev.phase[g->sp ^ 1];
+	A.hist_cs = g->dev.hist_cs[g->sp];
+	A.hist_lo = g->dev.hist_lo[g->sp];
+	A.hist_cs_next = g->dev.hist_cs[g->sp ^ 1];
+	A.hist_lo_next = g->dev.hist_lo[g->sp ^ 1];
+	A.flags = g->dev.flags;
+	A.taps1 = g->dev.taps1;
+	A.rot = g->dev.rot;
+	A.taps1u = g->dev.taps1u;
+	A.tapsel = g->dev.tapsel;
+	A.table = d->table_turn;
+	A.hi_cs = d->hi_cs;
+	A.lo_cs = d->lo_cs;
+	A.ring = s.ring;
+	A.post = wrk_post_args(L, g->dev);
+	A.post.host_stride = k2;                                /* the ring's rows lie back to back (RingSlot::stride = frames) */
+	A.prev_iq[0] = g->dev.prev_iq[0];
+	A.prev_iq[1] = g->dev.prev_iq[1];
+	A.dem[0] = g->dev.dem[0];
+	A.dem[1] = g->dev.dem[1];
+	A.parity0 = g->parity;
+
+	/* the doorbell as the launch finds it: block 0 rung */
+	++s.gen;
+	s.g = g;
+	s.count = 0;
+	s.nframes = nframes;
+	s.u8 = u8;
+	s.parity0 = g->parity;
+	s.k1 = k1;
+	s.k2 = k2;
+	s.last_iq = nullptr;
+	const unsigned long long seq = t->submit_seq++;
+	float *slot = stream_ring_entry(t, g, seq, k2, used, 0);
+	s.ctl->ready = 1;
+	s.ctl->stop = 0;
+	s.ctl->done = 0;
+	s.ctl->final_blocks = 0;
+	s.ctl->err = 0;
+	s.ctl->self_closed = 0;
+	s.desc[0].cur = (unsigned long long)(uintptr_t)iq;
+	s.desc[0].audio_host = (unsigned long long)(uintptr_t)slot;
+	std::atomic_thread_fence(std::memory_order_seq_cst);
+	HIP_TRY(hipMemsetAsync(s.sdev, 0, offsetof(WrStreamDev, desc), st));
+	HIP_TRY(hipMemcpyAsync(&s.sdev->desc[0], &s.desc[0], sizeof(WrStreamDesc), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(&s.sdev->cur[0], 0, sizeof(unsigned long long), st));
+	HIP_TRY(hipMemcpyAsync(&s.sdev->cur[1], &s.desc[0].cur, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+	/* (WrStreamDev::ready stays 0 until the bell republishes a count of 2 or more: block 0 is known to every wave
+	 * from the start.  It is NOT copied from the doorbell here: that copy would run when the stream gets to it, by
+	 * which time the host may have rung again -- and the bell, finding the higher count already in device memory,
+	 * would never bring the descriptors over that go with it) */
+
+	void *ev0 = nullptr, *ev1 = nullptr;
+	if (t->profiling) {
+		/* one event pair for the whole launch, stamped by the dispatch itself */
+		if (int rc = (t->ev_used & 1) ? WR_OK : prof_drain(t, 64))
+			return rc;
+		if (!(t->ev_used & 1)) {
+			while (t->ev.size() < t->ev_used + 2) {
+				hipEvent_t e;
+				HIP_TRY(hipEventCreate(&e));
+				t->ev.push_back(e);
+			}
+			ev0 = t->ev[t->ev_used];
+			ev1 = t->ev[t->ev_used + 1];
+		}
+	}
+	HIP_TRY(wrk_tuner_stream(st, A, ev0, ev1));
+	if (ev0) {
+		t->ev_span.resize(t->ev_used / 2 + 1, 1u);
+		t->ev_span[t->ev_used / 2] = 1u;
+		t->ev_used += 2;
+	}
+	s.live = true;
+	s.count = 1;
+	++s.blocks;
+	s.last_bell = std::chrono::steady_clock::now();
+	d->streaming = t;
+	*took = true;
+	return WR_OK;
+}
+
+/* close the live launch: tell it that no block follows, and advance the host's picture of the tuner by the blocks
+ * it was given.  Does not wait: the launch finishes them and ends, stream-ordered work queues behind it. */
+static int stream_close(wr_tuner *t)
+{
+	wr_tuner::Stream &s = t->stream;
+	if (!s.live)
+		return WR_OK;
+	std::atomic_thread_fence(std::memory_order_seq_cst);
+	s.ctl->stop = 1;
+	std::atomic_thread_fence(std::memory_order_seq_cst);
+	s.live = false;
+	s.unchecked = true;
+	if (t->dev->streaming == t)
+		t->dev->streaming = nullptr;
+	Group *g = s.g;
+	const unsigned int J = s.count;
+	for (Group *x : t->groups)
+		if (x != g)
+			x->last_k1 = x->last_k2 = 0;
+	g->sp ^= 1;                        /* the launch rolls the DDC's state into the other set ONCE, behind its last block */
+	g->last_parity = s.parity0;
+	g->parity = s.parity0 ^ 1;         /* ... and so it does with the post stage's */
+	g->last_k1 = s.k1;
+	g->last_k2 = s.k2;
+	g->last_demod_kept = false;
+	s.last_iq = s.ring + (size_t)((J - 1u) % WR_STREAM_RING) * s.k1 * g->slots * 2u;
+	t->in_par ^= 1;
+	for (Chan &c : t->chans) {
+		if (!c.in_use || c.group < 0)
+			continue;
+		c.phaseL += (unsigned int)((unsigned long long)s.nframes * J) * c.stepL;
+	}
+	t->submitted = true;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_set_streaming(wr_tuner *t, int enable)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (dev_bind(t->dev))
+		return WR_ERR_HIP;
+	if (int rc = tuner_launch_held(t))
+		return rc;
+	t->stream.enabled = enable != 0;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_stream_info(wr_tuner *t, int *live, unsigned long long *launches, unsigned long long *blocks)
+{
+	if (!t)
+		return fail(WR_ERR_ARG, "tuner is NULL");
+	if (live)
+		*live = t->stream.live ? 1 : 0;
+	if (launches)
+		*launches = t->stream.gen;
+	if (blocks)
+		*blocks = t->stream.blocks;
+	return WR_OK;
+}
+
 extern "C" int wr_tuner_last_staging(wr_tuner *t, int *how)
 {
 	if (!t || !how)
@@ -2157,7 +2619,8 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 		if (rc)
 			return rc;
 		if (stage == WR_STAGE_CHAN_IQ)
-			HIP_TRY(wrk_gather_rows(d->stream, g->d1b ? g->dev.chan_iq2[g->last_cb] : g->dev.chan_iq[g->last_cb],
+			HIP_TRY(wrk_gather_rows(d->stream, t->stream.last_iq ? t->stream.last_iq
+			                                   : g->d1b ? g->dev.chan_iq2[g->last_cb] : g->dev.chan_iq[g->last_cb],
 			                        g->last_k1, S * 2, (size_t)c->slot * 2, 2, d->scratch));
 		else if (!g->last_demod_kept)
 			return fail(WR_ERR_STATE, "wr_chan_fetch: the demodulator output was not kept "
@@ -2167,7 +2630,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 			                        (size_t)c->slot, 1, d->scratch));
 		HIP_TRY(hipMemcpyAsync(out_host, d->scratch, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
 	}
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -2235,7 +2698,7 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	}
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -2329,6 +2792,7 @@ static int ring_push(wr_tuner *t, Group *g, unsigned long long seq, size_t k2, u
 			                         k2 * sizeof(float), used, hipMemcpyDeviceToHost, st));
 	}
 	HIP_TRY(hipEventRecord(r.done, st));
+	r.stream_wait = 0;
 	r.stride = r.frames = k2;
 	r.slots = used;
 	r.seq = seq;
@@ -2376,6 +2840,8 @@ extern "C" int wr_tuner_audio_ring_acquire(wr_tuner *t, const float **audio_host
 		return fail(WR_ERR_ARG, "wr_tuner_audio_ring_acquire: bad argument");
 	hipEvent_t ev;
 	wr_tuner::RingSlot *r;
+	unsigned int swait = 0;
+	unsigned long long sgen = 0;
 	{
 		std::lock_guard<std::mutex> lk(t->ring_lock);
 		if (t->ring.empty())
@@ -2387,10 +2853,36 @@ extern "C" int wr_tuner_audio_ring_acquire(wr_tuner *t, const float **audio_host
 		const unsigned int n = (unsigned int)t->ring.size();
 		r = &t->ring[(t->ring_head + n - t->ring_count) % n];
 		ev = r->done;
+		swait = r->stream_wait;
+		sgen = r->stream_gen;
 		t->ring_held = true;
 	}
 	/* wait outside the lock: the producer may queue further blocks meanwhile */
-	hipError_t e = hipEventSynchronize(ev);
+	hipError_t e = hipSuccess;
+	if (swait) {
+		/* a block of a streaming launch: the launch's post stage wrote the slot itself and counts the blocks it has
+		 * finished in page-locked memory (a launch older than the tuner's current one has ended: stream_open waits) */
+		const auto t0 = std::chrono::steady_clock::now();
+		unsigned int spins = 0;
+		while (sgen == t->stream.gen && t->stream.ctl->done < swait && !t->stream.ctl->err) {
+			if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4 * WR_STREAM_WAIT_MS)) {
+				std::lock_guard<std::mutex> lk(t->ring_lock);
+				t->ring_held = false;
+				return fail(WR_ERR_HIP, "wr_tuner_audio_ring_acquire: the streaming launch did not deliver block %u", swait - 1u);
+			}
+#if defined(__x86_64__)
+			__builtin_ia32_pause();
+#endif
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+		if (sgen == t->stream.gen && t->stream.ctl->err) {
+			std::lock_guard<std::mutex> lk(t->ring_lock);
+			t->ring_held = false;
+			return fail(WR_ERR_HIP, "wr_tuner_audio_ring_acquire: the streaming launch reported error %u", t->stream.ctl->err);
+		}
+	} else {
+		e = hipEventSynchronize(ev);
+	}
 	if (e != hipSuccess) {
 		std::lock_guard<std::mutex> lk(t->ring_lock);
 		t->ring_held = false;
@@ -2417,7 +2909,12 @@ extern "C" int wr_tuner_audio_ring_ready(wr_tuner *t, int *ready)
 		if (t->ring.empty() || !t->ring_count || t->ring_held)
 			return WR_OK;
 		const unsigned int n = (unsigned int)t->ring.size();
-		ev = t->ring[(t->ring_head + n - t->ring_count) % n].done;
+		const wr_tuner::RingSlot &r = t->ring[(t->ring_head + n - t->ring_count) % n];
+		ev = r.done;
+		if (r.stream_wait) {
+			*ready = (r.stream_gen != t->stream.gen || t->stream.ctl->done >= r.stream_wait) ? 1 : 0;
+			return WR_OK;
+		}
 	}
 	if (dev_bind(t->dev))
 		return WR_ERR_HIP;
@@ -2675,7 +3172,7 @@ extern "C" int wr_spectrum_destroy(wr_spectrum *s)
 	if (!s)
 		return WR_OK;
 	(void)hipSetDevice(s->dev->device);
-	(void)hipStreamSynchronize(s->dev->stream);
+	(void)dev_stream_sync(s->dev);
 	plan_free(s->plan);
 	(void)hipFree(s->stage);
 	(void)hipFree(s->bins);
@@ -2712,7 +3209,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 				float *nb = nullptr;
 				const size_t cap = rest + s->n;
 				HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
-				HIP_TRY(hipStreamSynchronize(st));
+				HIP_TRY(dev_stream_sync(s->dev));
 				if (s->stage)
 					HIP_TRY(hipFree(s->stage));
 				s->stage = nb;
@@ -2730,7 +3227,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 		HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
 		if (s->pending)
 			HIP_TRY(hipMemcpyAsync(nb, s->stage, s->pending * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(dev_stream_sync(s->dev));
 		if (s->stage)
 			HIP_TRY(hipFree(s->stage));
 		s->stage = nb;
@@ -2771,7 +3268,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 		s->pending = have;
 	}
 	if (where == WR_HOST)
-		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(dev_stream_sync(s->dev));
 	return WR_OK;
 }
 
@@ -2785,7 +3282,7 @@ extern "C" int wr_spectrum_get_bins(wr_spectrum *s, float *bins_host)
 		return WR_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(bins_host, s->bins, (size_t)s->n * 2 * sizeof(float), hipMemcpyDeviceToHost,
 	                       s->dev->stream));
-	HIP_TRY(hipStreamSynchronize(s->dev->stream));
+	HIP_TRY(dev_stream_sync(s->dev));
 	return WR_OK;
 }
 
@@ -2806,7 +3303,7 @@ extern "C" int wr_spectrum_get_db(wr_spectrum *s, float *magnitudes_host)
 	HIP_TRY(wrk_bins_to_db(d->stream, s->bins, s->n, d->scratch));
 	HIP_TRY(hipMemcpyAsync(magnitudes_host, d->scratch, (size_t)s->n * sizeof(float), hipMemcpyDeviceToHost,
 	                       d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -2831,7 +3328,7 @@ extern "C" int wr_spectrum_get_waterfall_row(wr_spectrum *s, unsigned int width,
 		HIP_TRY(hipMemcpyAsync(db_row_host, db_dev, (size_t)width * sizeof(float), hipMemcpyDeviceToHost, d->stream));
 	if (palette_host)
 		HIP_TRY(hipMemcpyAsync(palette_host, pal_dev, width, hipMemcpyDeviceToHost, d->stream));
-	HIP_TRY(hipStreamSynchronize(d->stream));
+	HIP_TRY(dev_stream_sync(d));
 	return WR_OK;
 }
 
@@ -2861,7 +3358,7 @@ extern "C" int wr_spectrum_batch_db(wr_spectrum *s, const float *iq_dev, size_t 
 		if (want > nframes_fft)
 			want = nframes_fft;
 		if (want > p.work_frames) {
-			HIP_TRY(hipStreamSynchronize(s->dev->stream));
+			HIP_TRY(dev_stream_sync(s->dev));
 			(void)hipFree(p.work);
 			p.work = nullptr;
 			p.work_frames = 0;

@@ -150,6 +150,10 @@ struct WrPostArgs {
 	                                audio sample too, rows `host_stride` floats apart -- the block's audio is in the ring when
 	                                the launch has run, no device-to-host copy behind it; NULL: device memory only */
 	size_t       host_stride;
+	const float *chan_prev = nullptr;   /* r05 (the streaming launch): the channel IQ of the block BEFORE this one, [k1][slots][2], k1 >= 64 --
+	                                the 63 rows of audio-filter history and the demodulator's previous frame are then made from
+	                                ITS last 64 rows (the same operations on the same frames: the same bits) instead of read
+	                                from dem_hist / prev_iq, so that a block's post stage does not wait for the one before */
 };
 /* `post` (optional): the post stage of the PREVIOUS block, run by extra workgroups of the same
  * launch beside this block's DDC (only taken up by the ROTATE / uniform-taps kernel; *post_taken
@@ -180,6 +184,86 @@ hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int
                     unsigned long long frame);
 hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t row_stride_floats,
                            size_t col_offset_floats, unsigned int width_floats, float *dst);
+
+/* ---- the streaming launch (r05; wr_tuner_set_streaming): ONE persistent launch of the fused path that takes the
+ * tuner's blocks as they are submitted -- the host rings a doorbell in page-locked memory instead of launching a
+ * kernel per block, so a launch's ramp and tail (about 4.6 us at C2: every wave's state, the LDS tables, the first
+ * windows; the ragged end) are paid once per STREAM, not once per block, and a block's post stage starts the moment
+ * its last channel-IQ row is out, whether or not another block follows (dsp/dspblock.cxx:169-212: a block's output
+ * leaves within its own run()).  See k_tuner_stream in wr_kernels.hip. ---- */
+#define WR_STREAM_MAXJ   1024u             /* blocks one streaming launch takes at most (the host then opens the next) */
+#define WR_STREAM_RING   8u                /* blocks of channel IQ the ring between the DDC waves and the post stage holds */
+struct WrStreamDesc {                      /* one submitted block */
+	unsigned long long cur;                /* device address of its frames (float pairs, or byte pairs) */
+	unsigned long long audio_host;         /* mapped page-locked ring slot that takes its audio too, or 0 */
+};
+struct WrStreamCtl {                       /* page-locked host memory, mapped: the doorbell and the way back */
+	volatile unsigned int ready;           /* host -> device: blocks submitted so far (monotonic) */
+	volatile unsigned int stop;            /* host -> device: 1 = `ready` is final */
+	volatile unsigned int pad0[14];
+	volatile unsigned int done;            /* device -> host: blocks whose audio is complete */
+	volatile unsigned int final_blocks;    /* device -> host, at exit: blocks the launch processed */
+	volatile unsigned int err;             /* device -> host: non-zero = a wait ran into its deadline (WR_STREAM_ERR_*) */
+	volatile unsigned int self_closed;     /* device -> host: the doorbell was silent for `idle_ticks`: closed on its own */
+	volatile unsigned int pad1[12];
+};
+#define WR_STREAM_SHARDS 16u               /* counters a block's DDC completions are spread over, a cache line each */
+struct WrStreamDev {                       /* device memory: what the bell wave republishes, and the hand-over counters */
+	unsigned int ready, stop;
+	unsigned long long beat;                   /* the bell's heartbeat: the 100 MHz clock, every time round its loop */
+	unsigned int pad0[28];
+	/* what the waiting waves poll: one word each, written once per block (never the counters the arrivals land on:
+	 * 4 000 waves arriving on ONE word queue up at 11-13 ns each -- MI355X_MICROARCH.md "fanin" -- and every wave
+	 * that has an arrival in flight waits for it the next time it waits for vector memory) */
+	unsigned long long progress;               /* low word: blocks whose channel IQ is complete; high word: blocks whose post
+	                                              stage is complete, in order.  ONE writer (the watcher wave), one 8-byte store:
+	                                              a DDC wave entering a block learns both with one load */
+	unsigned int pad1[30];
+	unsigned int post_done[WR_STREAM_MAXJ];    /* post workgroups that have finished block j */
+	unsigned int ddc_done[WR_STREAM_MAXJ][WR_STREAM_SHARDS][32];   /* lane-group units of block j whose channel IQ is in memory:
+	                                              the sum over the shards' first words (wave w arrives on shard w mod SHARDS) */
+	WrStreamDesc desc[WR_STREAM_MAXJ];
+	unsigned long long cur[WR_STREAM_MAXJ + 1u];   /* cur[j + 1] = where block j lies, cur[0] = 0: a block's address and its
+	                                              predecessor's side by side */
+};
+struct WrStreamArgs {
+	/* control */
+	WrStreamCtl        *ctl;               /* mapped host memory */
+	const WrStreamDesc *desc_host;         /* mapped host memory, [WR_STREAM_MAXJ] */
+	WrStreamDev        *sdev;
+	unsigned long long  idle_ticks;        /* 100 MHz ticks without a bell after which the launch closes itself */
+	unsigned long long  wait_ticks;        /* ... any other wait may take before it gives up (an error) */
+	unsigned int        n_ddc, n_post;     /* workgroups per role; one more rings the bell */
+	unsigned int        dbg;               /* development switches (WR_STREAM_DBG): results are wrong with any of them set */
+	unsigned long long *tl;                /* WR_STREAM_DBG & 16: [wave][8] cycle counts of the DDC waves (development aid) */
+	/* the block shape (every block of a stream has it) */
+	unsigned long long  nframes;           /* input frames per block, = k1 * d1 */
+	unsigned int        k1, d1, is_u8;
+	unsigned int        slots, groups;     /* row stride of the per-slot arrays; lane groups in use */
+	unsigned long long  gmap0, gmap1;      /* which lane groups (as k_tuner_ddc) */
+	unsigned int        kslow;             /* output frames of a block whose window reaches into the block before */
+	/* the DDC's state (WrGroupDev), set `sp` read, set `sp ^ 1` written at exit */
+	const float        *hist;              /* tuner input history [63][2] before block 0 */
+	float              *hist_next;
+	const unsigned int *phase, *step;
+	unsigned int       *phase_next;
+	const float        *hist_cs, *hist_lo;
+	float              *hist_cs_next, *hist_lo_next;
+	const int          *flags;
+	const float        *taps1, *rot, *taps1u;
+	const int          *tapsel;
+	const float        *table, *hi_cs, *lo_cs;
+	float              *ring;              /* [WR_STREAM_RING * k1][slots][2] channel IQ */
+	/* the post stage: what wrk_post_args gives for ONE block, and the two ping-pong state sets */
+	WrPostArgs          post;
+	const float        *prev_iq[2];
+	float              *dem[2];
+	int                 parity0;           /* set block 0 reads */
+};
+#define WR_STREAM_ERR_WAIT   1u            /* a wait inside the launch ran into `wait_ticks` */
+/* workgroups the launch needs co-resident (it sizes its roles to them); 0 = this launch shape cannot stream */
+hipError_t wrk_stream_geometry(unsigned int d2, unsigned int groups, int num_cus, unsigned int *n_ddc, unsigned int *n_post);
+hipError_t wrk_tuner_stream(hipStream_t st, const WrStreamArgs &A, void *ev_start, void *ev_stop);
 
 /* ---- FFT (wr_fft.hip) ---- */
 struct WrFftPlan {

@@ -528,15 +528,23 @@ __device__ __forceinline__ float audio_out(float v, const float *__restrict__ ga
 
 __device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
                                           unsigned int s, int m, const float2 *__restrict__ prev_iq,
-                                          const float *__restrict__ dem_hist, size_t rr)
+                                          const float *__restrict__ dem_hist, size_t rr,
+                                          const float2 *__restrict__ chan_prev = nullptr)
 {
-	if (rr < WR_HIST)
-		return dem_hist[rr * slots + s];
+	if (rr < WR_HIST) {
+		if (!chan_prev)
+			return dem_hist[rr * slots + s];
+		/* (streaming launch) history row rr = the demodulated frame k1 - 63 + rr of the block before */
+		const size_t kp = (size_t)k1 - WR_HIST + rr;
+		const float2 z = chan_prev[kp * slots + s];
+		const float2 zp = chan_prev[(kp - 1u) * slots + s];
+		return demod_one(m, z.x, z.y, zp.x, zp.y);
+	}
 	const size_t kk = rr - WR_HIST;
 	if (kk >= k1)
 		return 0.0f;                                    /* beyond the block: never read by lowpass.cxx */
 	const float2 z = chan_iq[kk * slots + s];
-	const float2 zp = kk ? chan_iq[(kk - 1u) * slots + s] : prev_iq[s];
+	const float2 zp = kk ? chan_iq[(kk - 1u) * slots + s] : chan_prev ? chan_prev[((size_t)k1 - 1u) * slots + s] : prev_iq[s];
 	return demod_one(m, z.x, z.y, zp.x, zp.y);
 }
 
@@ -554,6 +562,7 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 	constexpr unsigned int NROW = POST_THREADS / 64u;
 	const float2 *__restrict__ chan_iq = (const float2 *)A.chan_iq;
 	const float2 *__restrict__ prev_iq = (const float2 *)A.prev_iq;
+	const float2 *__restrict__ chan_prev = (const float2 *)A.chan_prev;   /* (uniform: a kernel argument) */
 	const float *__restrict__ dem_hist = A.dem_hist;
 	const float *__restrict__ taps2 = A.taps2;
 	const unsigned int k1 = A.k1, slots = A.slots;
@@ -568,7 +577,7 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 		const size_t first = k1;                        /* the last 63 rows of [history | current] */
 #pragma unroll
 		for (unsigned int r = row; r < WR_HIST; r += NROW)   /* unrolled: one memory round, not eight */
-			A.dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r);
+			A.dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r, chan_prev);
 		if (row == 0)
 			((float2 *)A.prev_next)[s] = k1 ? chan_iq[(size_t)(k1 - 1u) * slots + s] : prev_iq[s];
 		return;
@@ -646,16 +655,23 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 				if (m >= 0 && beg < end) {
 					const size_t rr = r0 + beg;
 					if (rr == WR_HIST)
-						zp = prev_iq[s];
+						zp = chan_prev ? chan_prev[((size_t)k1 - 1u) * slots + s] : prev_iq[s];
 					else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
 						zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
+					else if (rr < WR_HIST && chan_prev)
+						zp = chan_prev[((size_t)k1 - WR_HIST - 1u + rr) * slots + s];
 				}
 #pragma unroll 6
 				for (unsigned int r = beg; r < end; ++r) {
 					const size_t rr = r0 + r;
 					float v = 0.0f;
 					if (m >= 0) {
-						if (rr < WR_HIST) {
+						if (rr < WR_HIST && chan_prev) {
+							/* (streaming launch) a history row = a demodulated frame of the block before, made again */
+							const float2 z = chan_prev[((size_t)k1 - WR_HIST + rr) * slots + s];
+							v = demod_one(m, z.x, z.y, zp.x, zp.y);
+							zp = z;                                 /* (row 62: the predecessor of the block's first frame) */
+						} else if (rr < WR_HIST) {
 							v = dem_hist[rr * slots + s];
 							if (rr + 1u == WR_HIST)
 								zp = prev_iq[s];                    /* the next row is the block's first frame */
@@ -731,6 +747,10 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 				A.audio[(size_t)so * A.k2max + k] = v;
 				if (A.audio_host)                       /* (uniform: a kernel argument) */
 					A.audio_host[(size_t)so * A.host_stride + k] = v;
+			} else if (k < A.k2 && A.audio_host) {
+				/* an idle slot below slots_used: the device array holds zeros there (it is never written), the ring
+				 * slot is page-locked memory that nobody cleared -- a consumer that walks every row reads zeros too */
+				A.audio_host[(size_t)so * A.host_stride + k] = 0.0f;
 			}
 		}
 		TLP(3);
@@ -2811,3 +2831,5 @@ hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t
 	                                                          col_offset_floats, width_floats, dst);
 	return hipGetLastError();
 }
+
+#include "wr_stream_kernel.inc"

@@ -140,6 +140,17 @@ class Tuner:
         """Hold up to n back-to-back device blocks and launch them as one (the same bits, per group)."""
         check(self.lib.wr_tuner_set_blocks_per_launch(self.h, n))
 
+    def streaming(self, enable=True):
+        """Device blocks go to ONE persistent launch through a doorbell (wr_tuner_set_streaming): the same bits,
+        no kernel launch per block.  flush() -- or anything else that touches the tuner -- closes the launch."""
+        check(self.lib.wr_tuner_set_streaming(self.h, 1 if enable else 0))
+
+    def stream_info(self):
+        """(live, launches opened, blocks taken) of the streaming mode"""
+        live, launches, blocks = C.c_int(), C.c_ulonglong(), C.c_ulonglong()
+        check(self.lib.wr_tuner_stream_info(self.h, C.byref(live), C.byref(launches), C.byref(blocks)))
+        return bool(live.value), launches.value, blocks.value
+
     def mark_launches(self, enable=True):
         """every launch that reads a submitted block stamps an event on completion (Ring.exchange_after waits for it)"""
         check(self.lib.wr_tuner_mark_launches(self.h, 1 if enable else 0))
