@@ -101,6 +101,72 @@ def parse():
     return ap.parse_args()
 
 
+def _hip_runtime():
+    import ctypes
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            pass
+    return None
+
+
+def rank_record(torch, dist, rank, local_rank, world, device_index, have, backend, units, seconds, extra=None):
+    """What THIS rank ran on and what it did -- gathered on rank 0 into the JSON line's `ranks`, so that a multi-GPU line
+    says for itself whether N distinct GPUs took part (radio.cxx:56-59: one front end, one tuner, per device): the
+    device's PCI bus id and UUID, whether the ring neighbour's GPU is reachable peer to peer, the RCCL the process
+    loaded and the size of its communicator, and the rank's own rate over its own clock."""
+    import ctypes
+    import socket
+    rec = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid(),
+           "device_index": device_index, "seconds": round(seconds, 6),
+           "msps": round(units / seconds / 1e6, 2) if seconds > 0 else None}
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        rec["device_name"] = p.name
+        rec["device_uuid"] = str(getattr(p, "uuid", "")) or None
+        rec["cus"] = p.multi_processor_count
+    except Exception as e:                                           # (never the reason a measurement is lost)
+        rec["device_error"] = str(e)[:100]
+    hip = _hip_runtime()
+    if hip is not None:
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, device_index) == 0:
+            rec["pci_bus_id"] = buf.value.decode()
+        if world > 1:
+            nb = ((local_rank + 1) % world) % have                   # the device of rank + 1, the halo ring's neighbour
+            can = ctypes.c_int(-1)
+            if nb != device_index and hip.hipDeviceCanAccessPeer(ctypes.byref(can), device_index, nb) == 0:
+                rec["ring_neighbour"] = {"device_index": nb, "peer_access": bool(can.value)}
+            else:
+                rec["ring_neighbour"] = {"device_index": nb, "peer_access": None, "same_device": nb == device_index}
+    rec["backend"] = backend if dist is not None else None
+    if dist is not None:
+        rec["comm_ranks"] = dist.get_world_size()
+        if backend == "nccl":
+            try:
+                rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rec["rccl_version"] = None
+    if extra:
+        rec.update(extra)
+    return rec
+
+
+def gather_ranks(dist, world, rec, backend):
+    """-> (records of all ranks in rank order, are their devices distinct) on every rank; N = 1: just this one"""
+    recs = [rec]
+    if dist is not None and world > 1:
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+    ids = [r.get("pci_bus_id") or "%s/%s" % (r.get("host"), r.get("device_index")) for r in recs]
+    distinct = len(set(ids)) == len(ids)
+    if backend == "nccl" and world > 1 and not distinct:
+        raise SystemExit("bench.py: %d ranks over RCCL on %d distinct GPU(s) (%s): not an %d-GPU measurement"
+                         % (world, len(set(ids)), ", ".join(ids), world))
+    return recs, distinct
+
+
 def _gpu_count(timeout_s=240.0):
     """The number of GPUs torch sees, asked of a CHILD process: the launching process never opens the
     device (it only waits for its ranks), and a runtime that does not come up costs a timeout, not the job."""
@@ -384,7 +450,7 @@ def c1_secondary(torch, dev, steps, settle_ms):
     }
 
 
-def run_c5(args, torch, dist, rank, world, device_index):
+def run_c5(args, torch, dist, rank, world, device_index, local_rank=0, have=1):
     """BASELINE config 5: one synthetic 1 Gsps stream, D1 = 4000, sharded IN TIME.
     Chunk c of T frames belongs to rank c mod world; a rank computes [halo | chunk] from the state
     of a stream that starts at the halo's first frame (wr_tuner_seek: closed-form NCO phase, empty
@@ -424,6 +490,7 @@ def run_c5(args, torch, dist, rank, world, device_index):
     elif world > 1:
         ring = timeshard.RingHalo(dist, rank, world)                 # torch.distributed (gloo: host tensors)
     posted = [None]
+    halo_wait = [0.0, 0]                                             # seconds this rank's host spent waiting for halos, waits
 
     def tail_of(i):
         return bufs[i % nb][2 * T:]                                  # last H frames of round i's [halo | chunk]
@@ -442,14 +509,20 @@ def run_c5(args, torch, dist, rank, world, device_index):
             # round's chunk is submitted and travels while it computes; nothing here waits on the host
             if posted[0] is None:
                 ring.post(tail_of(i), halo_of(i), tuner)
+            tw = time.perf_counter()
             ring.wait()                                     # round i's pair (and rank 0's halo, which came a round earlier)
+            halo_wait[0] += time.perf_counter() - tw
+            halo_wait[1] += 1
             ring.post(tail_of(i + 1), halo_of(i + 1), tuner)
             posted[0] = i + 1
         elif world == 1:
             bufs[(i + 1) % nb][:2 * H].copy_(tail)          # next chunk's halo: a device copy
         else:
             # (gloo -- the two-ranks-on-one-GPU test -- moves host tensors only)
+            tw = time.perf_counter()
             got = ring.exchange(tail if args.backend == "nccl" else tail.cpu())   # from rank - 1: the tail of chunk c - 1 ...
+            halo_wait[0] += time.perf_counter() - tw
+            halo_wait[1] += 1
             if rank == 0:
                 bufs[(i + 1) % nb][:2 * H].copy_(got, non_blocking=False)    # ... which rank 0 needs one round later
             else:
@@ -501,6 +574,11 @@ def run_c5(args, torch, dist, rank, world, device_index):
     barrier()
     launches, ddc_ms = tuner.profile_read()
     tuner.profile(False)
+    ranks, distinct = gather_ranks(dist, world, rank_record(
+        torch, dist, rank, local_rank, world, device_index, have, args.backend, float(T) * args.steps, elapsed,
+        {"launches_timed": launches, "kernel_ms": round(ddc_ms, 5),
+         "ring_exchanges": ring.native.exchanges() if native else halo_wait[1],
+         "halo_wait_us_per_exchange": round(halo_wait[0] / halo_wait[1] * 1e6, 2) if halo_wait[1] else None}), args.backend)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -515,7 +593,7 @@ def run_c5(args, torch, dist, rank, world, device_index):
             "metric": "complex Msamples/sec (node), 256-ch DDC+NFM demod, one 1 Gsps stream time-sharded",
             "value": round(float(T) * args.steps * world / elapsed / 1e6, 2),
             "unit": "complex Msamples/s of the one stream (whole job; halo recomputation not counted)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks": ranks, "devices_distinct": distinct, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
@@ -624,14 +702,16 @@ def main():
             raise SystemExit(3)
 
     if args.workload == "c5":
-        finish(run_c5(args, torch, dist, rank, world, device_index), dist, args.gpus)
+        finish(run_c5(args, torch, dist, rank, world, device_index, local_rank, have), dist, args.gpus)
         return
 
     cfg = synth.C2
     n = cfg["block_frames"]
     ifs = synth.c2_ifs(args.channels)
     # one independent tuner per GPU: its own stream of FM carriers, seed 12345 + tuner index
-    streaming = bool(args.stream) and args.nco == "rotate"
+    # (ranks that SHARE a GPU -- the tests' gloo worlds -- take a launch per block: a streaming launch fills the device, and two
+    # processes' launches on one device can each hold CUs the other waits for; one process per GPU is the deployment)
+    streaming = bool(args.stream) and args.nco == "rotate" and world <= have
     B = 1 if streaming else max(1, args.blocks_per_launch)
     BMAX = max(B, 4)                            # (the secondary four-blocks-per-launch run needs the room)
     nb = max(1, args.resident_blocks)
@@ -711,6 +791,10 @@ def main():
     elapsed, launches, ddc_ms = timed_steps(args.steps, stride)
     frames_per_launch = float(n) * args.steps / n_launches
 
+    ranks, distinct = gather_ranks(dist, world, rank_record(torch, dist, rank, local_rank, world, device_index, have, args.backend,
+                                                            float(n) * args.steps, elapsed,
+                                                            {"launches_timed": launches, "kernel_ms": round(ddc_ms, 5)}),
+                                   args.backend)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -781,6 +865,8 @@ def main():
             "value": round(value, 2),
             "unit": "complex Msamples/s of tuner input (whole job)",
             "n_gpus": world,
+            "ranks": ranks,                       # every rank's device and its own rate over its own clock (rank_record)
+            "devices_distinct": distinct,
             "steps": args.steps,
             "warmup": args.warmup,
             "settle": {"ms": args.settle_ms, "steps": settle_steps,

@@ -18,7 +18,7 @@ NG2_MODULES = ("test_gpu_tuner", "test_gpu_timeshard", "test_gpu_ring", "test_gp
 # Oracle-parity modules first, process-spawning contract tests last: under `-x` a hiccup in a launcher test must not
 # cost the parity run (GPUTEST_r03).
 ORDER = ["test_gpu_blocks", "test_gpu_tuner", "test_gpu_reference_pin", "test_gpu_spectrum", "test_gpu_stage", "test_gpu_f4",
-         "test_gpu_fuzz", "test_gpu_ring", "test_gpu_timeshard", "test_gpu_host", "test_gpu_c_client", "test_gpu_bench"]
+         "test_gpu_fuzz", "test_gpu_ring", "test_gpu_stream", "test_gpu_timeshard", "test_gpu_host", "test_gpu_c_client", "test_gpu_bench"]
 
 PER_TEST_LIMIT_S = 300.0        # no test takes a tenth of this; see the watchdog below
 

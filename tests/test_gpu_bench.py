@@ -35,13 +35,17 @@ def test_single_gpu_line():
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    B = j["config"]["blocks_per_launch"]
-    assert B == 4 and r["frames_per_launch"] == 4.0e6 * B and 4 <= r["launches_timed"] <= 40 // B
-    # the dominant kernel IS the step (the previous block's post stage rides in the same launch); its
-    # event-timed mean covers groups of 8 launches with their gaps
-    assert r["kernel_ms"] <= j["ms_per_step"] * B * 1.05
-    one = j["secondary"]["c2_one_block_per_launch"]
-    assert one["blocks_per_launch"] == 1 and one["value"] > 0 and one["kernel_ms"] <= one["ms_per_step"] * 1.05
+    # r05: the headline is the STREAMING launch -- the 40 timed steps are 40 rings of the doorbell of one persistent launch,
+    # opened by the first and closed by the flush inside the timed region: a block's audio is complete without another
+    # block behind it (dspblock.cxx:169-212), nothing is held back
+    assert j["config"]["streaming"] is True and j["config"]["blocks_per_launch"] == 1
+    assert r["launches_timed"] == 1 and r["frames_per_launch"] == 4.0e6 * 40
+    assert r["kernel_ms"] <= j["ms_per_step"] * 40 * 1.05           # the one launch IS the timed region's GPU work
+    one = j["secondary"]["c2_one_block_per_launch"]                  # a kernel launch per block: r01-r04's like-for-like figure
+    assert one["streaming"] is False and one["blocks_per_launch"] == 1 and one["value"] > 0
+    assert one["kernel_ms"] <= one["ms_per_step"] * 1.05 and j["value_one_block_per_launch"] == one["value"]
+    four = j["secondary"]["c2_four_blocks_per_launch"]               # r02-r04's headline, demoted: up to 120 ms of added latency
+    assert four["blocks_per_launch"] == 4 and four["value"] > 0 and four["launches_timed"] >= 4
     c = j["cpu_baseline"]
     # the reference's own classes where oracle/_ref/libwr_ref_chain.so is there (it is wherever build() ran with
     # /root/reference present), the oracle's port beside it -- the two agree within the noise of a shared memory system
@@ -72,6 +76,39 @@ def test_two_rank_launch_path():
     assert j["n_gpus"] == 2 and "cpu_baseline" not in j
     # whole-job aggregate: two tuners' samples over the slowest rank's time
     assert abs(j["value"] - 2 * 4.0e6 * 4 / (j["ms_per_step"] * 4 / 1e3) / 1e6) / j["value"] < 1e-3
+    _check_ranks(j, 2, "gloo")
+
+
+def _check_ranks(j, world, backend):
+    """r05: the line says for itself what every rank ran on: one record per rank, in rank order, with
+    the device's PCI bus id, the rank's own rate, the communicator's size -- and whether the devices are distinct (two gloo
+    ranks on the test box's one GPU are not, and say so; over RCCL that is an error, not a measurement)."""
+    rk = j["ranks"]
+    assert [r["rank"] for r in rk] == list(range(world))
+    for r in rk:
+        assert r["msps"] > 0 and r["seconds"] > 0 and r["pci_bus_id"] and r["device_name"]
+        assert r["comm_ranks"] == world and r["backend"] == backend
+        assert "ring_neighbour" in r and r["pid"] > 0
+    assert len({r["pid"] for r in rk}) == world                   # one process per rank
+    assert j["devices_distinct"] == (len({r["pci_bus_id"] for r in rk}) == world)
+    # the slowest rank's time is the job's
+    assert max(r["seconds"] for r in rk) <= j["ms_per_step"] * j["steps"] / 1e3 * 1.001 + 1e-6
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_eight_rank_line_on_one_gpu(workload):
+    """BASELINE configs 4 and 5 as far as a one-GPU box can walk them: EIGHT ranks started by bench.py itself (file store,
+    gloo: they share the GPU), each with its own 256-channel tuner (c2) or its chunks of the one stream and a halo from its
+    ring neighbour (c5).  The line carries eight rank records."""
+    extra = ["--workload", "c5"] if workload == "c5" else []
+    out = _proc.output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--settle-ms", "20", "--resident-blocks", "4", "--spawn-timeout", "400",
+                        "--rdzv-timeout", "200"] + extra, cwd=ROOT, env=_plain_env(), timeout=460)
+    j = _line(out)
+    assert j["n_gpus"] == 8 and j["steps"] == 3
+    _check_ranks(j, 8, "gloo")
+    if workload == "c5":
+        assert all(r["ring_exchanges"] >= 3 for r in j["ranks"])
 
 
 def test_c5_workload_line_and_two_rank_ring():
@@ -93,6 +130,8 @@ def test_c5_workload_line_and_two_rank_ring():
     j = _line(out)
     assert j["n_gpus"] == 2
     assert abs(j["value"] - 2 * j["config"]["chunk_frames"] * 3 / (j["ms_per_step"] * 3 / 1e3) / 1e6) / j["value"] < 1e-3
+    _check_ranks(j, 2, "gloo")
+    assert all(r["ring_exchanges"] >= 3 and r["halo_wait_us_per_exchange"] is not None for r in j["ranks"])
 
 
 def test_c5_ranks_take_the_same_number_of_settle_steps():

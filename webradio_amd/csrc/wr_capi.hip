@@ -91,6 +91,7 @@ struct wr_dev {
 	 * kernel ends when it is told to, not by itself: whoever is about to wait for the stream -- or to put work on it
 	 * that must not wait for the stream's idle deadline -- closes it first (dev_stream_sync, dev_settle_stream) */
 	wr_tuner *streaming = nullptr;
+	unsigned long long reg_gen = 1;    /* bumped by every wr_dev_host_register / _unregister */
 };
 #define SCRATCH_GUARD(d) std::lock_guard<std::mutex> scratch_guard_(*(d)->scratch_lock)
 
@@ -173,6 +174,9 @@ struct wr_tuner {
 	std::vector<Group *> groups;
 	float *in_stage;           /* [max_block_frames][2] for WR_HOST submits */
 	int last_staging = 0;      /* how the last WR_HOST block travelled: 0 none yet, 1 copied whole, 2 staged sparsely */
+	const void *probe_ptr = nullptr;   /* the last WR_HOST block found to be PAGEABLE (not asked about again while ... */
+	unsigned long long probe_gen = 0;  /* ... the device's registrations stay as they were: wr_dev::reg_gen) */
+	unsigned int probe_left = 0;
 	float *in_hist[2];         /* [63][2] ping-pong: last 63 IQ frames of the previous block */
 	int in_par;
 	bool submitted;
@@ -553,6 +557,7 @@ extern "C" int wr_dev_host_register(wr_dev *d, void *host, size_t bytes)
 	if (dev_bind(d))
 		return WR_ERR_HIP;
 	SCRATCH_GUARD(d);
+	++d->reg_gen;
 	hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
 	if (e == hipErrorHostMemoryAlreadyRegistered) {
 		(void)hipGetLastError();
@@ -587,6 +592,7 @@ extern "C" int wr_dev_host_unregister(wr_dev *d, void *host)
 	if (own == d->registered->end())
 		return WR_OK;                               /* not page-locked by this library: not ours to release */
 	d->registered->erase(own);
+	++d->reg_gen;
 	hipError_t e = hipHostUnregister(host);
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
@@ -1934,14 +1940,27 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 				}
 			}
 			void *mapped = nullptr;
-			if (same && sd && sd >= 2u * sl && nframes >= 4u * (size_t)sd &&
-			    hipHostGetDevicePointer(&mapped, const_cast<void *>(iq), 0) == hipSuccess && mapped) {
+			if (same && sd && sd >= 2u * sl && nframes >= 4u * (size_t)sd) {
+				/* is the block page-locked?  Asked once per buffer: the same source comes back block after block, and for a
+				 * pageable one the question is a failing runtime call every time.  Only the probe's OWN error is cleared
+				 * (a blanket hipGetLastError() here could swallow the pending error of an earlier asynchronous launch) */
+				if (iq != t->probe_ptr || t->probe_gen != d->reg_gen || !t->probe_left--) {
+					if (hipHostGetDevicePointer(&mapped, const_cast<void *>(iq), 0) != hipSuccess || !mapped) {
+						(void)hipGetLastError();
+						mapped = nullptr;
+						t->probe_ptr = iq;                  /* pageable: remembered until something is page-locked or released
+						                                       through this library (a "yes" is asked again every time: it is cheap,
+						                                       and an address that is no longer mapped must never be used) */
+						t->probe_gen = d->reg_gen;
+						t->probe_left = 64;                 /* (... or until 64 blocks later: the application may page-lock it itself) */
+					}
+				}
+			}
+			if (mapped) {
 				HIP_TRY(wrk_stage_windows(st, mapped, u8, t->in_stage, nframes, sd, sl, sl - 1u));
 				if (int rc = upload_mark(d, st))            /* (wr_dev_wait_uploads: the kernel has read the host block) */
 					return rc;
 				sparse = true;
-			} else {
-				(void)hipGetLastError();
 			}
 		}
 		if (nframes && !sparse)
@@ -2145,6 +2164,10 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 	if (!hist_written)
 		HIP_TRY(wrk_input_hist(st, cur, cur_u8, nframes, t->in_hist[t->in_par], t->in_hist[t->in_par ^ 1]));
 	t->in_par ^= 1;
+	if (t->mark_launches && !marked && !unmarked && nframes)
+		unmarked = true;                            /* (no rate group launched anything, but k_input_hist above reads the block: the
+		                                               completion mark must not be the block-before's -- a halo exchange ordered
+		                                               behind it could overwrite what that kernel is still reading) */
 	if (t->mark_launches && (marked || unmarked)) {
 		/* (a launch that could not stamp it -- profiling, a long channel filter -- or a history kernel behind the DDC:
 		 * an ordinary record, at an ordinary record's price) */
@@ -2197,6 +2220,13 @@ extern "C" int wr_debug_stream_tl(unsigned long long *out, size_t n)
 	memcpy(out, g_stream_tl, n * sizeof(unsigned long long));
 	return 0;
 }
+
+/* ONE streaming launch per GPU and process: every workgroup of such a launch must be resident (they wait for one another),
+ * and two of them on one device -- two wr_dev contexts, two front ends sharing a GPU -- could each hold CUs the other is
+ * waiting for.  A tuner that finds the device taken submits the ordinary way.  (Other PROCESSES on the same GPU are not
+ * seen from here: one process per GPU is the deployment; the launch's own deadlines end a stand-off as an error.) */
+static std::mutex g_stream_mu;
+static wr_tuner *g_stream_on[WR_MAX_DEVICES];
 
 static void stream_free(wr_tuner *t)
 {
@@ -2302,8 +2332,13 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	const unsigned int used = group_slots_used(g), groups = used / 64u;
 	if (!g->one_filter || !groups || groups > 16u)
 		return WR_OK;
-	if (int rc = dev_settle_stream(d))                      /* another tuner's launch on this device */
+	if (int rc = dev_settle_stream(d))                      /* another tuner's launch in this context */
 		return rc;
+	{
+		std::lock_guard<std::mutex> lk(g_stream_mu);
+		if (d->device < 0 || d->device >= WR_MAX_DEVICES || (g_stream_on[d->device] && g_stream_on[d->device] != t))
+			return WR_OK;                                   /* another context's launch holds this GPU: the ordinary way */
+	}
 	if (s.unchecked) {
 		/* the launch before this one must be over before its doorbell is reused */
 		HIP_TRY(dev_stream_sync(d));
@@ -2450,14 +2485,14 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	s.desc[0].cur = (unsigned long long)(uintptr_t)iq;
 	s.desc[0].audio_host = (unsigned long long)(uintptr_t)slot;
 	std::atomic_thread_fence(std::memory_order_seq_cst);
+	/* the counters, the progress words and the doorbell's device-side copy start from zero: one fill.  (Block 0's
+	 * descriptor travels in the kernel's arguments; WrStreamDev::ready stays 0 until the bell republishes a count of 2
+	 * or more -- it is NOT copied from the doorbell here: that copy would run when the stream gets to it, by which time
+	 * the host may have rung again, and the bell, finding the higher count already in device memory, would never bring
+	 * the descriptors over that go with it) */
 	HIP_TRY(hipMemsetAsync(s.sdev, 0, offsetof(WrStreamDev, desc), st));
-	HIP_TRY(hipMemcpyAsync(&s.sdev->desc[0], &s.desc[0], sizeof(WrStreamDesc), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(&s.sdev->cur[0], 0, sizeof(unsigned long long), st));
-	HIP_TRY(hipMemcpyAsync(&s.sdev->cur[1], &s.desc[0].cur, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-	/* (WrStreamDev::ready stays 0 until the bell republishes a count of 2 or more: block 0 is known to every wave
-	 * from the start.  It is NOT copied from the doorbell here: that copy would run when the stream gets to it, by
-	 * which time the host may have rung again -- and the bell, finding the higher count already in device memory,
-	 * would never bring the descriptors over that go with it) */
+	A.cur0 = s.desc[0].cur;
+	A.audio0 = s.desc[0].audio_host;
 
 	void *ev0 = nullptr, *ev1 = nullptr;
 	if (t->profiling) {
@@ -2485,6 +2520,10 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	++s.blocks;
 	s.last_bell = std::chrono::steady_clock::now();
 	d->streaming = t;
+	{
+		std::lock_guard<std::mutex> lk(g_stream_mu);
+		g_stream_on[d->device] = t;
+	}
 	*took = true;
 	return WR_OK;
 }
@@ -2503,6 +2542,11 @@ static int stream_close(wr_tuner *t)
 	s.unchecked = true;
 	if (t->dev->streaming == t)
 		t->dev->streaming = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_stream_mu);
+		if (g_stream_on[t->dev->device] == t)
+			g_stream_on[t->dev->device] = nullptr;
+	}
 	Group *g = s.g;
 	const unsigned int J = s.count;
 	for (Group *x : t->groups)
@@ -2881,7 +2925,8 @@ extern "C" int wr_tuner_audio_ring_acquire(wr_tuner *t, const float **audio_host
 			return fail(WR_ERR_HIP, "wr_tuner_audio_ring_acquire: the streaming launch reported error %u", t->stream.ctl->err);
 		}
 	} else {
-		e = hipEventSynchronize(ev);
+		e = hipEventSynchronize(ev);        /* (looking at the event ourselves first -- hipEventQuery in a loop -- changes nothing:
+		                                       what an on-time caller waits for here is the GPU, not the wake-up; r05) */
 	}
 	if (e != hipSuccess) {
 		std::lock_guard<std::mutex> lk(t->ring_lock);

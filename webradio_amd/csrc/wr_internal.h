@@ -15,6 +15,7 @@
 #define WR_HIST      (WR_FIR_LENGTH - 1)   /* 63 frames of FIR history, lowpass.cxx:133 */
 #define WR_LANES     64                    /* wavefront width on gfx950 */
 #define WR_SPLIT_N   256                   /* entries of the coarse and of the fine NCO table */
+#define WR_MAX_DEVICES 64                  /* device indices the per-device tables of this library hold */
 #define WR_TAPSETS   4                     /* distinct channel filters a lane group may mix in the fast DDC kernel:
                                               receivers of one tuner mostly share a passband (radio.cxx:78-79),
                                               the UI lets each choose its own (receiverhandler.cxx:130-137) */
@@ -191,7 +192,7 @@ hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t
  * windows; the ragged end) are paid once per STREAM, not once per block, and a block's post stage starts the moment
  * its last channel-IQ row is out, whether or not another block follows (dsp/dspblock.cxx:169-212: a block's output
  * leaves within its own run()).  See k_tuner_stream in wr_kernels.hip. ---- */
-#define WR_STREAM_MAXJ   1024u             /* blocks one streaming launch takes at most (the host then opens the next) */
+#define WR_STREAM_MAXJ   512u             /* blocks one streaming launch takes at most (the host then opens the next) */
 #define WR_STREAM_RING   8u                /* blocks of channel IQ the ring between the DDC waves and the post stage holds */
 struct WrStreamDesc {                      /* one submitted block */
 	unsigned long long cur;                /* device address of its frames (float pairs, or byte pairs) */
@@ -236,6 +237,9 @@ struct WrStreamArgs {
 	unsigned int        n_ddc, n_post;     /* workgroups per role; one more rings the bell */
 	unsigned int        dbg;               /* development switches (WR_STREAM_DBG): results are wrong with any of them set */
 	unsigned long long *tl;                /* WR_STREAM_DBG & 16: [wave][8] cycle counts of the DDC waves (development aid) */
+	unsigned long long  cur0, audio0;      /* block 0's descriptor (the launch exists because of it): here, not copied to
+	                                          device memory ahead of the launch -- two small copies on the stream cost the
+	                                          open 25 us; the bell wave puts it into WrStreamDev for whoever needs it later */
 	/* the block shape (every block of a stream has it) */
 	unsigned long long  nframes;           /* input frames per block, = k1 * d1 */
 	unsigned int        k1, d1, is_u8;

@@ -2196,7 +2196,6 @@ __global__ void k_gather_rows(const float *__restrict__ src, size_t rows, size_t
 /* hipFuncAttributeMaxDynamicSharedMemorySize is a per-device setting of the loaded code object:
  * a process that drives several GPUs (the host runtime gives every tuner its own) has to set
  * it once on each.  `done` is the call site's own flag array. */
-#define WR_MAX_DEVICES 64
 static hipError_t allow_lds(const void *fn, size_t bytes, bool (&done)[WR_MAX_DEVICES])
 {
 	int dev = 0;

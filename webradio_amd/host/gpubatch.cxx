@@ -9,6 +9,8 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <stdio.h>
 
 #include "debug.h"
 #include "demodulator.h"
@@ -489,11 +491,24 @@ void DevBuf::release()
 
 /* ------------------------------------------------------------------ TunerBatch -- */
 
+/* WEBRADIO_TIMES=1 (measurement only): where the wall time of an on-time block goes inside the batch -- averaged and printed
+ * when the batch goes (profiles/r05_host_times.txt) */
+static const bool g_times = getenv("WEBRADIO_TIMES") && atoi(getenv("WEBRADIO_TIMES")) != 0;
+static double g_tacc[8];
+static unsigned long g_tn;
+static double g_tlast;
+static inline double nowUs()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
 	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateDepth(envUnsigned("WEBRADIO_AUDIO_LATE", 0) >= 2 ? 2u : 1u),
-	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false)
+	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false), _submits(0), _partSeq0(0)
 {
 	if (_pieces < 1 || _late)
 		_pieces = 1;
@@ -503,6 +518,10 @@ TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 
 TunerBatch::~TunerBatch()
 {
+	if (g_times && g_tn)
+		fprintf(stderr, "WEBRADIO_TIMES, us per block over %lu blocks: walk+source %.1f | stage enqueued %.1f | submits+flush %.1f (from the submit's start) | "
+		        "wait part 0 %.1f copy %.1f | wait part 1 %.1f copy %.1f\n", g_tn, g_tacc[0] / g_tn, g_tacc[1] / g_tn, g_tacc[2] / g_tn,
+		        g_tacc[3] / g_tn, g_tacc[4] / g_tn, g_tacc[5] / g_tn, g_tacc[6] / g_tn);
 	if (_tuner)
 		wr_tuner_destroy(_tuner);
 }
@@ -616,6 +635,7 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 2 + batch->_lateDepth : 1 + (batch->_pieces > 1 ? batch->_pieces : 1));
 		batch->_lateQueued = false;
 		batch->_lateSeq = 0;
+		batch->_submits = 0;                    /* a new tuner numbers its submits from 0 again */
 	}
 	int id = -1;
 	if (wr_chan_add(batch->_tuner, &id) != WR_OK) {
@@ -760,9 +780,14 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 	/* (r04) Where every receiver decimates alike and by at least twice its channel filter's length, only the frames under
 	 * the taps are brought over (stagedSparse): a sixth of the block at BASELINE config 2 -- and no transfer to wait for. */
 	unsigned int sp = 0, sl = 0;
+	const double tt0 = g_times ? nowUs() : 0.0;
+	if (g_times && g_tlast > 0.0)
+		g_tacc[0] += tt0 - g_tlast;                 /* from the end of the last collectParts to this submit: the walk + the source */
 	if (!pushed && sparseWindows(&sp, &sl)) {
 		wr_dev *sdev = NULL;
 		const float *staged = stagedSparse(_channels[0]->mixer, tunerBuffer, &sdev, sp, sl, sl - 1u);
+		if (g_times)
+			g_tacc[1] += nowUs() - tt0;             /* staging enqueued */
 		if (staged && sdev == _dev) {
 			/* on time, the staged block goes through in P parts all the same: a part's audio is put where the audio
 			 * filters' consumers will read it while the parts behind it compute (collectParts) */
@@ -770,13 +795,21 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 			for (unsigned int p = 0; p < parts; p++)
 				if (wr_tuner_submit(_tuner, staged + (size_t)2 * (nframes / parts) * p, nframes / parts, WR_DEVICE) != WR_OK) {
 					LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
+					if (p)
+						drainRing();                /* the parts that did go out must not be taken for the next block's */
 					return false;
+				} else {
+					if (!p)
+						_partSeq0 = _submits;
+					++_submits;
 				}
 			if (parts == 1)
 				return afterSubmit(false);
 			++_lateSeq;
 			wr_tuner_flush(_tuner);
 			traceAdd(_source, 'S');
+			if (g_times)
+				g_tacc[2] += nowUs() - tt0;         /* ... parts submitted and flushed */
 			return collectParts(parts);
 		}
 	}
@@ -793,8 +826,13 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 			}
 			if (wr_tuner_submit(_tuner, part, nframes / P, WR_DEVICE) != WR_OK) {
 				LOG_ERROR("wr_tuner_submit (part %u of %u): %s\n", p, P, wr_last_error());
+				if (p)
+					drainRing();
 				return false;
 			}
+			if (!p)
+				_partSeq0 = _submits;
+			++_submits;
 		}
 	}
 	if (P > 1) {
@@ -829,6 +867,7 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
+	++_submits;
 	return afterSubmit(pushed);
 }
 
@@ -998,7 +1037,10 @@ unsigned int TunerBatch::piecesFor(unsigned int nframes)
 /* the audio of the P parts just submitted, in order: each part's rows are copied out of the tuner's pinned ring as soon as
  * they are there -- straight into the audio filters' output vectors where those already have the block's size (the steady
  * state: LowPass::process then has nothing left to copy), else into _audio for audio() to slice -- while the parts behind
- * it are still being worked on */
+ * it are still being worked on.  r05: a ring entry that is not the part expected -- a leftover of a run() that failed half
+ * way -- is an error, not somebody else's audio.  (Helper threads for the copies were tried and taken out again: 256 rows of
+ * 4 KB per part are 30-40 us of one core, but what an on-time block waits for is the GPU -- WEBRADIO_TIMES=1 says where the
+ * time goes: profiles/r05_host_times.txt.) */
 bool TunerBatch::collectParts(unsigned int P)
 {
 	size_t off = 0, total = 0;
@@ -1008,10 +1050,15 @@ bool TunerBatch::collectParts(unsigned int P)
 		size_t stride = 0, frames = 0;
 		unsigned int slots = 0;
 		unsigned long long seq = 0;
+		const double ta = g_times ? nowUs() : 0.0;
 		if (wr_tuner_audio_ring_acquire(_tuner, &ptr, &stride, &frames, &slots, &seq) != WR_OK) {
 			LOG_ERROR("audio of part %u of %u: %s\n", p, P, wr_last_error());
+			drainRing();
 			return false;
 		}
+		const double tb = g_times ? nowUs() : 0.0;
+		if (g_times)
+			g_tacc[p ? 5 : 3] += tb - ta;           /* waiting for the part's audio */
 		if (p == 0) {
 			total = frames * P;
 			for (size_t n = 0; n < _channels.size() && direct; n++)
@@ -1021,9 +1068,12 @@ bool TunerBatch::collectParts(unsigned int P)
 				_audio.resize((size_t)slots * total + 1);
 			_audioSlots = slots;
 		}
-		if (frames * P != total || slots != _audioSlots) {
+		/* the tuner numbers its submits from 0: part p of this block is submit _partSeq0 + p */
+		if (frames * P != total || slots != _audioSlots || seq != _partSeq0 + p) {
 			wr_tuner_audio_ring_release(_tuner);
-			LOG_ERROR("part %u of %u came back with %zu frames, the first with %zu\n", p, P, frames, total / P);
+			LOG_ERROR("part %u of %u came back as submit %llu with %zu frames (expected submit %llu, %zu frames): stale ring entries\n",
+			          p, P, seq, frames, _partSeq0 + p, total / P);
+			drainRing();
 			return false;
 		}
 		if (direct) {
@@ -1036,6 +1086,12 @@ bool TunerBatch::collectParts(unsigned int P)
 		}
 		wr_tuner_audio_ring_release(_tuner);
 		off += frames;
+		if (g_times)
+			g_tacc[p ? 6 : 4] += nowUs() - tb;      /* copying it out */
+	}
+	if (g_times) {
+		g_tlast = nowUs();
+		++g_tn;
 	}
 	_ringHeld = false;
 	_audioFrames = total;
@@ -1047,6 +1103,25 @@ bool TunerBatch::collectParts(unsigned int P)
 	}
 	_submitOk = true;
 	return true;
+}
+
+/* whatever is queued in the tuner's audio ring goes: after an error half way through a block its entries would be taken
+ * for the next block's parts */
+void TunerBatch::drainRing()
+{
+	wr_tuner_flush(_tuner);
+	for (;;) {
+		unsigned int queued = 0;
+		if (wr_tuner_audio_ring_stats(_tuner, &queued, NULL) != WR_OK || !queued)
+			break;
+		const float *ptr = NULL;
+		size_t stride = 0, frames = 0;
+		unsigned int slots = 0;
+		if (wr_tuner_audio_ring_acquire(_tuner, &ptr, &stride, &frames, &slots, NULL) != WR_OK)
+			break;
+		wr_tuner_audio_ring_release(_tuner);
+	}
+	_ringHeld = false;
 }
 
 bool TunerBatch::audio(const Channel *ch, vector<sample_t> &out)

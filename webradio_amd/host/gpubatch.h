@@ -133,6 +133,7 @@ private:
 	bool sparseWindows(unsigned int *period, unsigned int *length);
 	bool afterSubmit(bool pushed);
 	bool collectParts(unsigned int parts);
+	void drainRing();
 
 	DspSource *_source;
 	wr_dev *_dev;
@@ -155,6 +156,8 @@ private:
 	unsigned int _pieces;             /* WEBRADIO_PIECES: parts an on-time block is put through in (see submitOnce) */
 	bool _delivered;                  /* this block's audio already lies in the audio filters' output vectors */
 	std::mutex _lock;
+	unsigned long long _submits;      /* wr_tuner_submit calls that went through on _tuner: the tuner numbers its ring entries so */
+	unsigned long long _partSeq0;     /* ... the first part of the block collectParts is about to collect */
 };
 
 } // namespace wrhost
