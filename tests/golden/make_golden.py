@@ -7,10 +7,9 @@
                         oracle/ref_harness.cxx), all four modes, 8 blocks of 512 frames.
   dspblock_traces.json  scheduling traces of the REAL reference DspBlock runtime
                         (dsp/dspblock.cxx) for the scenarios of oracle/ref_harness.cxx.
-  oracle_selfcheck_c1.npz  regression vectors of the ORACLE for the functions whose
-                        reference sources cannot be built here (<fftw3.h> missing):
-                        C1-style single receiver, 4 blocks.  These pin the oracle to
-                        itself over time, NOT to the reference ("parity unpinned").
+(r01-r04 also wrote oracle_selfcheck_c1.npz here -- the ORACLE's outputs for BASELINE config 1's capture, a
+self-check.  r05: the capture goes through the REAL reference chain instead, on the GPU box:
+tests/golden/make_c1_reference_golden.py -> reference_c1.npz; the capture itself is synth.rtl_u8_stream(4 * 16384).)
 Only data is written; no reference source text is stored.
 """
 import json
@@ -45,21 +44,6 @@ def main():
     traces = [o.harness_trace(R, i) for i in range(R.wr_harness_scenarios())]
     json.dump(traces, open(os.path.join(HERE, "dspblock_traces.json"), "w"), indent=0)
 
-    c1 = synth.C1
-    n = 16384
-    rx = o.Receiver(c1["input_rate"], c1["if_hz"], c1["chan_passband"], c1["chan_rate"], o.FM,
-                    c1["audio_passband"], c1["audio_rate"])
-    u8 = synth.rtl_u8_stream(4 * n)
-    iqf = o.u8_to_float(u8)
-    audio, chan = [], []
-    for b in range(4):
-        a, c, _ = rx.run(iqf[2 * n * b: 2 * n * (b + 1)])
-        audio.append(a)
-        chan.append(c)
-    np.savez_compressed(os.path.join(HERE, "oracle_selfcheck_c1.npz"), u8=u8, audio=np.concatenate(audio),
-                        chan_iq=np.concatenate(chan), block_frames=n,
-                        taps_chan=o.lowpass_design(c1["chan_passband"], c1["input_rate"]),
-                        taps_audio=o.lowpass_design(c1["audio_passband"], c1["chan_rate"]))
     print("golden fixtures written to", HERE)
     return 0
 

@@ -398,12 +398,12 @@ np.savez(out, rc=rc, audio=audio[:n.value], left=L.wr_host_registry_sizes())
 
 @pytest.mark.parametrize("with_frontend", [1, 0])
 def test_c1_recorded_rtlsdr_file(tmp_path, oracle, with_frontend):
-    """BASELINE config 1 end to end: FileTuner replays an RTL-SDR format recording (the capture and
-    the ORACLE's outputs for it, oracle_selfcheck_c1.npz -- a self-check, not a reference pin), one
+    """BASELINE config 1 end to end: FileTuner replays an RTL-SDR format recording (the capture and what the REAL
+    reference chain gave for it: tests/golden/reference_c1.npz, see test_gpu_tuner.py::test_c1_single_receiver_u8_file), one
     DownConverter + FM Receiver.  The recording's bytes are staged on the device once per block (2 bytes per
     frame over PCIe) and converted there for SpectrumSink and receiver alike."""
     lib = os.path.join(CXXT, "libwr_host_pipeline.so")
-    g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_selfcheck_c1.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_c1.npz"))
     c1 = synth.C1
     n = int(g["block_frames"])
     path = str(tmp_path / "capture.bin")

@@ -119,13 +119,15 @@ def test_fast_nco_modes_within_tolerance(dev, oracle, nco):
 
 
 def test_c1_single_receiver_u8_file(dev, oracle):
-    """BASELINE config 1: one DownConverter + FM demod off an RTL-SDR format (u8) capture, against
-    oracle_selfcheck_c1.npz.  That file holds outputs of OUR oracle (DownConverter / LowPass cannot be
-    built from the reference here: no FFTW) -- it guards against drift of oracle and kernels over
-    time and is NOT a pin to the reference; the pinned pieces are in demod_reference.npz and
-    dspblock_traces.json."""
+    """BASELINE config 1: one DownConverter + FM demod off an RTL-SDR format (u8) capture, against what the REAL reference
+    chain gave for the same bytes (tests/golden/reference_c1.npz: io/rtlsdrtuner.cxx:106's conversion, then the reference's
+    own DownConverter -> LowPass -> Demodulator -> LowPass wired as radio.cxx:68-83, run on the GPU box through
+    oracle/_ref/libwr_ref_chain.so by tests/golden/make_c1_reference_golden.py).  The EXACT mode repeats the reference's
+    arithmetic operation for operation -- and for THESE passbands the reference's taps (a 64-point inverse DFT in f32) and
+    ours (a closed form accumulated in double) are the same floats: the channel IQ is the reference's bit for bit, the
+    audio within the in-kernel atan2's distance from glibc's (the generator prints oracle - reference = 0, 0, 0)."""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_selfcheck_c1.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_c1.npz"))
     c1 = synth.C1
     n = int(g["block_frames"])
     iq = oracle.u8_to_float(g["u8"])
@@ -140,6 +142,7 @@ def test_c1_single_receiver_u8_file(dev, oracle):
             chan.append(t.fetch(ch, capi.WR_STAGE_CHAN_IQ, 2 * n))
         audio, chan = np.concatenate(audio), np.concatenate(chan)
         t.destroy()
+        assert chan.shape == g["chan_iq"].shape and audio.shape == g["audio"].shape
         if exact:
             assert np.array_equal(chan.view(np.uint32), g["chan_iq"].view(np.uint32))
             assert np.abs(audio - g["audio"]).max() <= 2 * FM_ATOL

@@ -81,3 +81,27 @@ def test_spectrum_db(oracle, gold, name):
     assert int(np.argmax(got)) == int(np.argmax(want))
     if name == "n512_tone":
         assert int(np.argmax(want)) == 277                    # SURVEY 8a's probe: 256 + 21
+
+
+def test_c1_capture_against_the_reference(oracle):
+    """BASELINE config 1: the recorded RTL-SDR capture (131 072 bytes, io/rtlsdrtuner.cxx:106's (u8 - 128) / 128) through the
+    oracle's Receiver against what the REAL DownConverter -> LowPass -> Demodulator -> LowPass gave for it on the GPU box
+    (tests/golden/reference_c1.npz, made by tests/golden/make_c1_reference_golden.py).  r01-r04 compared the C1 tests'
+    results with the oracle's own output for this capture; they compare with the reference's now."""
+    from webradio_amd import synth
+    path = os.path.join(os.path.dirname(GOLDEN), "reference_c1.npz")
+    assert os.path.exists(path), "tests/golden/reference_c1.npz is missing (make_c1_reference_golden.py, on the GPU box)"
+    g = np.load(path)
+    c1, n = synth.C1, int(g["block_frames"])
+    iq = oracle.u8_to_float(g["u8"])
+    rx = oracle.Receiver(c1["input_rate"], c1["if_hz"], c1["chan_passband"], c1["chan_rate"], oracle.FM, c1["audio_passband"],
+                         c1["audio_rate"])
+    audio, chan, dem = [], [], []
+    for b in range(iq.size // 2 // n):
+        a, z, d = rx.run(iq[2 * n * b: 2 * n * (b + 1)])
+        audio.append(a), chan.append(z), dem.append(d)
+    for got, key, tol in ((np.concatenate(chan), "chan_iq", refcases.CHAN_TOL), (np.concatenate(dem), "demod", refcases.AUDIO_TOL),
+                          (np.concatenate(audio), "audio", refcases.AUDIO_TOL)):
+        assert got.shape == g[key].shape and g[key].size > 0, key
+        assert np.abs(got - g[key]).max() <= tol, (key, float(np.abs(got - g[key]).max()))
+    assert np.abs(g["audio"]).max() > 1e-3
