@@ -856,8 +856,12 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.channels == 256 and args.nco == tj.get("nco", "split") and tj.get("frames_per_launch", n) == nl:
-                traffic = tj["hbm_bytes_per_launch"]
+            if args.channels == 256 and args.nco == tj.get("nco", "split"):
+                if streaming and "streaming" in tj:
+                    # one streaming launch's bytes grow with the blocks it takes: the committed figure is per block
+                    traffic = int(round(tj["streaming"]["hbm_bytes_per_block"] * args.steps))
+                elif not streaming and tj.get("frames_per_launch", n) == nl:
+                    traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         out = {
@@ -916,7 +920,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic,
-                "traffic_unit": "bytes per launch, PMC FETCH_SIZE+WRITE_SIZE (profiles/traffic.json)",
+                "traffic_unit": "bytes per launch, PMC 2 x FETCH_SIZE + WRITE_SIZE (profiles/traffic.json: gfx950 tallies every 128-byte "
+                                "read request at 64 bytes, whatever the load width -- profiles/r05_fetch_calibration.txt)",
                 "kernel_ms": round(ddc_ms, 5),
                 "launches_timed": launches,
                 "timing": "HIP events on the launch stream inside the timed region, one pair around every %d consecutive "

@@ -5,7 +5,7 @@
 #                                            clock settling and the timed steps)
 #   gpurun_out/<round>_kernel_stats_timed.csv   the same trace, the timed region's launches only
 #   gpurun_out/<round>_pmc_fetch_size.txt / _pmc_write_size.txt   FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
-round=${1:-r04}
+round=${1:-r05}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R && python bench.py > gpurun_out/${round}_bench.json 2> gpurun_out/${round}_bench.err
@@ -45,17 +45,28 @@ for _, name, wgs, d in rows:
 with open(R + '/gpurun_out/%s_kernel_stats_timed.csv' % r, 'w') as f:
     w = csv.writer(f); w.writerow(['Name', 'Workgroups', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'Last15AverageNs'])
     for (name, wgs), d in sorted(g.items()):
-        if len(d) < 3 and not name.startswith('k_fft'):
+        if len(d) < 3 and not name.startswith(('k_fft', 'k_tuner_stream')):
             continue
         last = d[-16:-1] if len(d) > 40 else d
         w.writerow([name, wgs, len(d), '%.1f' % (sum(d) / len(d)), min(d), max(d), '%.1f' % (sum(last) / len(last))])
 PY
+# PMC passes (separate runs, --kernel-trace only beside --pmc):
+#   "stream": the headline's kernel -- ONE streaming launch of $SB blocks (no warm-up, no settling steps: the byte counters do
+#             not care about the clock), so that bytes per launch / $SB = bytes per block
+#   ""      : bench.py --no-stream --blocks-per-launch 4 -- k_tuner_ddc in its four-block and (secondary) one-block shapes, the FFT passes
+SB=24
+echo $SB > $R/gpurun_out/${round}_pmc_stream_blocks.txt
+for variant in stream ""; do
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
-  python3 - "$c" "$round" <<'PY'
+  if [ "$variant" = "stream" ]; then
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps $SB --warmup 0 --settle-ms 0 --no-secondary --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  else
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --no-stream --blocks-per-launch 4 --steps 12 --warmup 2 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  fi
+  python3 - "$c" "$round" "$variant" <<'PY'
 import csv, sys, glob, collections, os
-c, r = sys.argv[1], sys.argv[2]; R = os.environ['GRAFT_REPO_ROOT']
+c, r, variant = sys.argv[1], sys.argv[2], sys.argv[3]; R = os.environ['GRAFT_REPO_ROOT']
 acc = collections.defaultdict(list)
 for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
     for row in csv.DictReader(open(f)):
@@ -63,12 +74,14 @@ for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True)
         wgs = int(row.get('Grid_Size', 0) or 0) // max(1, int(row.get('Workgroup_Size', 1) or 1))
         if k.startswith(('k_', 'void k_')):
             acc['%s [%d workgroups]' % (k, wgs)].append(float(row['Counter_Value']))
-with open(R + '/gpurun_out/%s_pmc_%s.txt' % (r, c.lower()), 'w') as out:
+name = '%s_pmc_%s%s.txt' % (r, 'stream_' if variant else '', c.lower())
+with open(R + '/gpurun_out/' + name, 'w') as out:
     for k, v in sorted(acc.items()):
-        if len(v) < 3 and 'k_fft' not in k:
+        if len(v) < 3 and 'k_fft' not in k and 'k_tuner_stream' not in k:
             continue
         out.write('%s %s mean=%.1f KB per launch (n=%d)\n' % (k, c, sum(v) / len(v), len(v)))
 PY
+done
 done
 # profiles/traffic.json (what bench.py quotes as roofline.traffic) from the two PMC dumps: no hand step
 python3 $R/tools/make_traffic.py $round
