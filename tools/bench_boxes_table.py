@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r04_bench_boxes.txt from the per-box files tools/bench_box.sh left in gpurun_out/ (one fresh lease each):
+"""profiles/r05_bench_boxes.txt from the per-box files tools/bench_box.sh left in gpurun_out/ (one fresh lease each):
 the driver's invocation `python bench.py --steps 20 --warmup 5` on the boxes of the pool."""
 import glob
 import json
@@ -8,23 +8,26 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
-for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r04_box_*.json"))):
+for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r05_box_*.json"))):
     try:
         j = json.loads([l for l in open(path) if l.startswith("{")][-1])
     except Exception:
         continue
     hf = {(r.get("source", "")[:3], r.get("audio", "")[:7], r.get("staging", "")[:6]): r.get("ms_per_block")
           for r in (j.get("secondary", {}).get("host_fed") or {}).get("runs", [])}
-    rows.append((os.path.basename(path)[8:-5], j["value"] / 1e3, j["roofline"]["kernel_ms"] * 1e3, j["roofline"]["frac"],
-                 j["value_one_block_per_launch"] / 1e3, j["secondary"]["c3"]["ms_per_block"] * 1e3,
-                 j["secondary"]["c3"]["roofline"]["frac"], hf.get(("u8 ", "on time", "sparse")), hf.get(("f32", "on time", "sparse"))))
+    sec = j.get("secondary", {})
+    rows.append((os.path.basename(path)[8:-5], j["value"] / 1e3, j["ms_per_step"] * 1e3, j["roofline"]["kernel_ms"] * 1e3,
+                 j["roofline"]["frac"], j["value_one_block_per_launch"] / 1e3,
+                 (sec.get("c2_four_blocks_per_launch") or {}).get("value", 0.0) / 1e3, sec["c3"]["ms_per_block"] * 1e3,
+                 sec["c3"]["roofline"]["frac"], hf.get(("u8 ", "on time", "sparse")), hf.get(("f32", "on time", "sparse"))))
 out = ["python bench.py --steps 20 --warmup 5 --no-cpu-baseline, one fresh lease per row (tools/bench_box.sh; this table: tools/bench_boxes_table.py)",
-       "box (UTC)          Gsps    4-block launch us   frac    1 block/launch Gsps   C3 us/block  C3 frac   host on time ms: u8 / f32"]
+       "r05: `value` = the streaming launch (20 blocks through ONE persistent launch, opened and closed inside the timed region)",
+       "box (UTC)          Gsps   us/step   the launch us   frac    launch per block Gsps   4 blocks/launch Gsps   C3 us/block  C3 frac   host on time ms: u8 / f32"]
 for r in rows:
-    out.append("%-16s %7.1f %12.1f %13.4f %12.1f %17.1f %9.4f      %s / %s" % r)
+    out.append("%-16s %7.1f %8.2f %12.1f %10.4f %14.1f %22.1f %15.1f %9.4f      %s / %s" % r)
 if rows:
     v = [r[1] for r in rows]
     out.append("%d boxes: %.1f-%.1f Gsps, mean %.1f" % (len(v), min(v), max(v), sum(v) / len(v)))
 text = "\n".join(out) + "\n"
 sys.stdout.write(text)
-open(os.path.join(ROOT, "profiles", "r04_bench_boxes.txt"), "w").write(text)
+open(os.path.join(ROOT, "profiles", "r05_bench_boxes.txt"), "w").write(text)
