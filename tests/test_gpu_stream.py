@@ -255,3 +255,100 @@ def test_streaming_at_c2_size(dev):
     assert one.shape == many.shape == (256, nblk * n // 400 // 5)
     assert np.array_equal(_bits(one), _bits(many))
     assert float(np.abs(one[::4]).max()) > 0.0                  # the carrier channels carry audio
+
+
+RATES = [(2_000_000, 250_000, 50_000), (2_400_000, 240_000, 48_000), (1_920_000, 240_000, 24_000), (2_048_000, 256_000, 32_000)]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("WR_FUZZ_SEEDS", "10"))))
+def test_random_streams_with_streaming(dev, seed):
+    """The streaming launch under a random stream of calls (after tests/test_gpu_fuzz.py's blocks-per-launch fuzz): the same
+    sequence of submits (device blocks of the usual size, of another size, out of host memory), setters (IF, mode, a channel
+    filter of its own, af_gain), flushes and state reads goes through a tuner that launches every block on its own and one
+    with wr_tuner_set_streaming on -- which streams what it may and closes the launch for everything else.  Everything either
+    hands out through the audio ring, laid end to end, is the same bits; so are the NCO phases read on the way."""
+    import torch
+    rng = np.random.default_rng(9100 + seed)
+    fs, crate, arate = RATES[seed % len(RATES)]
+    d1, d2 = fs // crate, crate // arate
+    q = d1 * d2                                             # frames per audio frame
+    nchan = int(rng.choice([3, 64, 130, 200]))
+    whole = q * int(rng.integers((64 + d2 - 1) // d2, (64 + d2 - 1) // d2 + 6))     # >= 64 channel-rate frames: streams
+    total = whole * 36
+    ifs = [int(v) for v in rng.integers(-fs // 2 + 1, fs // 2, nchan)]
+    iq = synth.fm_stream(total, fs, ifs[:3], amp=0.15, fm_base=fs / 70_000.0, beta=2.0, seed=seed)
+    x = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    modes = [int(m) for m in rng.integers(0, 4, nchan)]
+
+    ops, pos = [], 0
+    while pos + 2 * whole < total and len(ops) < 60:
+        r = rng.random()
+        if r < 0.70:
+            ops.append(("dev", pos, whole)); pos += whole
+        elif r < 0.76:                                      # another size (whole audio frames): a launch of its own
+            n = whole + q * int(rng.integers(1, 3))
+            ops.append(("dev", pos, n)); pos += n
+        elif r < 0.80:                                      # ragged: not a whole number of audio frames -- never streamed
+            n = whole + int(rng.integers(1, q))
+            ops.append(("dev", pos, n)); pos += n
+        elif r < 0.84:
+            ops.append(("host", pos, whole)); pos += whole
+        elif r < 0.90:
+            ops.append(("set_if", int(rng.integers(0, nchan)), int(rng.integers(-fs // 2 + 1, fs // 2))))
+        elif r < 0.93:
+            ops.append(("set_mode", int(rng.integers(0, nchan)), int(rng.integers(0, 4))))
+        elif r < 0.95 and seed % 3 == 2:                    # (a third of the seeds: a filter of its own ends the streaming for good)
+            ops.append(("set_filter", int(rng.integers(0, nchan)), int(rng.choice([fs // 40, fs // 8]))))
+        elif r < 0.96:
+            ops.append(("gain", int(rng.integers(0, nchan)), float(rng.choice([-6.0, 0.0, 3.5]))))
+        elif r < 0.98:
+            ops.append(("flush",))
+        else:
+            ops.append(("state", int(rng.integers(0, nchan))))
+
+    def play(stream):
+        t = Tuner(dev, fs, nchan, whole + 3 * q, capi.WR_NCO_ROTATE)
+        chans = [t.add_receiver(f, fs // 16, crate, m, crate // 8, arate) for f, m in zip(ifs, modes)]
+        t.audio_ring(128)
+        t.streaming(stream)
+        rows, states = [], []
+
+        def drain():
+            while t.ring_stats()[0]:
+                a, _ = t.ring_acquire()
+                rows.append(a.copy())
+                t.ring_release()
+        for op in ops:
+            if op[0] == "dev":
+                t.submit_device(x[2 * op[1]: 2 * (op[1] + op[2])], op[2])
+            elif op[0] == "host":
+                t.submit_host(iq[2 * op[1]: 2 * (op[1] + op[2])])
+            elif op[0] == "set_if":
+                t.set_if(chans[op[1]], op[2])
+            elif op[0] == "set_mode":
+                t.set_mode(chans[op[1]], op[2])
+            elif op[0] == "set_filter":
+                t.set_filter(chans[op[1]], 0, op[2], crate)
+            elif op[0] == "gain":
+                t.set_af_gain(chans[op[1]], op[2])
+            elif op[0] == "flush":
+                t.flush()
+            elif op[0] == "state":
+                states.append(t.state(chans[op[1]])[0])
+            drain()
+        t.flush()
+        dev.sync()
+        drain()
+        slots = [t.slot(c) for c in chans]
+        info = t.stream_info()
+        t.destroy()
+        return np.concatenate([r[slots] for r in rows], axis=1) if rows else np.zeros((nchan, 0), np.float32), states, info
+
+    one, st1, _ = play(False)
+    many, st2, info = play(True)
+    assert one.shape == many.shape and one.shape[1] > 0
+    assert st1 == st2
+    assert np.array_equal(_bits(one), _bits(many)), (seed, info)
+    if seed % 3 != 2:
+        assert info[2] >= 3, info                           # blocks that did go through streaming launches
