@@ -44,7 +44,8 @@ extern "C" {
                                     wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
                                     wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
                                     4: wr_tune, wr_stage_windows_from_host, wr_tuner_last_staging added.
-                                    5: wr_tuner_set_streaming, wr_tuner_stream_info added.  Nothing of an earlier version changed or removed */
+                                    5: wr_tuner_set_streaming, wr_tuner_stream_info, wr_block_kernel_calls added; audio filters and second
+                                    channel stages of 128 / 256 taps accepted.  Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 
@@ -120,7 +121,7 @@ int wr_lowpass_design(unsigned int passband, unsigned int input_rate,
  * expression of init()/recalculate() is already written in terms of _firLength.  A power of
  * two (the mask logic of lowpass.cxx:172,184) in [2, WR_FIR_MAX]. */
 #define WR_FIR_MAX 1024
-#define WR_FIR_FUSED_MAX 256     /* longest channel filter the fused per-tuner path takes (wr_chan_set_taps_n, stage 0) */
+#define WR_FIR_FUSED_MAX 256     /* longest filter the per-tuner path takes (wr_chan_set_taps_n; r05: any of the three stages) */
 int wr_lowpass_design_n(unsigned int fir_length, unsigned int passband, unsigned int input_rate,
                         float *coeff_host /* [fir_length] */, unsigned int *maxbin_out);
 /* SpectrumSink::init window (io/spectrumsink.cxx:71-74); window[fft_size] */
@@ -180,6 +181,9 @@ int wr_fir_decimate(wr_dev *dev, const float *in_dev, size_t nframes, unsigned i
 int wr_fir_decimate_n(wr_dev *dev, const float *in_dev, size_t nframes, unsigned int channels,
                       unsigned int decimation, unsigned int fir_length, const float *coeff_host /* [fir_length] */,
                       float *history_dev, float *out_dev);
+/* how many stand-alone block kernels (wr_mix, wr_fir_decimate(_n), wr_demod) this process has run so far: 0 while every
+ * Receiver rides a tuner batch */
+unsigned long long wr_block_kernel_calls(void);
 
 /* Demodulator::process (dsp/demodulator.cxx:77-115).  prev_io[2] = {prev_i,prev_q}
  * (host), updated on return. */
@@ -250,7 +254,10 @@ int wr_chan_set_taps(wr_tuner *tuner, int chan, int stage, const float *coeff_ho
  * the exact kernels' pace.  The other nco modes: the window as L / 64 segments of the ROTATE recurrence, within its
  * tolerance (1e-6), about L / 64 times the 64-tap kernel's time (lane groups whose channels do not share one filter:
  * the reference's arithmetic).  Never a full-rate mixer output.
- * Longer filters and long audio filters: wr_fir_decimate_n, block by block. */
+ * r05: the AUDIO filter (stage 1) and the SECOND channel stage (stage 2) take 128 or 256 taps as well -- rate groups
+ * keyed by those lengths too, 127 / 255 rows of history, k_tuner_demod + k_tuner_audio and k_tuner_iq2 with the
+ * reference's order of additions: bit-identical to the reference chain in WR_NCO_EXACT, and in every mode as exact as
+ * the channel IQ they are fed.  Longer filters (up to WR_FIR_MAX): wr_fir_decimate_n, block by block. */
 int wr_chan_set_filter_n(wr_tuner *tuner, int chan, int stage, unsigned int fir_length,
                          unsigned int passband, unsigned int out_rate);
 int wr_chan_set_taps_n(wr_tuner *tuner, int chan, int stage, const float *coeff_host /* [fir_length] */,

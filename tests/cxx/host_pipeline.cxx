@@ -115,6 +115,8 @@ int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int
 		}
 		if (getenv("WR_TEST_FIR_LENGTH_CHAN"))       /* the channel filter alone: such a Receiver stays in the tuner batch */
 			rx[n]->channelFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH_CHAN")));
+		if (getenv("WR_TEST_FIR_LENGTH_AUDIO"))      /* the audio filter alone (r05: that stays in the batch too) */
+			rx[n]->audioFilter()->setFirLength((unsigned int)atoi(getenv("WR_TEST_FIR_LENGTH_AUDIO")));
 		rx[n]->setFrontEnd(fe);
 	}
 	int rc = 0;

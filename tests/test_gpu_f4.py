@@ -79,10 +79,12 @@ def test_fir_length_inside_the_fused_path(dev, oracle, nco, lengths):
     t = Tuner(dev, fs, 1, 1000, nco)
     c = C.c_int()
     capi.check(t.lib.wr_chan_add(t.h, C.byref(c)))
-    assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 512, 128_000, 5_000) == capi.WR_ERR_ARG     # channel filter: up to 256
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 512, 128_000, 5_000) == capi.WR_ERR_ARG     # every stage: up to 256
     assert t.lib.wr_chan_set_filter_n(t.h, 0, 0, 48, 128_000, 5_000) == capi.WR_ERR_ARG
     capi.check(t.lib.wr_chan_set_filter_n(t.h, 0, 0, 128, 128_000, 5_000))
-    assert t.lib.wr_chan_set_filter_n(t.h, 0, 1, 128, 800, 1_000) == capi.WR_ERR_ARG         # audio filter: up to 64
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 1, 512, 800, 1_000) == capi.WR_ERR_ARG
+    assert t.lib.wr_chan_set_filter_n(t.h, 0, 2, 512, 800, 1_000) == capi.WR_ERR_ARG
+    capi.check(t.lib.wr_chan_set_filter_n(t.h, 0, 1, 128, 800, 1_000))                        # r05: the audio filter too
     t.destroy()
 
 
@@ -192,6 +194,132 @@ def test_two_stage_channel_filter_through_the_tuner(dev, oracle, nco, fs, d1, pb
     assert live > 1e-3                                     # a live channel, not zeros
 
 
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+@pytest.mark.parametrize("stage,length", [("audio", 128), ("audio", 256), ("second", 128), ("second", 256),
+                                          ("both", 128), ("both", 256), ("all", 256)])
+def test_audio_filter_and_second_stage_of_128_and_256_taps_inside_the_tuner(dev, oracle, nco, stage, length, d2=5):
+    """r05, SURVEY 8f-4 (VERDICT r04 item 6): LowPass::_firLength 128 / 256 (lowpass.cxx:38-39 applies to every LowPass;
+    radio.cxx:69,71 builds two per receiver) for the AUDIO filter and for a SECOND channel stage, inside the tuner's
+    own launch sequence: the rate group is keyed by the lengths, keeps L - 1 rows of history (demodulator output /
+    first-stage IQ) as LowPass::block does (lowpass.cxx:138-142), and k_tuner_iq2 / k_tuner_demod + k_tuner_audio add
+    the products oldest sample first as lowpass.cxx:150-158 does.
+    EXACT: channel IQ and AM/USB/LSB audio bit-identical to the oracle's mixer -> `_n` filter [-> `_n` filter] ->
+    detector -> `_n` filter cascade; ROTATE: within the usual tolerance scaled by the filters' absolute gain.
+    "all": the channel filter has `length` taps as well (k_tuner_ddc_long).  70 receivers (two lane groups), blocks
+    shorter than the histories (the audio filter's 255 rows against 25 demodulator frames per block), a ragged block
+    size, a retune in mid-stream, all three linear detectors and FM, a 64-tap receiver beside them in the same tuner;
+    no stand-alone block kernel runs (wr_block_kernel_calls).  D2 = 5: the fused demodulator + audio filter
+    k_tuner_post<5, L / 64>; the next test: D2 = 7, which takes the two kernels."""
+    fs, d1, d1b = (2_000_000 if d2 == 5 else 2_100_000), 40, 5         # (rates stay integer related, dspblock.cxx:119-121)
+    two = stage in ("second", "both", "all")
+    l1 = length if stage == "all" else 64
+    l1b = length if two else None
+    l2 = length if stage in ("audio", "both", "all") else 64
+    pb1, r1 = 200_000, fs // d1                              # 50 k after the first stage
+    r_dem = r1 // d1b if two else r1                         # the demodulator's input rate: 10 k or 50 k
+    pb1b, pb2 = r1 // 8, r_dem // 8
+    assert oracle.lowpass_maxbin_n(l2, pb2, r_dem) >= 1 and (not two or oracle.lowpass_maxbin_n(l1b, pb1b, r1) >= 1)
+    ifs = [(-35 + c) * 6250 + 321 for c in range(70)]
+    modes_c = [capi.WR_AM, capi.WR_USB, capi.WR_LSB, capi.WR_FM]
+    modes_o = [oracle.AM, oracle.USB, oracle.LSB, oracle.FM]
+    probe = [0, 1, 2, 3, 33, 63, 64, 69]
+    calls0 = dev.lib.wr_block_kernel_calls()
+    unit = d1 * (d1b if two else 1) * d2
+    for n, blocks in ((unit * 40, 3), (unit * 5, 8 if two else 14), (unit * 13 + d1 * 3, 4)):
+        t = Tuner(dev, fs, 71, n, nco)
+        st2 = (l1b, pb1b, r1 // d1b) if two else None
+        chans = [t.add_receiver(f, pb1, r1, modes_c[c % 4], pb2, r_dem // d2, fir_lengths=(l1, l2), stage2=st2)
+                 for c, f in enumerate(ifs)]
+        plain = t.add_receiver(4321, pb1, r1, capi.WR_USB, r1 // 8, r1 // d2)
+        rxs = {c: OracleChain(oracle, fs, ifs[c], l1, pb1, d1, modes_o[c % 4], l2, pb2, d2,
+                              stage2=(l1b, pb1b, d1b) if two else None) for c in probe}
+        rxp = OracleChain(oracle, fs, 4321, 64, pb1, d1, oracle.USB, 64, r1 // 8, d2)
+        gain2 = max(1.0, float(np.abs(oracle.lowpass_design(pb2, r_dem, l2)).sum()))
+        gain1b = max(1.0, float(np.abs(oracle.lowpass_design(pb1b, r1, l1b)).sum())) if two else 1.0
+        pos = 0
+        live = 0.0
+        for b in range(blocks):
+            if b == 1:                                     # retune one of them between two blocks
+                t.set_if(chans[33], ifs[33] + 7777)
+                rxs[33].step = oracle.phase_step(ifs[33] + 7777, fs)
+            iq = synth.fm_stream(n, fs, [ifs[c] for c in probe[::2]] + [4321], start_frame=pos, amp=0.1, fm_base=30.0, beta=2.0)
+            pos += n
+            t.submit_host(iq)
+            for c in probe:
+                wa, wc, _ = rxs[c].run(iq)
+                gc = t.fetch(chans[c], capi.WR_STAGE_CHAN_IQ, 2 * n)      # the demodulator's input
+                ga = t.fetch(chans[c], capi.WR_STAGE_AUDIO, n)
+                assert gc.size == wc.size and ga.size == wa.size, (n, b, c)
+                fm = modes_c[c % 4] == capi.WR_FM
+                if nco == capi.WR_NCO_EXACT:
+                    assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, b, c)
+                    if not fm:
+                        assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, b, c)
+                    elif wa.size:                          # atan2f: ulps per demodulated frame, then the linear filter
+                        assert np.abs(ga - wa).max() <= 4.8e-7 * gain2, (n, b, c)
+                else:
+                    assert np.abs(gc - wc).max() <= 1e-6 * gain1b, (n, b, c, float(np.abs(gc - wc).max()))
+                    if wa.size and not fm:                 # |.| and Re/Im sums are 2-Lipschitz, then the linear filter
+                        assert np.abs(ga - wa).max() <= 2e-6 * gain1b * gain2, (n, b, c)
+                if wa.size and c == 0:
+                    live = max(live, float(np.abs(ga).max()))
+            wa, wc, _ = rxp.run(iq)
+            gc = t.fetch(plain, capi.WR_STAGE_CHAN_IQ, 2 * n)
+            ga = t.fetch(plain, capi.WR_STAGE_AUDIO, n)
+            if nco == capi.WR_NCO_EXACT:
+                assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), (n, b)
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (n, b)
+            else:
+                assert np.abs(gc - wc).max() <= 1e-6 and np.abs(ga - wa).max() <= 4e-6, (n, b)
+        assert live > 1e-3, (n, live)                      # a live channel, not zeros
+        t.destroy()
+    assert dev.lib.wr_block_kernel_calls() == calls0       # nothing left the tuner's own launches
+
+
+@pytest.mark.parametrize("nco", [capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE])
+@pytest.mark.parametrize("stage,length", [("audio", 128), ("both", 256)])
+def test_long_audio_filter_with_an_audio_decimation_of_7(dev, oracle, nco, stage, length):
+    """... and an audio decimation the fused kernel is not instantiated for: k_tuner_demod + k_tuner_audio with
+    L - 1 history rows, inside the tuner's launch sequence all the same."""
+    test_audio_filter_and_second_stage_of_128_and_256_taps_inside_the_tuner(dev, oracle, nco, stage, length, d2=7)
+
+
+@pytest.mark.parametrize("keep", [True, False])
+@pytest.mark.parametrize("length", [128, 256])
+def test_long_audio_filter_keeps_its_history_over_a_seek_and_a_kept_demodulator(dev, oracle, length, keep):
+    """The same group state under the calls that touch it from outside: wr_tuner_seek (a time-sharded stream starts
+    in the middle: empty histories of L - 1 rows, phase in closed form -- keep: made real by a launch, k_tuner_demod +
+    k_tuner_audio behind it; not keep: the lazy seek, k_tuner_post<D2, L / 64> reading the all-zero history set),
+    wr_tuner_keep_stages(DEMOD) (the demodulator rows sit behind L - 1 history rows now) and a receiver that joins a
+    running group (its own history rows zeroed, lowpass.cxx:138-139) -- EXACT mode, bit for bit."""
+    fs, d1, d2, n = 2_000_000, 40, 5, 8_000
+    ifs = [50_000, -75_000, 4321]
+    t = Tuner(dev, fs, 4, n, capi.WR_NCO_EXACT)
+    if keep:
+        t.keep_stages(capi.WR_STAGE_DEMOD)
+    chans = [t.add_receiver(f, 200_000, fs // d1, capi.WR_AM, 6_250, fs // d1 // d2, fir_lengths=(64, length)) for f in ifs]
+    start = 123_456 * d1 * d2                                # the shard begins here
+    t.seek(start)
+    rxs = [OracleChain(oracle, fs, f, 64, 200_000, d1, oracle.AM, length, 6_250, d2) for f in ifs]
+    for rx in rxs:
+        rx.phase = (rx.step * start) & 0x7FFFFFFF
+    late = None
+    for b in range(4):
+        if b == 2:                                         # a fourth receiver joins: fresh blocks, the phase of a fresh mixer
+            chans.append(t.add_receiver(-4444, 200_000, fs // d1, capi.WR_USB, 6_250, fs // d1 // d2, fir_lengths=(64, length)))
+            late = OracleChain(oracle, fs, -4444, 64, 200_000, d1, oracle.USB, length, 6_250, d2)
+            rxs.append(late)
+        iq = synth.fm_stream(n, fs, ifs[:2], start_frame=start + b * n, amp=0.2, fm_base=30.0, beta=2.0)
+        t.submit_host(iq)
+        for ch, rx in zip(chans, rxs):
+            wa, wc, wd = rx.run(iq)
+            assert np.array_equal(t.fetch(ch, capi.WR_STAGE_CHAN_IQ, 2 * n).view(np.uint32), wc.view(np.uint32)), b
+            if keep:
+                assert np.array_equal(t.fetch(ch, capi.WR_STAGE_DEMOD, n).view(np.uint32), wd.view(np.uint32)), b
+            assert np.array_equal(t.fetch(ch, capi.WR_STAGE_AUDIO, n).view(np.uint32), wa.view(np.uint32)), b
+    t.destroy()
+
+
 @pytest.mark.parametrize("keep_demod", [False, True])
 def test_af_gain_and_squelch(dev, oracle, keep_demod):
     """af_gain / squelch (named and left as FIXMEs by the reference, receiverhandler.cxx:112-127): the
@@ -250,13 +378,13 @@ def test_random_f4_configurations(dev, oracle, seed):
     specs, chans, rxs = [], [], []
     for c in range(nchan):
         f = int(rng.integers(-fs // 2 + 1, fs // 2))
-        l1, l2 = int(rng.choice([8, 16, 32, 64, 64, 128, 256])), int(rng.choice([16, 64]))   # 128 / 256: k_tuner_ddc_long (r03)
+        l1, l2 = int(rng.choice([8, 16, 32, 64, 64, 128, 256])), int(rng.choice([16, 64, 64, 128, 256]))   # 128 / 256: k_tuner_ddc_long (r03); r05: the audio filter and the second stage too
         pb1 = int(rng.choice([fs // 16, fs // 8, fs // 5]))
         two = bool(rng.integers(0, 2))
         mode = modes[int(rng.integers(0, 3))]
         r_in = fs // d1 // (d1b if two else 1)                # the demodulator's input rate
         pb2 = r_in // 8
-        st2 = (int(rng.choice([32, 64])), (fs // d1) // 8, fs // d1 // d1b) if two else None
+        st2 = (int(rng.choice([32, 64, 128, 256])), (fs // d1) // 8, fs // d1 // d1b) if two else None
         gain = float(rng.choice([0.0, 0.0, 6.0, -12.5]))
         sq = float(rng.choice([-60.0, -35.0])) if rng.integers(0, 3) == 0 else None
         specs.append((f, two, gain, sq))

@@ -38,8 +38,9 @@ L.wr_host_run.argtypes = [fp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, ip, ip, 
 rc = L.wr_host_run(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), nrx, ifs.ctypes.data_as(ip),
                    modes.ctypes.data_as(ip), int(p[2]), int(p[3]), int(p[4]), int(p[5]), int(p[6]), int(p[7]),
                    audio.ctypes.data_as(fp), cap, C.byref(n), fft, spec.ctypes.data_as(fp))
+L.wr_block_kernel_calls.restype = C.c_ulonglong     # (libwebradio_amd, a dependency of the harness)
 np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], spec=spec, left=L.wr_host_registry_sizes(),
-         traced=L.wr_host_trace_count())
+         traced=L.wr_host_trace_count(), block_calls=int(L.wr_block_kernel_calls()))
 '''
 
 
@@ -122,16 +123,17 @@ def test_sparse_staging_and_parts_give_the_same_bits(tmp_path, block):
 
 
 def test_runtime_fir_length_through_the_host_classes(tmp_path, oracle):
-    """LowPass::setFirLength(128) on both filters of every Receiver (SURVEY 8f-4, the reference's
-    FIXME at lowpass.cxx:38-39): such chains run block by block (the fused kernels are built for
-    64 taps), bit-identical for the linear detectors to the reference's algorithm with
-    _firLength = 128."""
-    L = 128
+    """LowPass::setFirLength(512) on both filters of every Receiver (SURVEY 8f-4, the reference's
+    FIXME at lowpass.cxx:38-39): longer than the tuner takes (WR_FIR_FUSED_MAX = 256), such chains run
+    block by block, bit-identical for the linear detectors to the reference's algorithm with
+    _firLength = 512 (r05: 128 and 256 stay in the batch, the next test)."""
+    L = 512
     ifs, modes = [50_000, -75_000, 10], [0, 2, 3]
     rate, block, cpb, crate, apb, arate = CFG["rate"], CFG["block"], CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"]
     iq = synth.fm_stream(3 * block, rate, ifs[:2], amp=0.3)
     got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
-                  env={"WR_TEST_FIR_LENGTH": str(L)})
+                  env={"WR_TEST_FIR_LENGTH": str(L), "WEBRADIO_TRACE": "1"})
+    assert int(np.load(str(tmp_path / "out.npz"))["traced"]) == 0          # nothing fused
     table = oracle.sin_table()
     for c, (f, m) in enumerate(zip(ifs, modes)):
         f1 = oracle.Fir(2, rate // crate, oracle.lowpass_design(cpb, rate, L))
@@ -148,6 +150,43 @@ def test_runtime_fir_length_through_the_host_classes(tmp_path, oracle):
     base, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
                    env={"WEBRADIO_NO_FUSION": "1"})
     assert np.abs(base - got).max() > 1e-4
+
+
+@pytest.mark.parametrize("which,L", [("audio", 128), ("audio", 256), ("both", 128), ("both", 256)])
+def test_long_audio_filter_stays_in_the_tuner_batch(tmp_path, oracle, which, L):
+    """r05: audioFilter()->setFirLength(128 | 256), alone or together with the channel filter:
+    the Receiver stays in the source's tuner batch (WEBRADIO_TRACE shows it submitting, and the library ran no
+    stand-alone block kernel: `block_calls` in the harness's output).  WEBRADIO_NCO=exact: the oracle's bits for the
+    linear detectors; the default mode within the ROTATE tolerance through the long filter."""
+    ifs, modes = [50_000, -75_000, 10, 33_333], [0, 2, 3, 0]
+    rate, block, cpb, crate, apb, arate = CFG["rate"], CFG["block"], CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"]
+    iq = synth.fm_stream(4 * block, rate, ifs[:2], amp=0.3)
+    var = {"audio": {"WR_TEST_FIR_LENGTH_AUDIO": str(L)}, "both": {"WR_TEST_FIR_LENGTH": str(L)}}[which]
+    got, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(2, 61_000),
+                  env=dict(var, WEBRADIO_TRACE="1", WEBRADIO_NCO="exact"))
+    z = np.load(str(tmp_path / "out.npz"))
+    assert int(z["traced"]) > 0 and int(z["block_calls"]) == 0
+    fast, _ = _run("libwr_host_pipeline.so", tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate, retune=(2, 61_000),
+                   env=dict(var, WEBRADIO_TRACE="1"))
+    z = np.load(str(tmp_path / "out.npz"))
+    assert int(z["traced"]) > 0 and int(z["block_calls"]) == 0
+    table = oracle.sin_table()
+    L1 = L if which == "both" else 64
+    gain2 = max(1.0, float(np.abs(oracle.lowpass_design(apb, crate, L)).sum()))
+    for c, (f, m) in enumerate(zip(ifs, modes)):
+        f1 = oracle.Fir(2, rate // crate, oracle.lowpass_design(cpb, rate, L1))
+        f2 = oracle.Fir(1, crate // arate, oracle.lowpass_design(apb, crate, L))
+        phase, prev, want = 0, (0.0, 0.0), []
+        for b in range(4):
+            if c == 0 and b == 2:
+                f = 61_000
+            mixed, phase = oracle.mix(table, phase, oracle.phase_step(f, rate), iq[2 * b * block: 2 * (b + 1) * block])
+            d, prev = oracle.demod(m, prev, f1.process(mixed))
+            want.append(f2.process(d))
+        want = np.concatenate(want)
+        assert got[c].size == want.size
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
+        assert np.abs(fast[c] - want).max() <= 4e-6 * gain2, (c, float(np.abs(fast[c] - want).max()))
 
 
 @pytest.mark.parametrize("L", [128, 256])

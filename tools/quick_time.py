@@ -28,7 +28,8 @@ for name in which:
         t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0) + (3_000_000 if odd else 0),
                        c2["chan_rate"], capi.WR_FM,
                        c2["audio_passband"], c2["audio_rate"],
-                       fir_lengths=(int(os.environ["QT_L1"]), 64) if os.environ.get("QT_L1") else None)   # 128 / 256: k_tuner_ddc_long
+                       fir_lengths=(int(os.environ.get("QT_L1", "64")), int(os.environ.get("QT_L2", "64")))
+                       if os.environ.get("QT_L1") or os.environ.get("QT_L2") else None)   # 128 / 256: k_tuner_ddc_long; r05: QT_L2, the audio filter
     for i in range(4):
         t.submit_device(blocks[i % nb], n)
     torch.cuda.synchronize()

@@ -18,7 +18,9 @@ for K in (200, 1, 2, 5, 10, 20, 50, 100):
         t0 = time.perf_counter()
         for i in range(K):
             t.submit_device(blocks[i % nb], n)
-        t.flush(); torch.cuda.synchronize()
+        t.flush()
+        if os.environ.get("DEVSYNC"): dev.sync()
+        torch.cuda.synchronize()
         t2 = time.perf_counter()
         got, ms = t.profile_read(); t.profile(False)
     print("K=%3d wall %.1f us total, kernel %.1f us (%d launch) -> fixed part vs 200-block rate" % (K, (t2 - t0) * 1e6, ms * 1e3, got), flush=True)

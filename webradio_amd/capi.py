@@ -86,6 +86,7 @@ SIGNATURES = {
     "wr_chan_set_state": (C.c_int, [_vp, C.c_int, _u32, _vp]),
     "wr_tuner_submit": (C.c_int, [_vp, _vp, _sz, C.c_int]),
     "wr_tuner_last_staging": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "wr_block_kernel_calls": (C.c_ulonglong, []),
     "wr_tuner_submit_u8": (C.c_int, [_vp, _vp, _sz, C.c_int]),
     "wr_chan_fetch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "wr_tuner_audio_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),

@@ -105,6 +105,8 @@ struct Chan {
 	float taps[3][WR_FIR_LENGTH];
 	unsigned int len1;         /* taps of the channel filter: 64 (shorter ones are zero-extended to it) or 128 / 256 */
 	float taps_long[WR_FIR_FUSED_MAX];   /* ... and, when len1 > 64, the taps themselves (taps[0] is not used then) */
+	unsigned int len2, len1b;  /* the same for the audio filter (stage 1) and the second channel stage (stage 2): 64, 128 or 256 */
+	float taps_long2[WR_FIR_FUSED_MAX], taps_long1b[WR_FIR_FUSED_MAX];
 	unsigned int decim[3];
 	float gain;                /* af_gain as a factor (1 = 0 dB) */
 	float squelch;             /* squelch threshold as a power (0 = open) */
@@ -121,6 +123,8 @@ struct Group {
 	unsigned int d1, d2;
 	unsigned int d1b = 0;      /* decimation of the second channel-filter stage, 0 = there is none */
 	unsigned int l1 = WR_FIR_LENGTH;   /* taps of the group's channel filters: 64, or 128 / 256 (k_tuner_ddc_long) */
+	unsigned int l2 = WR_FIR_LENGTH;   /* ... of its audio filters: 64, or 128 / 256 (k_tuner_demod + k_tuner_audio with 127 / 255 history rows) */
+	unsigned int l1b = WR_FIR_LENGTH;  /* ... of its second channel stage (k_tuner_iq2) */
 	int p2 = 0;                /* which iq2_hist set the next block reads */
 	bool use_gain = false, use_squelch = false;
 	unsigned int slots;
@@ -680,11 +684,21 @@ extern "C" int wr_dev_download(wr_dev *d, void *dst_host, const void *src_dev, s
 
 /* --------------------------------------------------- one kernel per block -- */
 
+/* how often this process has run one of the reference's blocks as a stand-alone kernel (wr_mix, wr_fir_decimate(_n),
+ * wr_demod): what a Receiver that is NOT in a tuner batch costs per block -- a test that expects a chain to stay in the
+ * batch reads 0 here */
+static std::atomic<unsigned long long> g_block_kernel_calls{0};
+extern "C" unsigned long long wr_block_kernel_calls(void)
+{
+	return g_block_kernel_calls.load(std::memory_order_relaxed);
+}
+
 extern "C" int wr_mix(wr_dev *d, const float *in_dev, float *out_dev, size_t nframes,
                       unsigned int *phase_io, int phase_step)
 {
 	if (!d || !phase_io || (nframes && (!in_dev || !out_dev)))
 		return fail(WR_ERR_ARG, "wr_mix: bad argument");
+	g_block_kernel_calls.fetch_add(1, std::memory_order_relaxed);
 	HIP_TRY(wrk_mix(d->stream, in_dev, out_dev, nframes, *phase_io, phase_step, d->table));
 	/* DownConverter::phase after nframes increments (downconverter.cxx:103) */
 	*phase_io = (*phase_io + (unsigned int)nframes * (unsigned int)phase_step) & 0x7FFFFFFFu;
@@ -706,6 +720,7 @@ extern "C" int wr_fir_decimate_n(wr_dev *d, const float *in_dev, size_t nframes,
 	if (rc)
 		return rc;
 	HIP_TRY(hipMemcpyAsync(d->coeff, coeff_host, fir_length * sizeof(float), hipMemcpyHostToDevice, d->stream));
+	g_block_kernel_calls.fetch_add(1, std::memory_order_relaxed);
 	HIP_TRY(wrk_fir(d->stream, in_dev, nframes, channels, decimation, fir_length, d->coeff, history_dev, out_dev));
 	HIP_TRY(wrk_hist_update(d->stream, in_dev, nframes, channels, fir_length, history_dev, d->scratch));
 	return WR_OK;
@@ -726,6 +741,7 @@ extern "C" int wr_demod(wr_dev *d, int mode, const float *in_dev, size_t nframes
 		return fail(WR_ERR_ARG, "wr_demod: bad argument");
 	if (mode < WR_AM || mode > WR_LSB)
 		return fail(WR_ERR_ARG, "wr_demod: bad mode %d", mode);   /* demodulator.cxx:105-107 */
+	g_block_kernel_calls.fetch_add(1, std::memory_order_relaxed);
 	HIP_TRY(wrk_demod(d->stream, mode, in_dev, nframes, prev_io[0], prev_io[1], out_dev));
 	if (nframes) {
 		/* prev_i/q = last input frame (demodulator.cxx:110-111) */
@@ -945,7 +961,8 @@ static void group_free(Group *g)
 	delete g;
 }
 
-static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned int d2, unsigned int l1, Group **out)
+static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned int d2, unsigned int l1, unsigned int l1b,
+                        unsigned int l2, Group **out)
 {
 	Group *g = new (std::nothrow) Group();
 	if (!g)
@@ -957,6 +974,8 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	g->d1b = d1b;
 	g->d2 = d2;
 	g->l1 = l1;
+	g->l2 = l2;
+	g->l1b = d1b ? l1b : (unsigned int)WR_FIR_LENGTH;
 	g->slots = ((t->max_channels + WR_LANES - 1) / WR_LANES) * WR_LANES;
 	g->k1max = t->max_block_frames / d1;       /* first-stage frames; the later stages need no more */
 	g->k2max = g->k1max / (d1b ? d1b : 1u) / d2;
@@ -968,6 +987,8 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	g->last_k1 = g->last_k2 = 0;
 	g->active = 0;
 	const size_t S = g->slots;
+	g->dev.l2 = g->l2;
+	g->dev.l1b = g->l1b;
 	int rc = WR_OK;
 	if (!rc) rc = dev_alloc_zero(&g->dev.phase[0], S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.phase[1], S);
@@ -979,10 +1000,10 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	if (!rc) rc = dev_alloc_zero(&g->dev.flags, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.mode, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1, S * WR_FIR_LENGTH);
-	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * WR_FIR_LENGTH);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps2, S * g->l2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.rot, S * 4);
 	if (!rc) rc = dev_alloc_zero(&g->dev.taps1u, S * WR_TAPSETS);
-	if (!rc) rc = dev_alloc_zero(&g->dev.taps2u, S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.taps2u, S / WR_LANES * g->l2);      /* [lane groups][l2] */
 	if (!rc) rc = dev_alloc_zero(&g->dev.tapsel, S);
 	if (l1 > WR_FIR_LENGTH) {
 		if (!rc) rc = dev_alloc_zero(&g->dev.taps1L, S * l1);
@@ -991,22 +1012,22 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	}
 	if (!rc) rc = dev_alloc_zero(&g->dev.gain, S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.squelch, S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[0], (size_t)WR_HIST * S * 2);      /* wr_tuner_seek clears it */
-	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[1], (size_t)WR_HIST * S * 2);
+	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[0], (size_t)(g->l1b - 1) * S * 2);      /* wr_tuner_seek clears it */
+	if (!rc) rc = dev_alloc_zero(&g->dev.iq2_hist[1], (size_t)(g->l1b - 1) * S * 2);
 	if (d1b) {
-		if (!rc) rc = dev_alloc_zero(&g->dev.taps1b, S * WR_FIR_LENGTH);
+		if (!rc) rc = dev_alloc_zero(&g->dev.taps1b, S * g->l1b);
 		if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq2[0], (g->k1max / d1b + 1) * S * 2);
 		if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq2[1], (g->k1max / d1b + 1) * S * 2);
 	}
 	if (!rc) rc = dev_alloc_zero(&g->z_hist, (size_t)WR_HIST * S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->z_prev, S * 2);
-	if (!rc) rc = dev_alloc_zero(&g->z_dem, (size_t)WR_HIST * S);
+	if (!rc) rc = dev_alloc_zero(&g->z_dem, (size_t)(g->l2 - 1) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[0], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.prev_iq[1], S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[0], (g->k1max ? g->k1max : 1) * S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[1], (g->k1max ? g->k1max : 1) * S * 2);
-	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], (WR_HIST + g->k1max) * S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], (WR_HIST + g->k1max) * S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], ((size_t)g->l2 - 1 + g->k1max) * S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], ((size_t)g->l2 - 1 + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
 	if (rc) {
 		group_free(g);
@@ -1149,7 +1170,7 @@ extern "C" int wr_chan_add(wr_tuner *t, int *chan)
 	Chan &c = t->chans[idx];
 	memset(&c, 0, sizeof(c));
 	c.in_use = true;
-	c.len1 = WR_FIR_LENGTH;
+	c.len1 = c.len2 = c.len1b = WR_FIR_LENGTH;
 	c.mode = WR_AM;                /* Demodulator ctor, demodulator.cxx:34 */
 	c.gain = 1.0f;                 /* what the reference reports: af_gain 0, squelch_threshold 0 (receiverhandler.cxx:118-119) */
 	c.squelch = 0.0f;
@@ -1219,7 +1240,7 @@ static int chan_seat(wr_tuner *t, int idx)
 	if (c.group >= 0) {
 		Group *g = t->groups[c.group];
 		if (g->d1 == c.decim[0] && g->d2 == c.decim[1] && g->d1b == (c.have[2] ? c.decim[2] : 0u) &&
-		    g->l1 == (c.len1 > WR_FIR_LENGTH ? c.len1 : (unsigned int)WR_FIR_LENGTH)) {
+		    g->l1 == c.len1 && g->l2 == c.len2 && g->l1b == (c.have[2] ? c.len1b : (unsigned int)WR_FIR_LENGTH)) {
 			g->dirty = true;
 			return WR_OK;
 		}
@@ -1231,7 +1252,8 @@ static int chan_seat(wr_tuner *t, int idx)
 	for (size_t i = 0; i < t->groups.size(); ++i)
 		if (t->groups[i]->d1 == c.decim[0] && t->groups[i]->d2 == c.decim[1] &&
 		    t->groups[i]->d1b == (c.have[2] ? c.decim[2] : 0u) &&
-		    t->groups[i]->l1 == (c.len1 > WR_FIR_LENGTH ? c.len1 : (unsigned int)WR_FIR_LENGTH)) {
+		    t->groups[i]->l1 == c.len1 && t->groups[i]->l2 == c.len2 &&
+		    t->groups[i]->l1b == (c.have[2] ? c.len1b : (unsigned int)WR_FIR_LENGTH)) {
 			gi = (int)i;
 			break;
 		}
@@ -1239,8 +1261,7 @@ static int chan_seat(wr_tuner *t, int idx)
 		if (dev_bind(t->dev))
 			return WR_ERR_HIP;
 		Group *g = nullptr;
-		int rc = group_create(t, c.decim[0], c.have[2] ? c.decim[2] : 0u, c.decim[1],
-		                      c.len1 > WR_FIR_LENGTH ? c.len1 : (unsigned int)WR_FIR_LENGTH, &g);
+		int rc = group_create(t, c.decim[0], c.have[2] ? c.decim[2] : 0u, c.decim[1], c.len1, c.len1b, c.len2, &g);
 		if (rc)
 			return rc;
 		t->groups.push_back(g);
@@ -1279,7 +1300,7 @@ extern "C" int wr_chan_set_if(wr_tuner *t, int chan, int if_hz)
 	return WR_OK;
 }
 
-/* `coeff`: 64 taps (a shorter filter zero-extended), or -- stage 0 only -- `len` = 128 or 256 of them */
+/* `coeff`: 64 taps (a shorter filter zero-extended), or `len` = 128 or 256 of them */
 static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff, unsigned int decim,
                            unsigned int len = WR_FIR_LENGTH)
 {
@@ -1290,11 +1311,11 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
 		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
 	if (!decim)
 		return fail(WR_ERR_ARG, "decimation must be >= 1");
-	if (stage == 0) {
-		c->len1 = len;
-		if (len > WR_FIR_LENGTH)
-			memcpy(c->taps_long, coeff, sizeof(float) * len);
-	}
+	unsigned int *lens[3] = {&c->len1, &c->len2, &c->len1b};
+	float *longs[3] = {c->taps_long, c->taps_long2, c->taps_long1b};
+	*lens[stage] = len;
+	if (len > WR_FIR_LENGTH)
+		memcpy(longs[stage], coeff, sizeof(float) * len);
 	if (len <= WR_FIR_LENGTH)
 		memcpy(c->taps[stage], coeff, sizeof(float) * WR_FIR_LENGTH);
 	c->decim[stage] = decim;
@@ -1307,10 +1328,11 @@ static int set_taps_common(wr_tuner *t, int chan, int stage, const float *coeff,
  * the oldest samples -- are zero.  lowpass.cxx:150-158 adds the products oldest sample first, so the
  * padded filter starts with 64 - L products that are +-0 and then runs through exactly the additions
  * of the short one: the same bits (finite input). */
-static bool fused_fir_length_ok(unsigned int n, int stage = 1)
+static bool fused_fir_length_ok(unsigned int n)
 {
-	/* the channel filter (stage 0) may also have 128 or 256 taps: k_tuner_ddc_long */
-	return n >= 2 && n <= (stage == 0 ? (unsigned int)WR_FIR_FUSED_MAX : (unsigned int)WR_FIR_LENGTH) && (n & (n - 1)) == 0;
+	/* 128 or 256 taps: k_tuner_ddc_long (channel filter), k_tuner_iq2 (second channel stage), k_tuner_demod +
+	 * k_tuner_audio (audio filter) with 127 / 255 rows of history -- every stage of the tuner's own launch sequence */
+	return n >= 2 && n <= (unsigned int)WR_FIR_FUSED_MAX && (n & (n - 1)) == 0;
 }
 
 extern "C" int wr_chan_set_taps_n(wr_tuner *t, int chan, int stage, const float *coeff_host,
@@ -1318,10 +1340,9 @@ extern "C" int wr_chan_set_taps_n(wr_tuner *t, int chan, int stage, const float 
 {
 	if (!t || !coeff_host)
 		return fail(WR_ERR_ARG, "wr_chan_set_taps: bad argument");
-	if (!fused_fir_length_ok(fir_length, stage))
-		return fail(WR_ERR_ARG, "wr_chan_set_taps_n: fir_length %u is not a power of two in [2, %d] (%d for the channel "
-		                        "filter; longer filters run block by block: wr_fir_decimate_n)", fir_length, WR_FIR_LENGTH,
-		            WR_FIR_FUSED_MAX);
+	if (!fused_fir_length_ok(fir_length))
+		return fail(WR_ERR_ARG, "wr_chan_set_taps_n: fir_length %u is not a power of two in [2, %d] (longer filters run "
+		                        "block by block: wr_fir_decimate_n)", fir_length, WR_FIR_FUSED_MAX);
 	float coeff[WR_FIR_FUSED_MAX] = {0.0f};
 	memcpy(coeff, coeff_host, sizeof(float) * fir_length);
 	return set_taps_common(t, chan, stage, coeff, decimation, fir_length > WR_FIR_LENGTH ? fir_length : (unsigned int)WR_FIR_LENGTH);
@@ -1341,9 +1362,9 @@ extern "C" int wr_chan_set_filter_n(wr_tuner *t, int chan, int stage, unsigned i
 		return g_settle_rc ? g_settle_rc : fail(WR_ERR_ARG, "wr_chan_set_filter: no channel %d", chan);
 	if (stage < 0 || stage > 2)
 		return fail(WR_ERR_ARG, "stage must be 0 (channel), 1 (audio) or 2 (second channel filter)");
-	if (!fused_fir_length_ok(fir_length, stage))
-		return fail(WR_ERR_ARG, "wr_chan_set_filter_n: fir_length %u is not a power of two in [2, %d] (%d for the channel filter)",
-		            fir_length, WR_FIR_LENGTH, WR_FIR_FUSED_MAX);
+	if (!fused_fir_length_ok(fir_length))
+		return fail(WR_ERR_ARG, "wr_chan_set_filter_n: fir_length %u is not a power of two in [2, %d]", fir_length,
+		            WR_FIR_FUSED_MAX);
 	unsigned int in_rate;
 	if (stage == 0) {
 		in_rate = t->input_rate;
@@ -1537,8 +1558,8 @@ static int group_upload(wr_tuner *t, Group *g)
 	}
 	std::vector<unsigned int> step(S, 0);
 	std::vector<int> flags(S, 0), mode(S, -1);      /* mode < 0 marks an idle slot */
-	std::vector<float> taps1(S * WR_FIR_LENGTH, 0.0f), taps2(S * WR_FIR_LENGTH, 0.0f);
-	std::vector<float> taps1b(g->d1b ? S * WR_FIR_LENGTH : 0, 0.0f), gain(S, 1.0f), squelch(S, 0.0f);
+	std::vector<float> taps1(S * WR_FIR_LENGTH, 0.0f), taps2(S * g->l2, 0.0f);
+	std::vector<float> taps1b(g->d1b ? S * g->l1b : 0, 0.0f), gain(S, 1.0f), squelch(S, 0.0f);
 	std::vector<float> taps1L(g->l1 > WR_FIR_LENGTH ? S * g->l1 : 0, 0.0f);
 	g->use_gain = g->use_squelch = false;
 	for (size_t s = 0; s < S; ++s) {
@@ -1549,12 +1570,13 @@ static int group_upload(wr_tuner *t, Group *g)
 		step[s] = c.stepL;
 		mode[s] = c.mode;
 		flags[s] = 1;
-		for (int j = 0; j < WR_FIR_LENGTH; ++j) {
+		for (int j = 0; j < WR_FIR_LENGTH; ++j)
 			taps1[(size_t)j * S + s] = c.taps[0][j];
-			taps2[(size_t)j * S + s] = c.taps[1][j];
-			if (g->d1b)
-				taps1b[(size_t)j * S + s] = c.taps[2][j];
-		}
+		for (unsigned int j = 0; j < g->l2; ++j)
+			taps2[(size_t)j * S + s] = g->l2 > WR_FIR_LENGTH ? c.taps_long2[j] : c.taps[1][j];
+		if (g->d1b)
+			for (unsigned int j = 0; j < g->l1b; ++j)
+				taps1b[(size_t)j * S + s] = g->l1b > WR_FIR_LENGTH ? c.taps_long1b[j] : c.taps[2][j];
 		if (g->l1 > WR_FIR_LENGTH)
 			for (unsigned int j = 0; j < g->l1; ++j)
 				taps1L[(size_t)j * S + s] = c.taps_long[j];
@@ -1623,7 +1645,8 @@ static int group_upload(wr_tuner *t, Group *g)
 	}
 	/* the audio filter likewise (one per lane group or the per-lane path; its taps go through the
 	 * scalar cache, see post_role) */
-	std::vector<float> taps2u(S, 0.0f);
+	const unsigned int l2 = g->l2;
+	std::vector<float> taps2u(S / WR_LANES * l2, 0.0f);         /* [lane groups][l2] */
 	unsigned long long u2mask = 0;
 	for (size_t base = 0; base < S && base / WR_LANES < 64; base += WR_LANES) {
 		int rep = -1;
@@ -1635,11 +1658,12 @@ static int group_upload(wr_tuner *t, Group *g)
 			if (rep < 0)
 				rep = ci;
 			else
-				same = !memcmp(t->chans[ci].taps[1], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH);
+				same = l2 > WR_FIR_LENGTH ? !memcmp(t->chans[ci].taps_long2, t->chans[rep].taps_long2, sizeof(float) * l2)
+				                          : !memcmp(t->chans[ci].taps[1], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH);
 		}
 		if (!same || rep < 0)
 			continue;
-		memcpy(&taps2u[base], t->chans[rep].taps[1], sizeof(float) * WR_FIR_LENGTH);
+		memcpy(&taps2u[base / WR_LANES * l2], l2 > WR_FIR_LENGTH ? t->chans[rep].taps_long2 : t->chans[rep].taps[1], sizeof(float) * l2);
 		u2mask |= 1ull << (base / WR_LANES);
 	}
 	g->uniform2_mask = u2mask;
@@ -1729,7 +1753,7 @@ static int group_upload(wr_tuner *t, Group *g)
 			HIP_TRY(hipMemset2DAsync(g->dev.hist_lo[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
 			                         WR_HIST, st));
 			HIP_TRY(hipMemset2DAsync(g->dev.iq2_hist[g->p2] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
-			                         WR_HIST, st));
+			                         g->l1b - 1, st));
 			if (g->l1 > WR_FIR_LENGTH)        /* the L - 1 mixed frames of this slot */
 				HIP_TRY(hipMemset2DAsync(g->dev.mixhist[g->sp] + 2 * s, S * 2 * sizeof(float), 0, 2 * sizeof(float),
 				                         g->l1 - 1, st));
@@ -1737,7 +1761,7 @@ static int group_upload(wr_tuner *t, Group *g)
 		}
 		if (c.dem_hist_reset) {
 			/* 63 history rows of this slot: one float per row, stride S */
-			HIP_TRY(hipMemset2DAsync(g->dev.dem[g->parity] + s, S * sizeof(float), 0, sizeof(float), WR_HIST, st));
+			HIP_TRY(hipMemset2DAsync(g->dev.dem[g->parity] + s, S * sizeof(float), 0, sizeof(float), g->l2 - 1, st));
 			c.dem_hist_reset = false;
 		}
 	}
@@ -2118,8 +2142,10 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		/* (r04: a group with a long channel filter defers too where its launch can carry a post stage: the ROTATE kernel,
 		 * every lane group on one long filter) */
 		const bool long_rides = g->l1 > WR_FIR_LENGTH && g->long_uniform && long_rot_enabled();
+		/* (r05: an audio filter of 128 / 256 taps -- k_tuner_post<D2, 2 | 4> -- goes out on its own behind the DDC: the
+		 * workgroups that ride are compiled for 64 taps) */
 		const bool defer = !two_kernels && !g->d1b && (g->l1 <= WR_FIR_LENGTH || long_rides) && L.k1 && t->defer_post &&
-		                   t->nco_mode == WR_NCO_ROTATE;
+		                   t->nco_mode == WR_NCO_ROTATE && g->l2 == WR_FIR_LENGTH;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, Lp, Gp));
 			HIP_TRY(wrk_tuner_audio(st, Lp, Gp));
@@ -2317,7 +2343,7 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	if (t->nco_mode != WR_NCO_ROTATE || !t->defer_post || t->mark_launches || (t->keep_mask & (1u << WR_STAGE_DEMOD)))
 		return WR_OK;
 	Group *g = single_group(t);
-	if (!g || g->l1 != WR_FIR_LENGTH || g->d1b || g->seek_pending || !wrk_tuner_post_supported(g->d2))
+	if (!g || g->l1 != WR_FIR_LENGTH || g->l2 != WR_FIR_LENGTH || g->d1b || g->seek_pending || !wrk_tuner_post_supported(g->d2))
 		return WR_OK;
 	/* (64 channel-rate frames per block at least: a block's post stage takes its history from the block before) */
 	if (nframes < (size_t)WR_FIR_LENGTH * g->d1 || nframes % ((size_t)g->d1 * g->d2) || nframes / g->d1 > 0x3FFFFFFFu)
@@ -2670,7 +2696,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 			return fail(WR_ERR_STATE, "wr_chan_fetch: the demodulator output was not kept "
 			            "(call wr_tuner_keep_stages(tuner, 1u << WR_STAGE_DEMOD) before submitting)");
 		else
-			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem[g->last_parity] + (size_t)WR_HIST * S, g->last_k1, S,
+			HIP_TRY(wrk_gather_rows(d->stream, g->dev.dem[g->last_parity] + (size_t)(g->l2 - 1) * S, g->last_k1, S,
 			                        (size_t)c->slot, 1, d->scratch));
 		HIP_TRY(hipMemcpyAsync(out_host, d->scratch, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
 	}

@@ -79,6 +79,9 @@ struct WrGroupDev {
 	                               that block b+1's DDC can run while block b is being demodulated */
 	float        *dem[2];       /* [63 + k1max][slots] demod output, 63 history rows in front; ping-pong */
 	float        *audio;        /* [slots][k2max] audio, channel major */
+	/* taps of the group's audio filter and of its second channel stage: 64, or 128 / 256 (the rate group is keyed by
+	 * them; dem then carries l2 - 1 history rows, iq2_hist l1b - 1, taps2 / taps1b l2 / l1b rows) */
+	unsigned int  l2 = 64, l1b = 64;
 };
 
 struct WrTunerLaunch {
@@ -130,7 +133,7 @@ struct WrPostArgs {
 	const int   *mode;
 	const float *prev_iq;        /* [slots][2] frame before the block's first */
 	float       *prev_next;
-	const float *dem_hist;       /* [63][slots] audio filter history */
+	const float *dem_hist;       /* [63][slots] audio filter history ([64 nseg - 1] rows) */
 	float       *dem_hist_next;
 	size_t       k2;
 	unsigned int tiles;          /* tiles of POST_TK audio frames per lane group */
@@ -151,6 +154,8 @@ struct WrPostArgs {
 	                                audio sample too, rows `host_stride` floats apart -- the block's audio is in the ring when
 	                                the launch has run, no device-to-host copy behind it; NULL: device memory only */
 	size_t       host_stride;
+	unsigned int nseg = 1;       /* the audio filter's taps / 64: 1, or 2 / 4 (dem_hist then has 127 / 255 rows, taps2 128 / 256,
+	                                taps2u [groups][taps]) */
 	const float *chan_prev = nullptr;   /* r05 (the streaming launch): the channel IQ of the block BEFORE this one, [k1][slots][2], k1 >= 64 --
 	                                the 63 rows of audio-filter history and the demodulator's previous frame are then made from
 	                                ITS last 64 rows (the same operations on the same frames: the same bits) instead of read

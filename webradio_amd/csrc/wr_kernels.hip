@@ -529,18 +529,19 @@ __device__ __forceinline__ float audio_out(float v, const float *__restrict__ ga
 __device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
                                           unsigned int s, int m, const float2 *__restrict__ prev_iq,
                                           const float *__restrict__ dem_hist, size_t rr,
-                                          const float2 *__restrict__ chan_prev = nullptr)
+                                          const float2 *__restrict__ chan_prev = nullptr, unsigned int hist = WR_HIST)
 {
-	if (rr < WR_HIST) {
+	/* `hist`: rows of history in front of the block's = the audio filter's taps - 1 (63; 127 / 255 for 128 / 256 taps) */
+	if (rr < hist) {
 		if (!chan_prev)
 			return dem_hist[rr * slots + s];
 		/* (streaming launch) history row rr = the demodulated frame k1 - 63 + rr of the block before */
-		const size_t kp = (size_t)k1 - WR_HIST + rr;
+		const size_t kp = (size_t)k1 - hist + rr;
 		const float2 z = chan_prev[kp * slots + s];
 		const float2 zp = chan_prev[(kp - 1u) * slots + s];
 		return demod_one(m, z.x, z.y, zp.x, zp.y);
 	}
-	const size_t kk = rr - WR_HIST;
+	const size_t kk = rr - hist;
 	if (kk >= k1)
 		return 0.0f;                                    /* beyond the block: never read by lowpass.cxx */
 	const float2 z = chan_iq[kk * slots + s];
@@ -554,12 +555,21 @@ __device__ __forceinline__ float post_row(const float2 *__restrict__ chan_iq, un
  * turn comes -- 64 fewer VGPRs, for the workgroups that run this inside k_tuner_ddc beside the
  * next block's DDC.  `stage` and `tile` are LDS: [NEED][64] and
  * [POST_TK][65] floats. */
-template <unsigned int D2, bool HREGS>
+template <unsigned int D2, bool HREGS, unsigned int NSEG = 1u>
 __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, unsigned int g,
                                           float *stage, float *tile, int *modes)
 {
-	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
+	/* An audio filter of 128 / 256 taps (r05; LowPass::_firLength, lowpass.cxx:38-39) is NSEG = 2 / 4 SEGMENTS of 64
+	 * taps over one staged window of (POST_TK - 1) D2 + 64 NSEG rows: segment q is the 64-tap filter
+	 * coeff[(NSEG - 1 - q) * 64 ..] over the rows starting 64 q further on, its products added -- oldest row first, as
+	 * lowpass.cxx:150-158 adds all L of them -- onto what the segments before left in the accumulators.  The history in
+	 * front of the block is L - 1 rows.  (NSEG is a template parameter: the 64-tap instances, the ones that ride in the
+	 * DDC launches, are compiled as they always were; k_tuner_post<D2, 2 | 4> is a launch of its own behind the DDC.) */
+	constexpr unsigned int HIST = WR_FIR_LENGTH * NSEG - 1u;
+	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH * NSEG;
 	constexpr unsigned int NROW = POST_THREADS / 64u;
+	static_assert(NSEG == 1u || !HREGS, "the segmented filter reads its taps when their turn comes (measured at C2, 128 / 256 taps: "
+	                                    "61 / 83 us per block; a segment's 64 taps fetched into registers first: 64 / 94)");
 	const float2 *__restrict__ chan_iq = (const float2 *)A.chan_iq;
 	const float2 *__restrict__ prev_iq = (const float2 *)A.prev_iq;
 	const float2 *__restrict__ chan_prev = (const float2 *)A.chan_prev;   /* (uniform: a kernel argument) */
@@ -574,10 +584,10 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 	if (bx == A.ntiles) {
 		if (m < 0)
 			return;
-		const size_t first = k1;                        /* the last 63 rows of [history | current] */
+		const size_t first = k1;                        /* the last 63 (L - 1) rows of [history | current] */
 #pragma unroll
-		for (unsigned int r = row; r < WR_HIST; r += NROW)   /* unrolled: one memory round, not eight */
-			A.dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r, chan_prev);
+		for (unsigned int r = row; r < HIST; r += NROW)      /* unrolled: one memory round, not eight */
+			A.dem_hist_next[(size_t)r * slots + s] = post_row(chan_iq, k1, slots, s, m, prev_iq, dem_hist, first + r, chan_prev, HIST);
 		if (row == 0)
 			((float2 *)A.prev_next)[s] = k1 ? chan_iq[(size_t)(k1 - 1u) * slots + s] : prev_iq[s];
 		return;
@@ -631,12 +641,12 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 			const unsigned int per = (NEED - first + NROW - 1u) / NROW;
 			const unsigned int beg = first + row * per;
 			const unsigned int end = (beg + per < NEED) ? beg + per : NEED;
-			if (r0 > WR_HIST && r0 + NEED <= (size_t)k1 + WR_HIST) {
+			if (r0 > HIST && r0 + NEED <= (size_t)k1 + HIST) {
 				/* every row is a frame of this block and so is its predecessor (all tiles but a
 				 * block's first and last): the loads of POST_LB rows go out together, nothing to
 				 * decide per row -- the stage phase is a chain of memory round trips, and one per
 				 * row made the post workgroups the last to finish */
-				const float2 *__restrict__ src = chan_iq + (r0 - WR_HIST) * slots + s;
+				const float2 *__restrict__ src = chan_iq + (r0 - HIST) * slots + s;
 				for (unsigned int r = beg; r < end; r += POST_LB) {
 					float2 z[POST_LB + 1u];
 					z[0] = src[((size_t)r - 1u) * slots];
@@ -654,29 +664,29 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 				float2 zp = make_float2(0.0f, 0.0f);
 				if (m >= 0 && beg < end) {
 					const size_t rr = r0 + beg;
-					if (rr == WR_HIST)
+					if (rr == HIST)
 						zp = chan_prev ? chan_prev[((size_t)k1 - 1u) * slots + s] : prev_iq[s];
-					else if (rr > WR_HIST && rr - WR_HIST - 1u < k1)
-						zp = chan_iq[(rr - WR_HIST - 1u) * slots + s];
-					else if (rr < WR_HIST && chan_prev)
-						zp = chan_prev[((size_t)k1 - WR_HIST - 1u + rr) * slots + s];
+					else if (rr > HIST && rr - HIST - 1u < k1)
+						zp = chan_iq[(rr - HIST - 1u) * slots + s];
+					else if (rr < HIST && chan_prev)
+						zp = chan_prev[((size_t)k1 - HIST - 1u + rr) * slots + s];
 				}
 #pragma unroll 6
 				for (unsigned int r = beg; r < end; ++r) {
 					const size_t rr = r0 + r;
 					float v = 0.0f;
 					if (m >= 0) {
-						if (rr < WR_HIST && chan_prev) {
+						if (rr < HIST && chan_prev) {
 							/* (streaming launch) a history row = a demodulated frame of the block before, made again */
-							const float2 z = chan_prev[((size_t)k1 - WR_HIST + rr) * slots + s];
+							const float2 z = chan_prev[((size_t)k1 - HIST + rr) * slots + s];
 							v = demod_one(m, z.x, z.y, zp.x, zp.y);
 							zp = z;                                 /* (row 62: the predecessor of the block's first frame) */
-						} else if (rr < WR_HIST) {
+						} else if (rr < HIST) {
 							v = dem_hist[rr * slots + s];
-							if (rr + 1u == WR_HIST)
+							if (rr + 1u == HIST)
 								zp = prev_iq[s];                    /* the next row is the block's first frame */
-						} else if (rr - WR_HIST < k1) {
-							const float2 z = chan_iq[(rr - WR_HIST) * slots + s];
+						} else if (rr - HIST < k1) {
+							const float2 z = chan_iq[(rr - HIST) * slots + s];
 							v = demod_one(m, z.x, z.y, zp.x, zp.y);
 							zp = z;
 						}
@@ -692,8 +702,8 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 #pragma unroll
 			for (unsigned int o = 0; o < POST_B; ++o)
 				acc[o] = 0.0f;
-			const float *x = stage + (row * POST_B * D2) * 64u + lane;
 			if (HREGS) {
+				const float *x = stage + (row * POST_B * D2) * 64u + lane;
 				/* rows outermost: each staged row is read from LDS once and meets the tap of every
 				 * frame of the group that uses it (which tap: resolved at compile time) */
 #pragma unroll
@@ -706,6 +716,10 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 					}
 				}
 			} else {
+#pragma unroll 1
+			for (unsigned int seg = 0; seg < NSEG; ++seg) {     /* (oldest rows first) */
+				const float *x = stage + (row * POST_B * D2 + seg * WR_FIR_LENGTH) * 64u + lane;
+				const unsigned int tap0 = (NSEG - 1u - seg) * WR_FIR_LENGTH;
 				/* taps outermost, newest tap last (so that every frame still adds its products
 				 * oldest row first): one memory read per tap, shared by the frames of the group; the
 				 * rows come from LDS once per frame */
@@ -713,7 +727,7 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 					/* every channel of the lane group has the same audio filter (radio.cxx:78-79: the
 					 * usual case): its taps come through the scalar cache into SGPRs -- no vector
 					 * memory round trips behind the next block's DDC gathers in this phase at all */
-					const WR_CONSTANT float *tu = (const WR_CONSTANT float *)(A.taps2u + (size_t)g * WR_FIR_LENGTH);
+					const WR_CONSTANT float *tu = (const WR_CONSTANT float *)(A.taps2u + (size_t)g * (WR_FIR_LENGTH * NSEG) + tap0);
 #pragma unroll
 					for (int j = WR_FIR_LENGTH - 1; j >= 0; --j) {
 						const float hj = tu[j];
@@ -724,12 +738,13 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 				} else {
 #pragma unroll 16
 					for (int j = WR_FIR_LENGTH - 1; j >= 0; --j) {
-						const float hj = taps2[(size_t)j * slots + s];
+						const float hj = taps2[((size_t)tap0 + j) * slots + s];
 #pragma unroll
 						for (unsigned int o = 0; o < POST_B; ++o)
 							acc[o] = acc[o] + hj * x[(o * D2 + (WR_FIR_LENGTH - 1u - (unsigned int)j)) * 64u];
 					}
 				}
+			}                                           /* (segments) */
 			}
 #pragma unroll
 			for (unsigned int o = 0; o < POST_B; ++o)
@@ -757,15 +772,24 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 	}
 }
 
-template <unsigned int D2>
+template <unsigned int D2, unsigned int NSEG = 1u>
 __global__ void __launch_bounds__(POST_THREADS)
 k_tuner_post(WrPostArgs A)
 {
-	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH;
-	__shared__ float stage[NEED * 64u];
-	__shared__ float tile[POST_TK * 65u];
-	__shared__ int modes[64];
-	post_role<D2, true>(A, blockIdx.x, blockIdx.y, stage, tile, modes);
+	constexpr unsigned int NEED = (POST_TK - 1u) * D2 + WR_FIR_LENGTH * NSEG;
+	if constexpr (NSEG == 1u) {
+		__shared__ float stage[NEED * 64u];
+		__shared__ float tile[POST_TK * 65u];
+		__shared__ int modes[64];
+		post_role<D2, NSEG == 1u, NSEG>(A, blockIdx.x, blockIdx.y, stage, tile, modes);
+	} else {
+		/* (the window of a long filter: up to 406 rows = 104 KB at D2 = 10 and 256 taps -- dynamic LDS, launch_post) */
+		extern __shared__ float post_lds[];
+		float *stage = post_lds;
+		float *tile = stage + NEED * 64u;
+		int *modes = (int *)(tile + POST_TK * 65u);
+		post_role<D2, NSEG == 1u, NSEG>(A, blockIdx.x, blockIdx.y, stage, tile, modes);
+	}
 }
 
 /* LDS plan of k_tuner_ddc: [0, 128 KiB) the two replicated NCO tables (SPLIT only),
@@ -2033,8 +2057,9 @@ __global__ void __launch_bounds__(256)
 k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int slots,
               const int *__restrict__ mode,
               const float2 *__restrict__ prev_iq, float2 *__restrict__ prev_next,
-              float *__restrict__ dem, float *__restrict__ dem_next)
+              float *__restrict__ dem, float *__restrict__ dem_next, unsigned int hist)
 {
+	/* `hist` = the audio filter's taps - 1: 63, or 127 / 255 (LowPass::_firLength, lowpass.cxx:38-39) */
 	/* thread = (slot lane, row lane): 64 slots x 4 row lanes per workgroup, DEM_RPT rows each */
 	const unsigned int lane = threadIdx.x & 63u;
 	const unsigned int rl = threadIdx.x >> 6;
@@ -2055,9 +2080,9 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 			const unsigned int k = kbeg + i;
 			if (k < kend) {
 				const float v = demod_one(m, z[i + 1].x, z[i + 1].y, z[i].x, z[i].y);
-				dem[(size_t)(WR_HIST + k) * slots + s] = v;
-				if (k + WR_HIST >= k1)                  /* among the last 63 rows */
-					dem_next[(size_t)(k + WR_HIST - k1) * slots + s] = v;
+				dem[(size_t)(hist + k) * slots + s] = v;
+				if (k + hist >= k1)                     /* among the last `hist` rows */
+					dem_next[(size_t)(k + hist - k1) * slots + s] = v;
 				p = z[i + 1];
 			}
 		}
@@ -2066,8 +2091,8 @@ k_tuner_demod(const float2 *__restrict__ chan_iq, unsigned int k1, unsigned int 
 	}
 	/* blocks shorter than the history: the older part of the next history comes from the
 	 * current history rows (not written by this launch) */
-	if (k1 < WR_HIST && blockIdx.y == 0 && m >= 0)
-		for (unsigned int r = rl; r < WR_HIST - k1; r += 4u)
+	if (k1 < hist && blockIdx.y == 0 && m >= 0)
+		for (unsigned int r = rl; r < hist - k1; r += 4u)
 			dem_next[(size_t)r * slots + s] = dem[(size_t)(k1 + r) * slots + s];
 }
 
@@ -2085,13 +2110,14 @@ __global__ void __launch_bounds__(AUD_THREADS)
 k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsigned int d2,
               unsigned int tk, unsigned int slots, const float *__restrict__ taps2,
               const int *__restrict__ mode, float *__restrict__ audio, size_t k2max, float scale,
-              const float *__restrict__ gain, const float *__restrict__ squelch, const float2 *__restrict__ chan_iq)
+              const float *__restrict__ gain, const float *__restrict__ squelch, const float2 *__restrict__ chan_iq,
+              unsigned int len)
 {
-	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [64][64] taps, [AUD_TMAX][65] out */
-	const unsigned int need = (tk - 1u) * d2 + WR_FIR_LENGTH;
+	extern __shared__ float aud_lds[];      /* [AUD_ROWS][64] rows, [len][64] taps, [AUD_TMAX][65] out; len = 64, 128 or 256 taps */
+	const unsigned int need = (tk - 1u) * d2 + len;
 	float *stage = aud_lds;                             /* [need][64] */
 	float *taps = aud_lds + need * 64u;
-	float *tile = taps + 64u * 64u;
+	float *tile = taps + len * 64u;
 	const unsigned int lane = threadIdx.x & 63u;        /* slot within the group */
 	const unsigned int row = threadIdx.x >> 6;          /* 0..15 */
 	const unsigned int nrow = AUD_THREADS / 64u;
@@ -2099,7 +2125,7 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 	const unsigned int s = g * 64u + lane;
 	const size_t kbase = (size_t)blockIdx.x * tk;
 
-	for (unsigned int j = row; j < WR_FIR_LENGTH; j += nrow)
+	for (unsigned int j = row; j < len; j += nrow)
 		taps[j * 64u + lane] = taps2[(size_t)j * slots + s];
 	const size_t r0 = kbase * d2;
 	for (unsigned int r = row; r < need; r += nrow) {
@@ -2110,9 +2136,10 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 	for (unsigned int kk = row; kk < tk; kk += nrow) {
 		const float *x = stage + (kk * d2) * 64u + lane;
 		float acc = 0.0f;
+		const float *hrev = taps + (len - 1u) * 64u + lane;
 #pragma unroll 16
-		for (int j = 0; j < WR_FIR_LENGTH; ++j)
-			acc = acc + taps[(WR_FIR_LENGTH - 1 - j) * 64 + lane] * x[j * 64];
+		for (unsigned int j = 0; j < len; ++j)
+			acc = acc + hrev[-(int)(j * 64u)] * x[j * 64u];
 		tile[kk * 65u + lane] = acc;
 	}
 	__syncthreads();
@@ -2135,17 +2162,19 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 __global__ void __launch_bounds__(512)
 k_tuner_iq2(const float2 *__restrict__ in, size_t k1a, unsigned int d1b, unsigned int slots,
             const float *__restrict__ taps, const int *__restrict__ mode,
-            const float2 *__restrict__ hist, float2 *__restrict__ hist_next, float2 *__restrict__ out, unsigned int tiles)
+            const float2 *__restrict__ hist, float2 *__restrict__ hist_next, float2 *__restrict__ out, unsigned int tiles,
+            unsigned int len)
 {
+	const unsigned int nh = len - 1u;                   /* history rows: 63, or 127 / 255 for a stage of 128 / 256 taps */
 	const unsigned int lane = threadIdx.x & 63u, row = threadIdx.x >> 6;
 	const unsigned int s = blockIdx.y * 64u + lane;
 	const int m = mode[s];
 	auto xrow = [&](size_t r) -> float2 {              /* row r of [history | block] */
-		return (r < WR_HIST) ? hist[r * slots + s] : in[(r - WR_HIST) * slots + s];
+		return (r < nh) ? hist[r * slots + s] : in[(r - nh) * slots + s];
 	};
 	if (blockIdx.x == tiles) {
 		if (m >= 0)
-			for (unsigned int r = row; r < WR_HIST; r += 8u)
+			for (unsigned int r = row; r < nh; r += 8u)
 				hist_next[(size_t)r * slots + s] = xrow(k1a + r);
 		return;
 	}
@@ -2154,8 +2183,8 @@ k_tuner_iq2(const float2 *__restrict__ in, size_t k1a, unsigned int d1b, unsigne
 		return;
 	float ai = 0.0f, aq = 0.0f;
 #pragma unroll 8
-	for (int j = 0; j < WR_FIR_LENGTH; ++j) {
-		const float c = taps[(size_t)(WR_FIR_LENGTH - 1 - j) * slots + s];
+	for (unsigned int j = 0; j < len; ++j) {
+		const float c = taps[(size_t)(len - 1u - j) * slots + s];
 		const float2 x = xrow(k * d1b + j);
 		ai = ai + c * x.x;
 		aq = aq + c * x.y;
@@ -2172,7 +2201,7 @@ hipError_t wrk_tuner_iq2(hipStream_t st, const WrGroupDev &G, unsigned int slots
 	dim3 grid(tiles + 1u, slots_used / 64);
 	k_tuner_iq2<<<grid, 512, 0, st>>>((const float2 *)G.chan_iq[cb], k1a, d1b, slots, G.taps1b, G.mode,
 	                                  (const float2 *)G.iq2_hist[p2], (float2 *)G.iq2_hist[p2 ^ 1],
-	                                  (float2 *)G.chan_iq2[cb], tiles);
+	                                  (float2 *)G.chan_iq2[cb], tiles, G.l1b);
 	return hipGetLastError();
 }
 
@@ -2647,7 +2676,7 @@ hipError_t wrk_tuner_demod(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	dim3 grid(L.slots_used / 64, (unsigned int)((L.k1 + 4 * DEM_RPT - 1) / (4 * DEM_RPT)));
 	k_tuner_demod<<<grid, 256, 0, st>>>(
 		(const float2 *)G.chan_iq[L.cb], (unsigned int)L.k1, L.slots, G.mode, (const float2 *)G.prev_iq[p],
-		(float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1]);
+		(float2 *)G.prev_iq[p ^ 1], G.dem[p], G.dem[p ^ 1], G.l2 - 1u);
 	return hipGetLastError();
 }
 
@@ -2689,6 +2718,7 @@ WrPostArgs wrk_post_args(const WrTunerLaunch &L, const WrGroupDev &G)
 	A.squelch = L.use_squelch ? G.squelch : nullptr;
 	A.audio_host = nullptr;
 	A.host_stride = 0;
+	A.nseg = G.l2 / WR_FIR_LENGTH;                      /* 1; 2 / 4: an audio filter of 128 / 256 taps */
 	return A;
 }
 
@@ -2696,7 +2726,23 @@ template <unsigned int D2>
 static hipError_t launch_post(hipStream_t st, const WrPostArgs &A)
 {
 	dim3 grid(A.ntiles + 1u, A.groups);
-	k_tuner_post<D2><<<grid, POST_THREADS, 0, st>>>(A);
+	/* (an audio filter of 128 / 256 taps: 2 / 4 segments of 64, post_role) */
+	if (A.nseg == 2u || A.nseg == 4u) {
+		const size_t lds = (((size_t)(POST_TK - 1u) * D2 + WR_FIR_LENGTH * A.nseg) * 64u + POST_TK * 65u + 64u) * sizeof(float);
+		static bool attr2[WR_MAX_DEVICES], attr4[WR_MAX_DEVICES];
+		const size_t lds_max = (((size_t)(POST_TK - 1u) * D2 + WR_FIR_LENGTH * 4u) * 64u + POST_TK * 65u + 64u) * sizeof(float);
+		hipError_t e = A.nseg == 2u ? allow_lds((const void *)k_tuner_post<D2, 2u>, lds_max, attr2)
+		                            : allow_lds((const void *)k_tuner_post<D2, 4u>, lds_max, attr4);
+		if (e != hipSuccess)
+			return e;
+		if (A.nseg == 2u)
+			k_tuner_post<D2, 2u><<<grid, POST_THREADS, lds, st>>>(A);
+		else
+			k_tuner_post<D2, 4u><<<grid, POST_THREADS, lds, st>>>(A);
+	} else if (A.nseg == 1u)
+		k_tuner_post<D2><<<grid, POST_THREADS, 0, st>>>(A);
+	else
+		return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 
@@ -2722,6 +2768,9 @@ hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A0)
 		static const int forced = getenv("WR_POST_FLUSH_RUN") ? atoi(getenv("WR_POST_FLUSH_RUN")) : 0;
 		const unsigned int all = A.tiles * A.groups;
 		A.run = forced > 0 ? (unsigned int)forced : all >= 4096u ? 2u : 1u;   /* C2, four blocks: 43.6 / 33.6 / 36.0 us at runs of 1 / 2 / 4 */
+		if (forced <= 0 && A.nseg == 4u && all >= 1024u)
+			A.run = 2u;     /* 256 taps: a tile stages 331 rows for its 80 new ones (D2 = 5) and one workgroup fits a CU --
+			                   C2, us per block all in at runs of 1 / 2 / 4: 91 / 83 / 104 (128 taps: 61 / 67 / 79) */
 	}
 	A.ntiles = (A.tiles + A.run - 1u) / A.run;
 	switch (A.d2) {
@@ -2749,24 +2798,25 @@ hipError_t wrk_tuner_audio(hipStream_t st, const WrTunerLaunch &L, const WrGroup
 	if (!L.k2 || !L.slots_used)
 		return hipSuccess;
 	/* as many output frames per tile as the staged rows allow */
+	const unsigned int len = G.l2;                      /* 64, or 128 / 256 taps (LowPass::_firLength) */
 	unsigned int tk = AUD_TMAX;
-	if (L.d2 > 1 && (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u < tk)
-		tk = (AUD_ROWS - WR_FIR_LENGTH) / L.d2 + 1u;
+	if (L.d2 > 1 && (AUD_ROWS - len) / L.d2 + 1u < tk)
+		tk = (AUD_ROWS - len) / L.d2 + 1u;
 	/* LDS sized to what this decimation needs, so that two workgroups fit a CU when D2 is small */
-	const unsigned int need = (tk - 1u) * L.d2 + WR_FIR_LENGTH;
-	const size_t lds = ((size_t)need * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
+	const unsigned int need = (tk - 1u) * L.d2 + len;
+	const size_t lds = ((size_t)need * 64u + (size_t)len * 64u + AUD_TMAX * 65u) * sizeof(float);
 	static bool attr_done[WR_MAX_DEVICES];
 	{
-		const size_t lds_max = ((size_t)AUD_ROWS * 64u + 64u * 64u + AUD_TMAX * 65u) * sizeof(float);
+		const size_t lds_max = ((size_t)AUD_ROWS * 64u + (size_t)WR_FIR_FUSED_MAX * 64u + AUD_TMAX * 65u) * sizeof(float);   /* 156 KiB of 160 */
 		hipError_t e = allow_lds((const void *)k_tuner_audio, lds_max, attr_done);
 		if (e != hipSuccess)
 			return e;
 	}
 	dim3 grid((unsigned int)((L.k2 + tk - 1) / tk), L.slots_used / 64);
-	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], WR_HIST + L.k1, L.k2, L.d2, tk, L.slots,
+	k_tuner_audio<<<grid, AUD_THREADS, lds, st>>>(G.dem[L.parity], (size_t)(len - 1u) + L.k1, L.k2, L.d2, tk, L.slots,
 	                                      G.taps2, G.mode, G.audio, L.k2max, L.audio_scale,
 	                                      L.use_gain ? G.gain : nullptr, L.use_squelch ? G.squelch : nullptr,
-	                                      (const float2 *)G.chan_iq[L.cb]);
+	                                      (const float2 *)G.chan_iq[L.cb], len);
 	return hipGetLastError();
 }
 
@@ -2799,6 +2849,12 @@ hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int
 	k_seek<<<(rows + 255u) / 256u, 256, 0, st>>>(G.phase[sp], G.step, frame, (float2 *)G.hist_cs[sp],
 	                                             (float2 *)G.hist_lo[sp], (float2 *)G.prev_iq[parity], G.dem[parity],
 	                                             (float2 *)G.iq2_hist[p2], slots);
+	/* (an audio filter or a second channel stage of 128 / 256 taps keeps 127 / 255 rows: the rest of them) */
+	if (G.l2 > WR_FIR_LENGTH && hipMemsetAsync(G.dem[parity], 0, (size_t)(G.l2 - 1u) * slots * sizeof(float), st) != hipSuccess)
+		return hipGetLastError();
+	if (G.l1b > WR_FIR_LENGTH && G.iq2_hist[p2] &&
+	    hipMemsetAsync(G.iq2_hist[p2], 0, (size_t)(G.l1b - 1u) * slots * 2u * sizeof(float), st) != hipSuccess)
+		return hipGetLastError();
 	return hipGetLastError();
 }
 

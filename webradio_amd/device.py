@@ -111,8 +111,8 @@ class Tuner:
         """Receiver() + setFrontEnd(): the wiring of radio.cxx:62-90 with explicit parameters.
         fir_lengths: (channel, audio) LowPass::_firLength, powers of two: the channel filter up to 256
         (WR_FIR_FUSED_MAX; above 64: WR_NCO_EXACT the reference's own arithmetic, the other modes the ROTATE recurrence in L / 64 segments),
-        the audio filter up to 64 (default 64, 64).
-        stage2: (fir_length, passband, out_rate) of a second channel LowPass in front of the demodulator."""
+        the audio filter up to 256 as well (r05; default 64, 64).
+        stage2: (fir_length, passband, out_rate) of a second channel LowPass in front of the demodulator; fir_length up to 256."""
         c = C.c_int()
         check(self.lib.wr_chan_add(self.h, C.byref(c)))
         ch = c.value

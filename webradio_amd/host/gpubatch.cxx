@@ -579,11 +579,11 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 		return NULL;
 	if (f1->_channel || dm->_channel || f2->_channel || (f1b && f1b->_channel))
 		return NULL;
-	if (f1->firLength() > WR_FIR_FUSED_MAX || f2->firLength() > WR_FIR_LENGTH ||
-	    (f1b && f1b->firLength() > WR_FIR_LENGTH))
-		return NULL;                         /* the fused path takes up to the reference's 64 taps (shorter filters
-		                                        ride as 64 taps with the oldest ones zero) and, for the channel filter,
-		                                        128 or 256 (a plain kernel with the reference's arithmetic) */
+	if (f1->firLength() > WR_FIR_FUSED_MAX || f2->firLength() > WR_FIR_FUSED_MAX ||
+	    (f1b && f1b->firLength() > WR_FIR_FUSED_MAX))
+		return NULL;                         /* the tuner takes the reference's 64 taps (shorter filters ride as 64 taps
+		                                        with the oldest ones zero) and 128 or 256 for any of the three filters
+		                                        (r05: the audio filter and the second channel stage too) */
 
 	TunerBatch *batch = src->batch();
 	if (!batch) {
@@ -734,7 +734,7 @@ bool TunerBatch::pushParams(Channel *ch)
 			std::lock_guard<std::mutex> g(fs[n]->_coeffLock);          /* see LowPass::recalculate */
 			taps = fs[n]->_coeff;
 		}
-		if (!taps.empty() && taps.size() <= (n == 0 ? (size_t)WR_FIR_FUSED_MAX : (size_t)WR_FIR_LENGTH) &&
+		if (!taps.empty() && taps.size() <= (size_t)WR_FIR_FUSED_MAX &&
 		    wr_chan_set_taps_n(_tuner, ch->id, stages[n], taps.data(), (unsigned int)taps.size(),
 		                       fs[n]->decimation()) != WR_OK)
 			return false;
