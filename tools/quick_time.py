@@ -22,14 +22,17 @@ for name in which:
     t = Tuner(dev, fs, nch, n, modes[name])
     if os.environ.get("QT_KEEP") == "1":
         t.keep_stages(capi.WR_STAGE_DEMOD)
+    # QT_L1B: a second channel stage of that many taps, 250 k -> 50 k (the audio filter then 50 k -> 10 k)
+    st2 = (int(os.environ["QT_L1B"]), c2["chan_rate"] // 16, c2["chan_rate"] // 5) if os.environ.get("QT_L1B") else None
     mixed = os.environ.get("QT_MIXED") == "1"     # per-lane taps: a different passband per channel
     for i, f in enumerate(ifs):
         odd = os.environ.get("QT_ONE_ODD") == "1" and i == 70       # one receiver with its own passband
         t.add_receiver(f, c2["chan_passband"] + (3_000_000 * (i % 7) if mixed else 0) + (3_000_000 if odd else 0),
                        c2["chan_rate"], capi.WR_FM,
-                       c2["audio_passband"], c2["audio_rate"],
+                       c2["audio_passband"] // (5 if st2 else 1), c2["audio_rate"] // (5 if st2 else 1),
                        fir_lengths=(int(os.environ.get("QT_L1", "64")), int(os.environ.get("QT_L2", "64")))
-                       if os.environ.get("QT_L1") or os.environ.get("QT_L2") else None)   # 128 / 256: k_tuner_ddc_long; r05: QT_L2, the audio filter
+                       if os.environ.get("QT_L1") or os.environ.get("QT_L2") else None,   # 128 / 256: k_tuner_ddc_long; r05: QT_L2, the audio filter
+                       stage2=st2)
     for i in range(4):
         t.submit_device(blocks[i % nb], n)
     torch.cuda.synchronize()

@@ -2768,9 +2768,10 @@ hipError_t wrk_tuner_post_args(hipStream_t st, const WrPostArgs &A0)
 		static const int forced = getenv("WR_POST_FLUSH_RUN") ? atoi(getenv("WR_POST_FLUSH_RUN")) : 0;
 		const unsigned int all = A.tiles * A.groups;
 		A.run = forced > 0 ? (unsigned int)forced : all >= 4096u ? 2u : 1u;   /* C2, four blocks: 43.6 / 33.6 / 36.0 us at runs of 1 / 2 / 4 */
-		if (forced <= 0 && A.nseg == 4u && all >= 1024u)
+		if (forced <= 0 && A.nseg == 4u && all >= 384u)
 			A.run = 2u;     /* 256 taps: a tile stages 331 rows for its 80 new ones (D2 = 5) and one workgroup fits a CU --
-			                   C2, us per block all in at runs of 1 / 2 / 4: 91 / 83 / 104 (128 taps: 61 / 67 / 79) */
+			                   C2 (500 tiles), us per block all in at runs of 1 / 2 / 4: 93 / 83 / 104 (128 taps: 62 / 69 / 79),
+			                   profiles/r05_long_filter.txt */
 	}
 	A.ntiles = (A.tiles + A.run - 1u) / A.run;
 	switch (A.d2) {
