@@ -2144,19 +2144,21 @@ static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int whe
 		const bool long_rides = g->l1 > WR_FIR_LENGTH && g->long_uniform && long_rot_enabled();
 		/* (r05: an audio filter of 128 / 256 taps -- k_tuner_post<D2, 2 | 4> -- goes out on its own behind the DDC: the
 		 * workgroups that ride are compiled for 64 taps) */
-		const bool defer = !two_kernels && !g->d1b && (g->l1 <= WR_FIR_LENGTH || long_rides) && L.k1 && t->defer_post &&
+		/* (r05: a group with a second channel stage defers as well -- its post stage reads chan_iq2, which the NEXT block's
+		 * k_tuner_iq2 does not touch: that one writes the other buffer, behind the launch the post stage rides in) */
+		const bool defer = !two_kernels && (g->l1 <= WR_FIR_LENGTH || long_rides) && Lp.k1 && t->defer_post &&
 		                   t->nco_mode == WR_NCO_ROTATE && g->l2 == WR_FIR_LENGTH;
 		if (two_kernels) {
 			HIP_TRY(wrk_tuner_demod(st, Lp, Gp));
 			HIP_TRY(wrk_tuner_audio(st, Lp, Gp));
 		} else if (defer) {
 			g->post_pending = true;
-			g->post_args = wrk_post_args(L, Gs);
+			g->post_args = wrk_post_args(Lp, Gp);
 			g->pend_seq = seq;
-			g->pend_k2 = L.k2;
+			g->pend_k2 = Lp.k2;
 			g->pend_slots = L.slots_used;
-			g->post_args.audio_host = ring_reserve(t, g, L.k2, L.slots_used);
-			g->post_args.host_stride = L.k2;            /* the ring's rows lie back to back (RingSlot::stride = frames) */
+			g->post_args.audio_host = ring_reserve(t, g, Lp.k2, L.slots_used);
+			g->post_args.host_stride = Lp.k2;           /* the ring's rows lie back to back (RingSlot::stride = frames) */
 			g->pend_direct = g->post_args.audio_host != nullptr;
 		} else {
 			HIP_TRY(wrk_tuner_post(st, Lp, Gp));

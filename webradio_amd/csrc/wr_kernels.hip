@@ -2154,17 +2154,26 @@ k_tuner_audio(const float *__restrict__ dem, size_t rows_valid, size_t k2, unsig
 }
 
 /* A second channel LowPass::process (dsp/lowpass.cxx:131-162, 2 channels) on the channel-rate IQ of
- * every receiver, between the DDC and the demodulator: out[k][s] = sum_j coeff[63 - j] * X[k*D + j][s]
- * over X = [63 history rows | the block's k1a first-stage rows], products added oldest row first,
- * unfused, I and Q apart (lowpass.cxx:150-158 walks the channels innermost).  Thread = (slot, output
- * frame); a wave reads whole 512-byte rows.  blockIdx.x == tiles: the next history (last 63 rows). */
-#define IQ2_TK 8u
+ * every receiver, between the DDC and the demodulator: out[k][s] = sum_j coeff[L - 1 - j] * X[k*D + j][s]
+ * over X = [L - 1 history rows | the block's k1a first-stage rows], products added oldest row first,
+ * unfused, I and Q apart (lowpass.cxx:150-158 walks the channels innermost).  L = 64, 128 or 256 taps.
+ * r05: tiled through LDS.  Workgroup = 64 slots x `tk` output frames; per SEGMENT of 64 taps, oldest rows
+ * first, the (tk - 1) D + 64 rows the tile's frames meet and the segment's 64 x 64 taps are staged once
+ * (whole 512-byte / 256-byte rows per wave) and every wave runs its output frames (IQ2_B of them share a
+ * tap read) over them, the sums carried from segment to segment in registers -- the order of additions
+ * is the reference's.  (r02-r04: every thread read its 64 taps and 64 rows straight from L2: 20 / 42 / 84 us
+ * per C2 block at 64 / 128 / 256 taps.)  blockIdx.x == tiles: the next history (last L - 1 rows). */
+static hipError_t allow_lds(const void *fn, size_t bytes, bool (&done)[WR_MAX_DEVICES]);
+#define IQ2_ROWS 128u           /* staged rows: 128 x 64 x 8 B = 64 KiB; + 16 KiB of taps: two workgroups per CU */
+#define IQ2_B 2u                /* output frames per wave */
+#define IQ2_TKMAX (8u * IQ2_B)
 __global__ void __launch_bounds__(512)
 k_tuner_iq2(const float2 *__restrict__ in, size_t k1a, unsigned int d1b, unsigned int slots,
             const float *__restrict__ taps, const int *__restrict__ mode,
             const float2 *__restrict__ hist, float2 *__restrict__ hist_next, float2 *__restrict__ out, unsigned int tiles,
-            unsigned int len)
+            unsigned int len, unsigned int tk)
 {
+	extern __shared__ float iq2_lds[];                  /* [need][64] float2 rows, then [64][64] taps of the segment */
 	const unsigned int nh = len - 1u;                   /* history rows: 63, or 127 / 255 for a stage of 128 / 256 taps */
 	const unsigned int lane = threadIdx.x & 63u, row = threadIdx.x >> 6;
 	const unsigned int s = blockIdx.y * 64u + lane;
@@ -2178,18 +2187,72 @@ k_tuner_iq2(const float2 *__restrict__ in, size_t k1a, unsigned int d1b, unsigne
 				hist_next[(size_t)r * slots + s] = xrow(k1a + r);
 		return;
 	}
-	const size_t k = (size_t)blockIdx.x * IQ2_TK + row;
-	if (m < 0 || k >= k1a / d1b)
-		return;
-	float ai = 0.0f, aq = 0.0f;
+	const unsigned int need = (tk - 1u) * d1b + WR_FIR_LENGTH;
+	float2 *st = (float2 *)iq2_lds;
+	float *tp = iq2_lds + (size_t)need * 128u;
+	const size_t kout = k1a / d1b;
+	const size_t k0 = (size_t)blockIdx.x * tk;
+	const size_t rows_valid = (size_t)nh + k1a;
+	float ai[IQ2_B], aq[IQ2_B];
+#pragma unroll
+	for (unsigned int b = 0; b < IQ2_B; ++b)
+		ai[b] = aq[b] = 0.0f;
+	const unsigned int nseg = len / WR_FIR_LENGTH;
+	/* a thread's share of a segment -- 8 tap rows, up to 16 window rows -- is loaded into registers in one go (one
+	 * memory round trip per segment, not one per row) and the NEXT segment's while this one is being summed */
+	float tv[WR_FIR_LENGTH / 8u];
+	float2 xv[IQ2_ROWS / 8u];
+	auto fetch = [&](unsigned int seg) {
+		const size_t r0 = k0 * d1b + (size_t)seg * WR_FIR_LENGTH;
+		const unsigned int tap0 = (nseg - 1u - seg) * WR_FIR_LENGTH;
+#pragma unroll
+		for (unsigned int i = 0; i < WR_FIR_LENGTH / 8u; ++i)
+			tv[i] = taps[((size_t)tap0 + row + 8u * i) * slots + s];
+#pragma unroll
+		for (unsigned int i = 0; i < IQ2_ROWS / 8u; ++i) {
+			const unsigned int r = row + 8u * i;
+			const size_t rr = r0 + r;
+			xv[i] = (m >= 0 && r < need && rr < rows_valid) ? xrow(rr) : make_float2(0.0f, 0.0f);
+		}
+	};
+	fetch(0);
+	for (unsigned int seg = 0; seg < nseg; ++seg) {
+		if (seg)
+			__syncthreads();                            /* the segment before has been read */
+#pragma unroll
+		for (unsigned int i = 0; i < WR_FIR_LENGTH / 8u; ++i)
+			tp[(row + 8u * i) * 64u + lane] = tv[i];
+#pragma unroll
+		for (unsigned int i = 0; i < IQ2_ROWS / 8u; ++i) {
+			const unsigned int r = row + 8u * i;
+			if (r < need)
+				st[r * 64u + lane] = xv[i];
+		}
+		__syncthreads();
+		if (seg + 1u < nseg)
+			fetch(seg + 1u);
 #pragma unroll 8
-	for (unsigned int j = 0; j < len; ++j) {
-		const float c = taps[(size_t)(len - 1u - j) * slots + s];
-		const float2 x = xrow(k * d1b + j);
-		ai = ai + c * x.x;
-		aq = aq + c * x.y;
+		for (unsigned int j = 0; j < WR_FIR_LENGTH; ++j) {
+			const float c = tp[(WR_FIR_LENGTH - 1u - j) * 64u + lane];
+#pragma unroll
+			for (unsigned int b = 0; b < IQ2_B; ++b) {
+				const unsigned int kk = row + 8u * b;   /* (rows beyond the tile's: within the staged window or not read) */
+				if (kk < tk) {
+					const float2 x = st[(kk * d1b + j) * 64u + lane];
+					ai[b] = ai[b] + c * x.x;
+					aq[b] = aq[b] + c * x.y;
+				}
+			}
+		}
 	}
-	out[k * slots + s] = make_float2(ai, aq);
+	if (m < 0)
+		return;
+#pragma unroll
+	for (unsigned int b = 0; b < IQ2_B; ++b) {
+		const unsigned int kk = row + 8u * b;
+		if (kk < tk && k0 + kk < kout)
+			out[(k0 + kk) * slots + s] = make_float2(ai[b], aq[b]);
+	}
 }
 
 hipError_t wrk_tuner_iq2(hipStream_t st, const WrGroupDev &G, unsigned int slots, unsigned int slots_used,
@@ -2197,11 +2260,23 @@ hipError_t wrk_tuner_iq2(hipStream_t st, const WrGroupDev &G, unsigned int slots
 {
 	if (!slots_used || !d1b)
 		return hipSuccess;
-	const unsigned int tiles = (unsigned int)((k1a / d1b + IQ2_TK - 1) / IQ2_TK);
+	/* as many output frames per tile as the staged rows allow (D = 5: 13; D = 10: 7; D >= 64: one) */
+	unsigned int tk = IQ2_TKMAX;
+	if ((IQ2_ROWS - WR_FIR_LENGTH) / d1b + 1u < tk)
+		tk = (IQ2_ROWS - WR_FIR_LENGTH) / d1b + 1u;
+	const unsigned int need = (tk - 1u) * d1b + WR_FIR_LENGTH;
+	const size_t lds = ((size_t)need * 128u + 64u * 64u) * sizeof(float);
+	static bool attr_done[WR_MAX_DEVICES];
+	{
+		hipError_t e = allow_lds((const void *)k_tuner_iq2, ((size_t)IQ2_ROWS * 128u + 64u * 64u) * sizeof(float), attr_done);
+		if (e != hipSuccess)
+			return e;
+	}
+	const unsigned int tiles = (unsigned int)((k1a / d1b + tk - 1) / tk);
 	dim3 grid(tiles + 1u, slots_used / 64);
-	k_tuner_iq2<<<grid, 512, 0, st>>>((const float2 *)G.chan_iq[cb], k1a, d1b, slots, G.taps1b, G.mode,
-	                                  (const float2 *)G.iq2_hist[p2], (float2 *)G.iq2_hist[p2 ^ 1],
-	                                  (float2 *)G.chan_iq2[cb], tiles, G.l1b);
+	k_tuner_iq2<<<grid, 512, lds, st>>>((const float2 *)G.chan_iq[cb], k1a, d1b, slots, G.taps1b, G.mode,
+	                                    (const float2 *)G.iq2_hist[p2], (float2 *)G.iq2_hist[p2 ^ 1],
+	                                    (float2 *)G.chan_iq2[cb], tiles, G.l1b, tk);
 	return hipGetLastError();
 }
 
