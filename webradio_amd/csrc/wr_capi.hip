@@ -2388,11 +2388,13 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 			n_post = np;
 		}
 	}
-	if (!s.ctl) {
+	/* (each on its own: an allocation that failed last time is tried again, never skipped because an earlier one stands) */
+	if (!s.ctl)
 		HIP_TRY(hipHostMalloc((void **)&s.ctl, sizeof(WrStreamCtl), hipHostMallocMapped | hipHostMallocCoherent));
+	if (!s.desc)
 		HIP_TRY(hipHostMalloc((void **)&s.desc, sizeof(WrStreamDesc) * WR_STREAM_MAXJ, hipHostMallocMapped | hipHostMallocCoherent));
+	if (!s.sdev)
 		HIP_TRY(hipMalloc((void **)&s.sdev, sizeof(WrStreamDev)));
-	}
 	const size_t ring_floats = (size_t)WR_STREAM_RING * k1 * g->slots * 2u;
 	if (ring_floats > s.ring_floats) {
 		HIP_TRY(dev_stream_sync(d));

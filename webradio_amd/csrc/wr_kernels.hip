@@ -2926,12 +2926,12 @@ hipError_t wrk_seek(hipStream_t st, const WrGroupDev &G, unsigned int slots, int
 	                                             (float2 *)G.hist_lo[sp], (float2 *)G.prev_iq[parity], G.dem[parity],
 	                                             (float2 *)G.iq2_hist[p2], slots);
 	/* (an audio filter or a second channel stage of 128 / 256 taps keeps 127 / 255 rows: the rest of them) */
-	if (G.l2 > WR_FIR_LENGTH && hipMemsetAsync(G.dem[parity], 0, (size_t)(G.l2 - 1u) * slots * sizeof(float), st) != hipSuccess)
-		return hipGetLastError();
-	if (G.l1b > WR_FIR_LENGTH && G.iq2_hist[p2] &&
-	    hipMemsetAsync(G.iq2_hist[p2], 0, (size_t)(G.l1b - 1u) * slots * 2u * sizeof(float), st) != hipSuccess)
-		return hipGetLastError();
-	return hipGetLastError();
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && G.l2 > WR_FIR_LENGTH)
+		e = hipMemsetAsync(G.dem[parity], 0, (size_t)(G.l2 - 1u) * slots * sizeof(float), st);
+	if (e == hipSuccess && G.l1b > WR_FIR_LENGTH && G.iq2_hist[p2])
+		e = hipMemsetAsync(G.iq2_hist[p2], 0, (size_t)(G.l1b - 1u) * slots * 2u * sizeof(float), st);
+	return e;
 }
 
 __global__ void k_input_hist(const float2 *__restrict__ cur, const uchar2 *__restrict__ cur_u8, size_t nframes,
