@@ -224,8 +224,13 @@ struct WrStreamDev {                       /* device memory: what the bell wave 
 	unsigned long long progress;               /* low word: blocks whose channel IQ is complete; high word: blocks whose post
 	                                              stage is complete, in order.  ONE writer (the watcher wave), one 8-byte store:
 	                                              a DDC wave entering a block learns both with one load */
-	unsigned int pad1[30];
-	unsigned int post_done[WR_STREAM_MAXJ];    /* post workgroups that have finished block j */
+	unsigned int drain_from;                   /* 0, or 1 + the first block whose post-stage tasks are handed out by TICKET (post_ticket)
+	                                              instead of by workgroup index: the watcher sets it when it learns that the stream is
+	                                              closed, to a block nobody can have begun (its channel IQ is not complete yet) -- from
+	                                              there on the DDC workgroups, which have nothing left to do, take post tasks too */
+	unsigned int pad1[29];
+	unsigned int post_done[WR_STREAM_MAXJ];    /* post-stage TASKS of block j that are finished (their stores released) */
+	unsigned int post_ticket[WR_STREAM_MAXJ];  /* the next task of block j to hand out (blocks from drain_from on) */
 	unsigned int ddc_done[WR_STREAM_MAXJ][WR_STREAM_SHARDS][32];   /* lane-group units of block j whose channel IQ is in memory:
 	                                              the sum over the shards' first words (wave w arrives on shard w mod SHARDS) */
 	WrStreamDesc desc[WR_STREAM_MAXJ];
