@@ -320,6 +320,50 @@ def test_long_audio_filter_keeps_its_history_over_a_seek_and_a_kept_demodulator(
     t.destroy()
 
 
+def test_long_filters_at_c2_full_size(dev, oracle):
+    """BASELINE config 2's size (256 receivers, one 4 M-frame block off 100 Msps, input made on the device) with a second
+    channel stage of 128 taps (250 k -> 50 k) and an audio filter of 256 taps (50 k -> 10 k), AM:
+      - EXACT: three receivers against the oracle's cascade on the first 400 000 frames (causal filters: a prefix of the
+        input gives a prefix of every stage), bit for bit -- second-stage IQ and audio;
+      - ROTATE (the shipped mode: k_tuner_iq2, its post stage k_tuner_post<5, 4> riding/launched as the tuner decides)
+        against EXACT on ALL 256 receivers within the ROTATE tolerance through the two filters' absolute gains."""
+    import torch
+    c2 = synth.C2
+    fs, n = c2["input_rate"], c2["block_frames"]
+    ifs = synth.c2_ifs()
+    d1 = fs // c2["chan_rate"]
+    r1 = c2["chan_rate"]
+    st2 = (128, r1 // 16, r1 // 5)
+    pb2, arate = r1 // 5 // 8, r1 // 5 // 5
+    x = synth.fm_stream_torch(n, fs, ifs[::4], "cuda")
+    torch.cuda.synchronize()
+    outs = {}
+    for mode in (capi.WR_NCO_EXACT, capi.WR_NCO_ROTATE):
+        t = Tuner(dev, fs, 256, n, mode)
+        chans = [t.add_receiver(f, c2["chan_passband"], r1, capi.WR_AM, pb2, arate, fir_lengths=(64, 256), stage2=st2) for f in ifs]
+        t.submit_device(x, n)
+        dev.sync()
+        k1b, k2 = n // d1 // 5, n // d1 // 5 // 5
+        outs[mode] = [(t.fetch(ch, capi.WR_STAGE_CHAN_IQ, 2 * k1b), t.fetch(ch, capi.WR_STAGE_AUDIO, k2)) for ch in chans]
+        assert outs[mode][0][0].size == 2 * k1b and outs[mode][0][1].size == k2
+        t.destroy()
+    g1b = max(1.0, float(np.abs(oracle.lowpass_design(st2[1], r1, st2[0])).sum()))
+    g2 = max(1.0, float(np.abs(oracle.lowpass_design(pb2, r1 // 5, 256)).sum()))
+    worst_iq = max(float(np.abs(a[0] - b[0]).max()) for a, b in zip(outs[capi.WR_NCO_EXACT], outs[capi.WR_NCO_ROTATE]))
+    worst_au = max(float(np.abs(a[1] - b[1]).max()) for a, b in zip(outs[capi.WR_NCO_EXACT], outs[capi.WR_NCO_ROTATE]))
+    assert worst_iq <= 1e-6 * g1b and worst_au <= 2e-6 * g1b * g2, (worst_iq, worst_au)
+    assert max(float(np.abs(a[1]).max()) for a in outs[capi.WR_NCO_EXACT][::4]) > 1e-3       # the carrier channels are live
+    m = 400_000
+    xh = x[: 2 * m].cpu().numpy()
+    for c in (0, 128, 252):
+        rx = OracleChain(oracle, fs, ifs[c], 64, c2["chan_passband"], d1, oracle.AM, 256, pb2, 5, stage2=(128, st2[1], 5))
+        wa, wc, _ = rx.run(xh)
+        got_iq, got_au = outs[capi.WR_NCO_EXACT][c]
+        assert wc.size and wa.size
+        assert np.array_equal(got_iq[: wc.size].view(np.uint32), wc.view(np.uint32)), c
+        assert np.array_equal(got_au[: wa.size].view(np.uint32), wa.view(np.uint32)), c
+
+
 @pytest.mark.parametrize("keep_demod", [False, True])
 def test_af_gain_and_squelch(dev, oracle, keep_demod):
     """af_gain / squelch (named and left as FIXMEs by the reference, receiverhandler.cxx:112-127): the
