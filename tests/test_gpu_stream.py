@@ -140,6 +140,46 @@ def test_whatever_touches_the_tuner_closes_the_launch(dev):
         assert u.shape == v.shape and np.array_equal(_bits(u), _bits(v))
 
 
+def test_two_tuners_on_one_device_both_asked_to_stream(dev):
+    """One streaming launch per device at a time (its workgroups must all be resident, and it holds the device's stream):
+    with two tuners on one wr_dev submitting in turn, each submit closes the other tuner's launch at its block boundary
+    and opens its own -- a launch per block again, no worse -- and a tuner left alone streams as usual.  Both tuners'
+    audio: the bits of the ordinary path."""
+    nch, nblk = 70, 6
+    x = _stream_dev(2 * nblk, nch)
+
+    def run(stream):
+        ta, ca = _tuner(dev, nch)
+        tb, cb = _tuner(dev, nch, modes=(capi.WR_AM, capi.WR_FM))
+        for t in (ta, tb):
+            t.streaming(stream)
+            t.audio_ring(nblk + 3)
+        for b in range(nblk):                                    # in turn: the other tuner's launch is open at every submit
+            ta.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+            tb.submit_device(x[2 * N * (nblk + b): 2 * N * (nblk + b + 1)], N)
+        ta.flush()
+        tb.flush()
+        oa, ob = _drain(ta, nblk), _drain(tb, nblk)
+        ia, ib = ta.stream_info(), tb.stream_info()
+        for b in range(3):                                        # b alone: one launch for the three
+            tb.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        tb.flush()
+        ob += _drain(tb, 3)
+        ib2 = tb.stream_info()
+        ta.destroy()
+        tb.destroy()
+        return oa, ob, ia, ib, ib2
+
+    pa, pb, _, _, _ = run(False)
+    sa, sb, ia, ib, ib2 = run(True)
+    assert ia[1] >= nblk - 1 and ib[1] >= nblk - 1, (ia, ib)      # a launch per block each while they took turns
+    assert ib2[1] == ib[1] + 1 and ib2[2] == ib[2] + 3, (ib, ib2)  # ... and ONE for the three blocks b submitted alone
+    for want, got in ((pa, sa), (pb, sb)):
+        assert [q for q, _ in want] == [q for q, _ in got]
+        for (_, u), (_, v) in zip(want, got):
+            assert u.shape == v.shape and np.array_equal(_bits(u), _bits(v))
+
+
 def test_a_blocks_audio_arrives_without_a_flush(dev):
     """dspblock.cxx:169-212: a block's output leaves within its own run().  The ring entry of a streamed block
     becomes ready when the launch's post stage has finished THAT block -- nothing has to follow it, nobody has to
