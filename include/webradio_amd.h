@@ -448,7 +448,11 @@ int wr_tuner_set_blocks_per_launch(wr_tuner *tuner, unsigned int nblocks);
  *   Rules for the caller: a block's memory stays untouched until the NEXT block's audio is complete (or the launch is
  * closed and the stream waited for); before waiting for the device's stream by other means than this library
  * (hipStreamSynchronize on a stream handed to wr_dev_open, torch.cuda.synchronize()) call wr_tuner_flush -- an open
- * launch that nobody rings ends by itself only after half a second. */
+ * launch that nobody rings ends by itself only after half a second.  An open launch holds nearly every wave slot and
+ * register of the GPU: calls on the same wr_dev close it first (a second tuner of the device that streams too takes
+ * turns with it, a launch per block), but work sent to the GPU by other means -- another wr_dev, another process --
+ * waits until the launch has ended; one streaming launch per GPU and process, a second context's tuner goes the
+ * ordinary way meanwhile. */
 int wr_tuner_set_streaming(wr_tuner *tuner, int enable);
 /* `live`: a streaming launch is open right now; `launches`, `blocks`: opened / taken so far (any may be NULL) */
 int wr_tuner_stream_info(wr_tuner *tuner, int *live, unsigned long long *launches, unsigned long long *blocks);
