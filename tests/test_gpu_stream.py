@@ -180,6 +180,37 @@ def test_two_tuners_on_one_device_both_asked_to_stream(dev):
             assert u.shape == v.shape and np.array_equal(_bits(u), _bits(v))
 
 
+def test_a_second_context_on_the_same_gpu_goes_the_ordinary_way(dev):
+    """... and one streaming launch per GPU and process: a tuner of ANOTHER wr_dev on the same GPU that asks for streaming
+    while the first context's launch is open is not given a launch of its own (both could not be resident: they would
+    wait for each other until their deadlines) -- its blocks go the ordinary way, their kernels wait for room on the
+    GPU until the open launch has ended, and the bits are the ordinary path's."""
+    from webradio_amd.device import Device
+    nch, nblk = 70, 3
+    x = _stream_dev(nblk + 1, nch)
+    want_a, want_b = None, None
+    for stream in (False, True):
+        devb = Device(0)
+        ta, _ = _tuner(dev, nch)
+        tb, _ = _tuner(devb, nch, modes=(capi.WR_AM, capi.WR_FM))
+        for t in (ta, tb):
+            t.streaming(stream)
+        for b in range(nblk):
+            ta.submit_device(x[2 * N * b: 2 * N * (b + 1)], N)
+        tb.submit_device(x[2 * N * nblk: 2 * N * (nblk + 1)], N)   # a's launch is open: enqueued the ordinary way
+        got_a = ta.fetch_audio_all().copy()                        # closes a's launch; b's kernels find room
+        got_b = tb.fetch_audio_all().copy()
+        ia, ib = ta.stream_info(), tb.stream_info()
+        ta.destroy()
+        tb.destroy()
+        devb.close()
+        if not stream:
+            want_a, want_b = got_a, got_b
+        else:
+            assert ia[2] >= nblk - 1 and ib[1] == 0 and ib[2] == 0, (ia, ib)
+            assert np.array_equal(_bits(got_a), _bits(want_a)) and np.array_equal(_bits(got_b), _bits(want_b))
+
+
 def test_a_blocks_audio_arrives_without_a_flush(dev):
     """dspblock.cxx:169-212: a block's output leaves within its own run().  The ring entry of a streamed block
     becomes ready when the launch's post stage has finished THAT block -- nothing has to follow it, nobody has to
