@@ -126,7 +126,9 @@ TAPS_TOL = 1e-7          # the 64-point inverse DFT: rocFFT's f32 butterflies vs
                          # FFT is good to a few 1e-8 on the widest filters (measured: profiles/r04_reference_pin.txt)
 CHAN_TOL = 1e-6          # channel IQ (the oracle's own bar for the fast NCO modes)
 AUDIO_TOL = 1e-5
-DB_TOL = 0.02            # dB, on bins within 60 dB of the frame's peak (f32 FFT rounding dominates below)
+DB_TOL = 0.01            # dB, on the bins within DB_MASK of the frame's peak: SURVEY 8c's own bar (0.01 dB within 80 dB).  Measured
+DB_MASK = 80.0           # against the live reference (profiles/r06_reference_pin.txt): <= 3.4e-4 dB within 60 dB, <= 1.2e-3 within 70,
+                         # <= 3.8e-3 within 80 (65536 points: f32 butterflies leave ~3e-7 of the peak on every bin)
 
 
 # ---- full-size cases, LIVE only (the inputs are regenerated on the box; nothing of this size is committed) -------------

@@ -75,7 +75,7 @@ def test_spectrum_db(oracle, gold, name):
     for b in range(c["blocks"]):
         s.process(iq[2 * n * b: 2 * n * (b + 1)])
     got, want = s.get(), gold["spec_" + name]
-    strong = want >= want.max() - 60.0
+    strong = want >= want.max() - refcases.DB_MASK
     assert strong.sum() >= 3
     assert np.abs(got - want)[strong].max() <= refcases.DB_TOL
     assert int(np.argmax(got)) == int(np.argmax(want))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Measured distances between the REAL reference blocks (oracle/_ref/libwr_ref_chain.so: the reference's own
 downconverter/lowpass/demodulator/spectrumsink over the image's hipFFTW), the oracle and the HIP path, for every case
-of tests/refcases.py.  Runs on the GPU box; the output is committed as profiles/r04_reference_pin.txt."""
+of tests/refcases.py.  Runs on the GPU box; the output is committed as profiles/r0N_reference_pin.txt.
+r06: a row per case for the STREAMING launch (k_tuner_stream, the kernel bench.py times), and the spectrum distances on
+the bins within 60, 70 and 80 dB of the frame's peak (what tests/refcases.py DB_TOL / DB_MASK assert)."""
 import os
 import sys
 
@@ -70,10 +72,15 @@ def main():
                 a.append(t.fetch(ch, capi.WR_STAGE_AUDIO, n))
             t.destroy()
             rows.append([np.concatenate(a), np.concatenate(z), np.concatenate(d)])
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_gpu_reference_pin as pin
+        s_audio, s_chan = pin._hip_chain_stream(dev, c, iq)
+        stream_txt = "stream (k_tuner_stream, blocks of %d): last block's IQ %.1e, audio %.1e" % (
+            pin._stream_cut(c), np.abs(s_chan - w[1][-s_chan.size:]).max(), np.abs(s_audio - w[0]).max())
         txt = "; ".join("%.1e / %.1e / %.1e" % (np.abs(r[1] - w[1]).max(), np.abs(r[2] - w[2]).max(), np.abs(r[0] - w[0]).max())
                         for r in rows)
-        print("  %-6s %s   max|audio| %.3f" % (name, txt, np.abs(w[0]).max()))
-    print("\nSpectrumSink dB: max |x - ref| on bins within 60 dB of the peak (oracle; HIP), peak bin ref / oracle / HIP")
+        print("  %-6s %s   max|audio| %.3f\n         %s" % (name, txt, np.abs(w[0]).max(), stream_txt))
+    print("\nSpectrumSink dB: max |x - ref| on bins within 60 / 70 / 80 dB of the peak (oracle; HIP), peak bin ref / oracle / HIP")
     for name, c in sorted(refcases.SPECTRA.items()):
         iq = refcases.spectrum_input(c)
         want = live["spec_" + name]
@@ -85,8 +92,12 @@ def main():
             s.push_host(iq[2 * n * b: 2 * n * (b + 1)])
         got = s.get_db()
         s.destroy()
-        print("  %-10s %.2e ; %.2e   (%d strong bins)  %d / %d / %d" % (name, np.abs(oo.get() - want)[strong].max(),
-              np.abs(got - want)[strong].max(), int(strong.sum()), int(np.argmax(want)), int(np.argmax(oo.get())), int(np.argmax(got))))
+        txt = []
+        for mask in (60.0, 70.0, 80.0):
+            strong = want >= want.max() - mask
+            txt.append("%g dB: %.2e ; %.2e (%d bins)" % (mask, np.abs(oo.get() - want)[strong].max(), np.abs(got - want)[strong].max(),
+                                                          int(strong.sum())))
+        print("  %-10s %s   %d / %d / %d" % (name, "   ".join(txt), int(np.argmax(want)), int(np.argmax(oo.get())), int(np.argmax(got))))
     # full-size cases (live only): BASELINE configs 2, 5 (parameters) and 3
     full_path = os.path.join(os.path.dirname(live_path), "full.npz")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "golden", "make_reference_chain_golden.py"), "--full", full_path],
@@ -109,6 +120,29 @@ def main():
         print("  %-10s %d frames x %d block(s): " % (name, n, c["blocks"]) + "; ".join(
             "rx %d: %.1e / %.1e" % (ch, np.abs(np.concatenate(got[ch][0]) - full["full_%s_%d_chan" % (name, ch)]).max(),
                                     np.abs(np.concatenate(got[ch][1]) - full["full_%s_%d_audio" % (name, ch)]).max()) for ch in c["probe"]))
+        # the same through ONE streaming launch (k_tuner_stream<5, 2> at C2: bench.py's headline kernel and configuration)
+        t = Tuner(dev, c["fs"], c["channels"], n, capi.WR_NCO_ROTATE)
+        chans = [t.add_receiver(f, c["cpb"], c["crate"], refcases.full_mode(c, i), c["apb"], c["arate"]) for i, f in enumerate(ifs)]
+        xd = torch.from_numpy(iq).cuda()
+        torch.cuda.synchronize()
+        t.audio_ring(c["blocks"])
+        t.streaming(True)
+        for b in range(c["blocks"]):
+            t.submit_device(xd[2 * n * b: 2 * n * (b + 1)], n)
+        info = t.stream_info()
+        t.flush()
+        sa = {ch: [] for ch in c["probe"]}
+        for b in range(c["blocks"]):
+            a, seq = t.ring_acquire()
+            for ch in c["probe"]:
+                sa[ch].append(a[t.slot(chans[ch])].copy())
+            t.ring_release()
+        sz = {ch: t.fetch(chans[ch], capi.WR_STAGE_CHAN_IQ, 2 * n) for ch in c["probe"]}
+        t.destroy()
+        del xd
+        print("  %-10s   streaming launch (live %s, launches %d, blocks %d; last block's IQ / every block's audio): " % ("", info[0], info[1], info[2])
+              + "; ".join("rx %d: %.1e / %.1e" % (ch, np.abs(sz[ch] - full["full_%s_%d_chan" % (name, ch)][-sz[ch].size:]).max(),
+                                                  np.abs(np.concatenate(sa[ch]) - full["full_%s_%d_audio" % (name, ch)]).max()) for ch in c["probe"]))
     c3 = refcases.C3_FULL
     c = refcases.FULL[c3["case"]]
     iq = refcases.full_input(c)
@@ -120,9 +154,10 @@ def main():
     torch.cuda.synchronize()
     rows = out.cpu().numpy().reshape(nrows, c3["n"])
     s.destroy()
-    print("  C3 waterfall, %d rows of 65536 points, rows %s against the reference's SpectrumSink: max |dB - ref| on strong bins: %s" % (
-        nrows, c3["rows"], ", ".join("%.1e" % np.abs(rows[r] - full["c3_row_%d" % r])[full["c3_row_%d" % r] >= full["c3_row_%d" % r].max() - 60.0].max()
-                                    for r in c3["rows"])))
+    for mask in (60.0, 70.0, 80.0):
+        print("  C3 waterfall, %d rows of 65536 points, rows %s against the reference's SpectrumSink: max |dB - ref| on bins within %g dB of the peak: %s" % (
+            nrows, c3["rows"], mask, ", ".join("%.1e (%d)" % (np.abs(rows[r] - full["c3_row_%d" % r])[full["c3_row_%d" % r] >= full["c3_row_%d" % r].max() - mask].max(),
+                                                        int((full["c3_row_%d" % r] >= full["c3_row_%d" % r].max() - mask).sum())) for r in c3["rows"])))
     dev.close()
 
 
