@@ -756,7 +756,7 @@ def main():
             gpu_sync()
     def launches_of(steps, B=B, streaming=streaming):
         if streaming:
-            return (steps + 4095) // 4096          # WR_STREAM_MAXJ blocks per streaming launch
+            return (steps + capi.WR_STREAM_MAX_BLOCKS - 1) // capi.WR_STREAM_MAX_BLOCKS     # blocks one streaming launch takes at most
         # the launches `steps` consecutive steps from the start of the resident stream make: a launch
         # closes when it holds B blocks or the next block does not follow on in memory (the wrap)
         count, held = 0, 0
@@ -771,6 +771,7 @@ def main():
         tuner.flush()
         tuner.profile(stride)
         barrier()
+        opened0 = tuner.stream_info()[1]
         t0 = time.perf_counter()
         for i in range(steps):
             tuner.submit_device(blocks[i % nb], n)
@@ -782,6 +783,10 @@ def main():
         barrier()                              # ... the ranks meet again, and the job's time is the MAX over them (below):
         got, ms = tuner.profile_read()         # a collective's own latency (RCCL: tens of us) is not part of anybody's steps
         tuner.profile(False)
+        opened = tuner.stream_info()[1] - opened0
+        #  the streaming launches the region opened are the library's count, not this script's guess
+        assert opened in (0, launches_of(steps, 1, True)), \
+            "the timed region opened %d streaming launches, launches_of() expected %d" % (opened, launches_of(steps, 1, True))
         return dt, got, ms
 
     n_launches = launches_of(args.steps)

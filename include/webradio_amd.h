@@ -453,6 +453,7 @@ int wr_tuner_set_blocks_per_launch(wr_tuner *tuner, unsigned int nblocks);
  * turns with it, a launch per block), but work sent to the GPU by other means -- another wr_dev, another process --
  * waits until the launch has ended; one streaming launch per GPU and process, a second context's tuner goes the
  * ordinary way meanwhile. */
+#define WR_STREAM_MAX_BLOCKS 512u   /* blocks ONE streaming launch takes; the submit after them opens the next launch */
 int wr_tuner_set_streaming(wr_tuner *tuner, int enable);
 /* `live`: a streaming launch is open right now; `launches`, `blocks`: opened / taken so far (any may be NULL) */
 int wr_tuner_stream_info(wr_tuner *tuner, int *live, unsigned long long *launches, unsigned long long *blocks);

@@ -70,6 +70,11 @@ def test_streamed_blocks_give_the_same_bits(dev, nch):
         t.flush()
         assert t.stream_info()[0] is False
         got = _drain(t, nblk)
+        # the tuner's DEVICE audio array behind the stream is the LAST block's (two blocks' post stages can run
+        # side by side in the drain; they store into two arrays by turns) -- by wr_tuner_fetch_audio_all and per channel
+        last_dev = t.fetch_audio_all()
+        assert np.array_equal(_bits(last_dev[:nch]), _bits(got[-1][1][:nch]))
+        assert np.array_equal(_bits(t.fetch(chans[-1], capi.WR_STAGE_AUDIO, N)), _bits(got[-1][1][t.slot(chans[-1])]))
         iq = np.stack([t.fetch(c, capi.WR_STAGE_CHAN_IQ, 2 * N) for c in chans[::3]])
         state = [t.state(c) for c in chans]
         t.streaming(False)
@@ -313,6 +318,8 @@ def test_streaming_at_c2_size(dev):
             t.submit_device(x[2 * n * b: 2 * n * (b + 1)], n)
         t.flush()
         out = [a for _, a in _drain(t, nblk - 1)]
+        #  the device audio array after the close holds the LAST streamed block's audio, all 256 rows
+        assert np.array_equal(_bits(t.fetch_audio_all()), _bits(out[-1]))
         t.streaming(False)
         t.submit_device(x[2 * n * (nblk - 1): 2 * n * nblk], n)
         out.append(t.fetch_audio_all().copy())

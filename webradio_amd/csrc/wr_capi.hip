@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -279,6 +280,14 @@ static hipError_t dev_stream_sync(wr_dev *d)
 		return hipErrorUnknown;
 	return hipStreamSynchronize(d->stream);
 }
+/* ... and, on a tuner's own paths, read what a launch that was closed on the way left behind (WrStreamCtl::err,
+ * final_blocks) before the caller is handed results: a launch that ran into a deadline or closed itself early is an
+ * error here, not stale audio with WR_OK */
+/* an entry point that puts work on the device's stream (or touches the null stream) while a streaming launch is open on it:
+ * close the launch first -- the work would otherwise sit behind a kernel that ends only when it is told to, or after
+ * WR_STREAM_IDLE_MS of silence (include/webradio_amd.h: "calls on the same wr_dev close it first") */
+#define DEV_SETTLE(d_) do { if (int rc_ = dev_settle_stream(d_)) return rc_; } while (0)
+#define TUNER_SYNC_CHECKED(t_) do { HIP_TRY(dev_stream_sync((t_)->dev)); if (int rc_ = stream_check(t_)) return rc_; } while (0)
 
 
 static int dev_bind(wr_dev *d)
@@ -510,8 +519,9 @@ extern "C" int wr_dev_sync(wr_dev *d)
 {
 	if (!d)
 		return fail(WR_ERR_ARG, "dev is NULL");
+	wr_tuner *live = d->streaming;                       /* (closed by the sync: its outcome is this call's) */
 	HIP_TRY(dev_stream_sync(d));
-	return WR_OK;
+	return live ? stream_check(live) : WR_OK;
 }
 
 extern "C" void *wr_dev_stream(wr_dev *d) { return d ? (void *)d->stream : nullptr; }
@@ -677,9 +687,10 @@ extern "C" int wr_dev_download(wr_dev *d, void *dst_host, const void *src_dev, s
 		return fail(WR_ERR_ARG, "wr_dev_download: bad argument");
 	if (!bytes)
 		return WR_OK;
+	wr_tuner *live = d->streaming;
 	HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(dev_stream_sync(d));
-	return WR_OK;
+	return live ? stream_check(live) : WR_OK;
 }
 
 /* --------------------------------------------------- one kernel per block -- */
@@ -698,6 +709,7 @@ extern "C" int wr_mix(wr_dev *d, const float *in_dev, float *out_dev, size_t nfr
 {
 	if (!d || !phase_io || (nframes && (!in_dev || !out_dev)))
 		return fail(WR_ERR_ARG, "wr_mix: bad argument");
+	DEV_SETTLE(d);
 	g_block_kernel_calls.fetch_add(1, std::memory_order_relaxed);
 	HIP_TRY(wrk_mix(d->stream, in_dev, out_dev, nframes, *phase_io, phase_step, d->table));
 	/* DownConverter::phase after nframes increments (downconverter.cxx:103) */
@@ -715,6 +727,7 @@ extern "C" int wr_fir_decimate_n(wr_dev *d, const float *in_dev, size_t nframes,
 	if (!fir_length_ok(fir_length))
 		return fail(WR_ERR_ARG, "wr_fir_decimate: fir_length %u is not a power of two in [2, %d]", fir_length,
 		            WR_FIR_MAX);
+	DEV_SETTLE(d);
 	SCRATCH_GUARD(d);
 	int rc = dev_scratch(d, (size_t)(fir_length - 1) * channels);
 	if (rc)
@@ -742,6 +755,7 @@ extern "C" int wr_demod(wr_dev *d, int mode, const float *in_dev, size_t nframes
 	if (mode < WR_AM || mode > WR_LSB)
 		return fail(WR_ERR_ARG, "wr_demod: bad mode %d", mode);   /* demodulator.cxx:105-107 */
 	g_block_kernel_calls.fetch_add(1, std::memory_order_relaxed);
+	DEV_SETTLE(d);
 	HIP_TRY(wrk_demod(d->stream, mode, in_dev, nframes, prev_io[0], prev_io[1], out_dev));
 	if (nframes) {
 		/* prev_i/q = last input frame (demodulator.cxx:110-111) */
@@ -756,6 +770,7 @@ extern "C" int wr_u8_to_f32(wr_dev *d, const uint8_t *in_dev, float *out_dev, si
 {
 	if (!d || (count && (!in_dev || !out_dev)))
 		return fail(WR_ERR_ARG, "wr_u8_to_f32: bad argument");
+	DEV_SETTLE(d);
 	HIP_TRY(wrk_u8_to_f32(d->stream, in_dev, out_dev, count));
 	return WR_OK;
 }
@@ -958,6 +973,7 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.dem[0]);
 	(void)hipFree(g->dev.dem[1]);
 	(void)hipFree(g->dev.audio);
+	(void)hipFree(g->dev.audio2);
 	delete g;
 }
 
@@ -1029,6 +1045,7 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], ((size_t)g->l2 - 1 + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], ((size_t)g->l2 - 1 + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
+	if (!rc) rc = dev_alloc_zero(&g->dev.audio2, g->k2max * S);
 	if (rc) {
 		group_free(g);
 		return rc;
@@ -1050,6 +1067,7 @@ extern "C" int wr_tuner_create(wr_tuner **tuner, wr_dev *dev, unsigned int input
 	*tuner = nullptr;
 	if (dev_bind(dev))
 		return WR_ERR_HIP;
+	DEV_SETTLE(dev);                                        /* (the allocations below fill through the null stream and wait for it) */
 	wr_tuner *t = new (std::nothrow) wr_tuner();
 	if (!t)
 		return fail(WR_ERR_NOMEM, "out of memory");
@@ -2486,6 +2504,7 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	A.hi_cs = d->hi_cs;
 	A.lo_cs = d->lo_cs;
 	A.ring = s.ring;
+	A.audio_alt = g->dev.audio2;
 	A.post = wrk_post_args(L, g->dev);
 	A.post.host_stride = k2;                                /* the ring's rows lie back to back (RingSlot::stride = frames) */
 	A.prev_iq[0] = g->dev.prev_iq[0];
@@ -2589,6 +2608,10 @@ static int stream_close(wr_tuner *t)
 	g->last_k2 = s.k2;
 	g->last_demod_kept = false;
 	s.last_iq = s.ring + (size_t)((J - 1u) % WR_STREAM_RING) * s.k1 * g->slots * 2u;
+	/* the blocks of a stream store their audio into the group's two device arrays by turns (two blocks' post
+	 * stages may run side by side in the drain); the one the LAST block wrote is the group's audio from here on */
+	if ((J - 1u) & 1u)
+		std::swap(g->dev.audio, g->dev.audio2);
 	t->in_par ^= 1;
 	for (Chan &c : t->chans) {
 		if (!c.in_use || c.group < 0)
@@ -2704,7 +2727,7 @@ extern "C" int wr_chan_fetch(wr_tuner *t, int chan, int stage, float *out_host, 
 			                        (size_t)c->slot, 1, d->scratch));
 		HIP_TRY(hipMemcpyAsync(out_host, d->scratch, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
 	}
-	HIP_TRY(dev_stream_sync(d));
+	TUNER_SYNC_CHECKED(t);
 	return WR_OK;
 }
 
@@ -2772,7 +2795,7 @@ extern "C" int wr_tuner_fetch_audio_all(wr_tuner *t, float *out_host, size_t out
 	}
 	HIP_TRY(hipMemcpy2DAsync(out_host, g->last_k2 * sizeof(float), g->dev.audio, g->k2max * sizeof(float),
 	                         g->last_k2 * sizeof(float), used, hipMemcpyDeviceToHost, d->stream));
-	HIP_TRY(dev_stream_sync(d));
+	TUNER_SYNC_CHECKED(t);
 	return WR_OK;
 }
 
@@ -3177,6 +3200,7 @@ extern "C" int wr_spectrum_create(wr_spectrum **spec, wr_dev *dev, unsigned int 
 		return fail(WR_ERR_ARG, "hop must not exceed fft_size");
 	if (dev_bind(dev))
 		return WR_ERR_HIP;
+	DEV_SETTLE(dev);
 	wr_spectrum *s = new (std::nothrow) wr_spectrum();
 	if (!s)
 		return fail(WR_ERR_NOMEM, "out of memory");
@@ -3264,6 +3288,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 	wr_dev *d = s->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	DEV_SETTLE(d);
 	hipStream_t st = d->stream;
 	if (where == WR_DEVICE && s->pending + nframes >= s->n &&
 	    ((s->pending + nframes - s->n) / s->hop) * s->hop >= s->pending) {
@@ -3421,6 +3446,7 @@ extern "C" int wr_spectrum_batch_db(wr_spectrum *s, const float *iq_dev, size_t 
 		return fail(WR_ERR_ARG, "wr_spectrum_batch_db: bad argument");
 	if (dev_bind(s->dev))
 		return WR_ERR_HIP;
+	DEV_SETTLE(s->dev);
 	/* the two-pass transforms keep their intermediate in `work`: room for the whole batch, up
 	 * to 128 MB (it then still sits in the 256 MB Infinity Cache between the passes), means one
 	 * pair of launches per call instead of one per 64 frames */

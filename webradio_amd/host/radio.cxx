@@ -82,7 +82,7 @@ Receiver::Receiver() : _frontEnd(NULL)
 	_stream->setSubdevice(_uuid);
 
 	receiverRegistry()[_uuid] = this;
-	LOG_DEBUG("Created receiver %s\n", _uuid.c_str());
+	LOG_DEBUG("receiver %s: chain built (DownConverter, channel LowPass, Demodulator, audio LowPass, sink)\n", _uuid.c_str());
 }
 
 Receiver::~Receiver()
@@ -95,7 +95,7 @@ Receiver::~Receiver()
 	delete _demodulator;
 	delete _audioFilter;
 	delete _stream;
-	LOG_DEBUG("Destroyed receiver %s\n", _uuid.c_str());
+	LOG_DEBUG("receiver %s: chain released\n", _uuid.c_str());
 }
 
 void Receiver::setFrontEnd(FrontEnd *frontend)
@@ -114,7 +114,7 @@ FrontEnd::FrontEnd(TunerFactory factory)
 	_spectrum = new SpectrumSink(_uuid);
 	_tuner->connect(_spectrum);
 	frontEndRegistry()[_uuid] = this;
-	LOG_DEBUG("Created front-end %s\n", _uuid.c_str());
+	LOG_DEBUG("front end %s: tuner and SpectrumSink wired\n", _uuid.c_str());
 }
 
 FrontEnd::~FrontEnd()
@@ -125,19 +125,19 @@ FrontEnd::~FrontEnd()
 	frontEndRegistry().erase(_uuid);
 	delete _tuner;
 	delete _spectrum;
-	LOG_DEBUG("Destroyed front-end %s\n", _uuid.c_str());
+	LOG_DEBUG("front end %s: released\n", _uuid.c_str());
 }
 
 void FrontEnd::addReceiver(Receiver *rx)
 {
 	_tuner->connect(rx->input());
 	_receivers[rx->uuid()] = rx;
-	LOG_DEBUG("Added rx %s to front-end %s\n", rx->uuid().c_str(), _uuid.c_str());
+	LOG_DEBUG("receiver %s now listens to front end %s\n", rx->uuid().c_str(), _uuid.c_str());
 }
 
 void FrontEnd::removeReceiver(Receiver *rx)
 {
 	_receivers.erase(rx->uuid());
 	_tuner->disconnect(rx->input());
-	LOG_DEBUG("Removed rx %s from front-end %s\n", rx->uuid().c_str(), _uuid.c_str());
+	LOG_DEBUG("receiver %s detached from front end %s\n", rx->uuid().c_str(), _uuid.c_str());
 }
