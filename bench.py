@@ -429,14 +429,33 @@ def c1_secondary(torch, dev, steps, settle_ms):
         for i in range(100):
             t.submit_u8_device(blocks[i % nb], n)
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        t.submit_u8_device(blocks[i % nb], n)
-    t.flush()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed(k):
+        t.flush()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            t.submit_u8_device(blocks[i % nb], n)
+        t.flush()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    dt = timed(steps)
     a = t.fetch(0, capi.WR_STAGE_AUDIO, n)
     assert a.size == n // 8 // 8 and bool((a == a).all()) and float(abs(a).max()) > 0.0
+    # r06: the same blocks through ONE streaming launch (D2 = 8 is eligible): a doorbell per 64 ms block
+    # instead of a launch -- parity: tests/test_gpu_stream.py::test_c1_capture_streams_against_the_reference_vectors
+    streamed = None
+    t.streaming(True)
+    timed(50)
+    opened0, blocks0 = t.stream_info()[1:]
+    dts = timed(steps)
+    opened, taken = t.stream_info()[1] - opened0, t.stream_info()[2] - blocks0
+    t.streaming(False)
+    if opened >= 1 and taken == steps:
+        b = t.fetch(0, capi.WR_STAGE_AUDIO, n)
+        assert b.size == a.size and bool((b == b).all()) and float(abs(b).max()) > 0.0
+        streamed = {"value": round(n * steps / dts / 1e6, 2), "ms_per_block": round(dts / steps * 1e3, 5),
+                    "times_real_time": round(n * steps / dts / c1["input_rate"], 1), "launches": opened, "blocks": taken}
     t.destroy()
     msps = n * steps / dt / 1e6
     return {
@@ -447,6 +466,9 @@ def c1_secondary(torch, dev, steps, settle_ms):
         "times_real_time": round(msps / (c1["input_rate"] / 1e6), 1),
         "note": "launch-latency bound: ONE small launch per 64 ms block (r03: the fused demodulator + audio filter also for "
                 "D2 = 8, riding in the next block's DDC launch; r02: three launches, 28.6-30.8 us)",
+        "streaming": streamed,
+        "streaming_note": "wr_tuner_set_streaming(1): the %d blocks ring the doorbell of one persistent launch (opened and closed "
+                          "inside the timing)" % steps,
     }
 
 

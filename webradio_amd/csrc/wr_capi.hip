@@ -131,6 +131,7 @@ struct Group {
 	unsigned int slots;
 	size_t k1max, k2max;
 	WrGroupDev dev;
+	int audio_cur = 0;         /* which member of dev.audio_set is dev.audio */
 	int parity;                /* index of the current ping-pong buffers (prev_iq, dem) */
 	int last_parity;           /* parity the last submit wrote its demod rows with */
 	bool last_demod_kept = false; /* the last submit left its demod rows in HBM */
@@ -972,8 +973,8 @@ static void group_free(Group *g)
 	(void)hipFree(g->dev.chan_iq[1]);
 	(void)hipFree(g->dev.dem[0]);
 	(void)hipFree(g->dev.dem[1]);
-	(void)hipFree(g->dev.audio);
-	(void)hipFree(g->dev.audio2);
+	for (float *a : g->dev.audio_set)
+		(void)hipFree(a);                               /* (`audio` is one of them) */
 	delete g;
 }
 
@@ -1044,8 +1045,10 @@ static int group_create(wr_tuner *t, unsigned int d1, unsigned int d1b, unsigned
 	if (!rc) rc = dev_alloc_zero(&g->dev.chan_iq[1], (g->k1max ? g->k1max : 1) * S * 2);
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[0], ((size_t)g->l2 - 1 + g->k1max) * S);
 	if (!rc) rc = dev_alloc_zero(&g->dev.dem[1], ((size_t)g->l2 - 1 + g->k1max) * S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.audio, g->k2max * S);
-	if (!rc) rc = dev_alloc_zero(&g->dev.audio2, g->k2max * S);
+	for (int i = 0; i < 4 && !rc; ++i)
+		rc = dev_alloc_zero(&g->dev.audio_set[i], g->k2max * S);
+	g->dev.audio = g->dev.audio_set[0];
+	g->audio_cur = 0;
 	if (rc) {
 		group_free(g);
 		return rc;
@@ -2504,7 +2507,8 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	A.hi_cs = d->hi_cs;
 	A.lo_cs = d->lo_cs;
 	A.ring = s.ring;
-	A.audio_alt = g->dev.audio2;
+	for (int i = 0; i < 4; ++i)
+		A.audio_bufs[i] = g->dev.audio_set[(g->audio_cur + i) & 3];
 	A.post = wrk_post_args(L, g->dev);
 	A.post.host_stride = k2;                                /* the ring's rows lie back to back (RingSlot::stride = frames) */
 	A.prev_iq[0] = g->dev.prev_iq[0];
@@ -2608,10 +2612,10 @@ static int stream_close(wr_tuner *t)
 	g->last_k2 = s.k2;
 	g->last_demod_kept = false;
 	s.last_iq = s.ring + (size_t)((J - 1u) % WR_STREAM_RING) * s.k1 * g->slots * 2u;
-	/* the blocks of a stream store their audio into the group's two device arrays by turns (two blocks' post
-	 * stages may run side by side in the drain); the one the LAST block wrote is the group's audio from here on */
-	if ((J - 1u) & 1u)
-		std::swap(g->dev.audio, g->dev.audio2);
+	/* the blocks of a stream store their audio into the group's four device arrays by turns (blocks' post stages
+	 * may run side by side); the one the LAST block wrote is the group's audio from here on */
+	g->audio_cur = (int)((g->audio_cur + (J - 1u)) & 3u);
+	g->dev.audio = g->dev.audio_set[g->audio_cur];
 	t->in_par ^= 1;
 	for (Chan &c : t->chans) {
 		if (!c.in_use || c.group < 0)

@@ -79,10 +79,10 @@ struct WrGroupDev {
 	                               that block b+1's DDC can run while block b is being demodulated */
 	float        *dem[2];       /* [63 + k1max][slots] demod output, 63 history rows in front; ping-pong */
 	float        *audio;        /* [slots][k2max] audio, channel major */
-	float        *audio2;       /* a second array of that shape: inside a streaming launch the blocks' post stages store by turns
-	                               (block j into `audio` when j is even, `audio2` when odd), so that two blocks whose post-stage tasks
-	                               run side by side never store into the same array; the stream's close makes the array its last
-	                               block wrote `audio` (wr_capi.hip: stream_close) */
+	float        *audio_set[4]; /* four arrays of that shape, `audio` one of them: inside a streaming launch the blocks' post stages store
+	                               by turns (block j into set member (first + j) mod 4), so that blocks whose post-stage tasks run side by
+	                               side never store into the same array; the stream's close makes the array its last block wrote
+	                               `audio` (wr_capi.hip: stream_close) */
 	/* taps of the group's audio filter and of its second channel stage: 64, or 128 / 256 (the rate group is keyed by
 	 * them; dem then carries l2 - 1 history rows, iq2_hist l1b - 1, taps2 / taps1b l2 / l1b rows) */
 	unsigned int  l2 = 64, l1b = 64;
@@ -272,7 +272,7 @@ struct WrStreamArgs {
 	const int          *tapsel;
 	const float        *table, *hi_cs, *lo_cs;
 	float              *ring;              /* [WR_STREAM_RING * k1][slots][2] channel IQ */
-	float              *audio_alt;         /* WrGroupDev::audio2: the device audio array of the stream's odd blocks (post.audio: the even ones') */
+	float              *audio_bufs[4];     /* WrGroupDev::audio_set, from the current one on: block j's device audio goes to audio_bufs[j & 3] */
 	/* the post stage: what wrk_post_args gives for ONE block, and the two ping-pong state sets */
 	WrPostArgs          post;
 	const float        *prev_iq[2];
