@@ -379,6 +379,76 @@ def c3_secondary(torch, dev, blocks, n, steps, settle_ms):
     }
 
 
+def frontend_secondary(torch, dev, tuner, blocks, n, steps, streaming_ok):
+    """The whole FrontEnd (radio.cxx:120-133: a tuner feeds its receivers AND a SpectrumSink, DspBlock::run hands both every
+    block): BASELINE configs 2 and 3 on the SAME resident blocks of one tuner -- 256 receivers and the 65536-point waterfall at
+    50 % overlap -- instead of timed apart.  Three ways:
+      per_block_launches        a tuner launch and the waterfall's two passes per block, one stream: what r01-r04's path does;
+      streaming_closed_per_block  wr_tuner_set_streaming with a waterfall batch every block: every batch closes the launch
+                                (the FFT passes need the CUs the launch holds) -- what a stream costs a front end that
+                                wants EVERY frame's row;
+      streaming_newest_frame    the reference's own semantics (spectrumsink.cxx:114-116,136-141: only the most recent frame
+                                is observable; waterfallhandler.cxx:56-61 reads it at 5 Hz = every fifth 40 ms block): a
+                                push per block beside the open launch (kept, not transformed), one getSpectrum per five
+                                blocks (one closed launch per poll).
+    Times are wall clock over `steps` blocks between two synchronisations; the roofline fractions take each config's
+    algorithmic bytes over the COMBINED time."""
+    from webradio_amd.device import Spectrum
+    rows = (n - C3_FFT) // C3_HOP + 1
+    nb = len(blocks)
+    outs = [torch.empty(rows * C3_FFT, dtype=torch.float32, device="cuda") for _ in range(min(nb, 4))]
+    spec = Spectrum(dev, C3_FFT, C3_HOP)
+
+    def run(stream_on, mode, k, poll_every=5):
+        tuner.flush()
+        tuner.streaming(stream_on)
+        tuner.blocks_per_launch(1)
+        for phase in range(2):                              # the same loop untimed first (clocks, allocations), then timed
+            tuner.flush()
+            torch.cuda.synchronize()
+            opened0 = tuner.stream_info()[1]
+            t0 = time.perf_counter()
+            for i in range(k):
+                tuner.submit_device(blocks[i % nb], n)
+                if mode == "waterfall":
+                    spec.batch_db(blocks[i % nb], rows, outs[i % len(outs)])
+                else:
+                    spec.push_device(blocks[i % nb], n)
+                    if poll_every and (i + 1) % poll_every == 0:
+                        spec.get_db()
+            tuner.flush()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        us = dt / k * 1e6
+        c2 = n * ALGO_BYTES_PER_SAMPLE / (us * 1e-6) / 1e9
+        c3 = (rows * C3_BYTES_PER_FRAME if mode == "waterfall" else C3_BYTES_PER_FRAME / 5.0) / (us * 1e-6) / 1e9
+        return {"us_per_block": round(us, 2), "msps": round(n / us, 1), "streaming_launches": tuner.stream_info()[1] - opened0,
+                "c2_frac_of_hbm_roof": round(c2 / HBM_PEAK_GBPS, 4), "c3_frac_of_hbm_roof": round(c3 / HBM_PEAK_GBPS, 4),
+                "spectrum": "%d waterfall rows per block" % rows if mode == "waterfall" else
+                            "newest frame, polled every 5th block" if poll_every else "newest frame kept, never polled"}
+
+    k = max(10, min(steps, 60)) // 5 * 5
+    out = {"workload": "C2 + C3 on the same blocks: 256 receivers and the SpectrumSink (65536 points, hop 32768) of one FrontEnd, "
+                       "%d-frame blocks resident in HBM" % n,
+           "blocks": k,
+           "per_block_launches": run(False, "waterfall", k),
+           "per_block_launches_newest_frame": run(False, "newest", k)}
+    if streaming_ok:
+        out["streaming_closed_per_block"] = run(True, "waterfall", k)
+        out["streaming_newest_frame"] = run(True, "newest", k)
+        quiet = run(True, "newest", k, 0)
+        out["streaming_newest_frame"]["us_per_block_between_polls"] = quiet["us_per_block"]
+        out["streaming_newest_frame"]["us_per_poll"] = round((out["streaming_newest_frame"]["us_per_block"] - quiet["us_per_block"]) * 5, 1)
+        out["streaming_newest_frame"]["note"] = ("a poll = wr_spectrum_get_db: closes the launch (its drain), transforms the kept frame, "
+                                                 "brings 256 KB of dB values to the host and returns -- synchronous, the GPU idles meanwhile; "
+                                                 "at the UI's 5 Hz that is once per 200 ms of signal")
+        out["lazy"] = dict(zip(("pushes_kept", "transformed_on_demand"), spec.lazy_info()))
+    tuner.flush()
+    tuner.streaming(streaming_ok)
+    spec.destroy()
+    return out
+
+
 def host_fed_secondary():
     """The drop-in path with the block in HOST memory (PCIe inside the timing; never `value`): tests/cxx/host_bench --
     one FrontEnd, 256 Receivers wired as radio.cxx wires them, Radio::run() pumping 4 000 000-frame blocks through the C++
@@ -862,11 +932,12 @@ def main():
             streamed = other_mode(True, 1, k1)
 
     # BASELINE config 3 off the same resident stream, outside the timed region of the headline
-    c3 = c1 = None
+    c3 = c1 = fe = None
     if world == 1 and not args.no_secondary:
         tuner.flush()
         torch.cuda.synchronize()
         c3 = c3_secondary(torch, dev, blocks, n, max(nb, min(args.steps, 60)), args.settle_ms)
+        fe = frontend_secondary(torch, dev, tuner, blocks, n, args.steps, streaming)
         c1 = c1_secondary(torch, dev, 400, args.settle_ms)
 
     if rank == 0:
@@ -989,6 +1060,8 @@ def main():
                 out["secondary"]["c2_streaming"] = streamed
             if c3 is not None:
                 out["secondary"]["c3"] = c3
+            if fe is not None:
+                out["secondary"]["frontend"] = fe
             if c1 is not None:
                 out["secondary"]["c1"] = c1
             hf = host_fed_secondary()

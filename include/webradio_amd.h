@@ -477,8 +477,14 @@ int wr_tuner_profile_read(wr_tuner *tuner, unsigned int *launches, double *mean_
 int wr_spectrum_create(wr_spectrum **spec, wr_dev *dev, unsigned int fft_size, unsigned int hop);
 int wr_spectrum_destroy(wr_spectrum *spec);
 /* SpectrumSink::process (io/spectrumsink.cxx:88-123): append frames; every time a
- * frame is complete it is windowed and transformed.  Async for WR_DEVICE input. */
+ * frame is complete it is windowed and transformed.  Async for WR_DEVICE input.
+ *   While a streaming launch is open on the device (wr_tuner_set_streaming) a WR_DEVICE block that holds a whole frame is
+ * not transformed then and there -- that would close the launch every block: the newest frame (and what follows it) is
+ * copied aside by the DMA engine and transformed when a getter below asks for it; only the most recent frame is
+ * observable anyway (spectrumsink.cxx:93-94's FIXME, waterfallhandler.cxx:56-61 polls at 5 Hz).  A poll then costs one
+ * closed launch, a block nothing.  wr_spectrum_lazy_info counts both. */
 int wr_spectrum_push(wr_spectrum *spec, const float *iq, size_t nframes, int where);
+int wr_spectrum_lazy_info(wr_spectrum *spec, unsigned long long *deferred_pushes, unsigned long long *resolves);
 /* SpectrumSink::getSpectrum (io/spectrumsink.cxx:125-142): dB, fft-shifted, of the
  * most recent transform.  WR_ERR_STATE before the first complete frame (the
  * reference returns uninitialised memory there, quirk Q8). */

@@ -563,3 +563,49 @@ def test_c1_capture_streams_against_the_reference_vectors(dev, oracle):
         assert float(np.abs(g["audio"]).max()) > 1e-3
         outs.append((audio, chan))
     assert np.array_equal(_bits(outs[0][0]), _bits(outs[1][0])) and np.array_equal(_bits(outs[0][1]), _bits(outs[1][1]))
+
+
+@pytest.mark.parametrize("nfft,hop", [(512, 0), (4096, 2048)])
+def test_a_front_ends_spectrum_sink_beside_the_stream(dev, nfft, hop):
+    """radio.cxx:120-133: every FrontEnd wires a SpectrumSink to its tuner, and DspBlock::run hands it every block
+    (dspblock.cxx:207-209).  While the tuner's streaming launch is open a pushed block's newest frame is kept, not
+    transformed (that would close the launch every block); a poll -- waterfallhandler.cxx:56-61, 5 Hz -- transforms it and
+    costs ONE closed launch.  The same blocks through the ordinary way (a launch per block, a transform per push): the
+    same audio bits, the same spectrum bits at every poll."""
+    from webradio_amd.device import Spectrum
+    nch, nblk, poll_every = 70, 12, 5
+    x = _stream_dev(nblk, nch)
+
+    def run(stream):
+        t, chans = _tuner(dev, nch)
+        sp = Spectrum(dev, nfft, hop)
+        t.audio_ring(nblk)
+        t.streaming(stream)
+        polls, launches_at_poll = [], []
+        for b in range(nblk):
+            blk = x[2 * N * b: 2 * N * (b + 1)]
+            t.submit_device(blk, N)
+            sp.push_device(blk, N)
+            if stream:
+                assert t.stream_info()[0], "a pushed block closed the launch"
+            if (b + 1) % poll_every == 0:
+                polls.append((sp.get_db().copy(), sp.get_bins().copy(), sp.frames_done()))
+                launches_at_poll.append(t.stream_info()[1])
+        t.flush()
+        audio = _drain(t, nblk)
+        info, lazy = t.stream_info(), sp.lazy_info()
+        sp.destroy()
+        t.destroy()
+        return audio, polls, info, lazy, launches_at_poll
+
+    a1, p1, _, lazy1, _ = run(False)
+    a2, p2, info2, lazy2, lp = run(True)
+    assert lazy1 == (0, 0)
+    assert lazy2 == (nblk, nblk // poll_every)              # every push kept, one transform per poll
+    assert info2[1] == 1 + nblk // poll_every and lp == [1, 2]      # a poll closes the launch; the next block opens the next
+    assert info2[2] == nblk                                 # ... and every block went through a streaming launch
+    for (s1, u), (s2, v) in zip(a1, a2):
+        assert s1 == s2 and np.array_equal(_bits(u[:nch]), _bits(v[:nch]))
+    assert len(p1) == len(p2) == nblk // poll_every
+    for (d1, b1, f1), (d2, b2, f2) in zip(p1, p2):
+        assert f1 == f2 and np.array_equal(_bits(b1), _bits(b2)) and np.array_equal(_bits(d1), _bits(d2))

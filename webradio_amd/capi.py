@@ -111,6 +111,7 @@ SIGNATURES = {
     "wr_spectrum_create": (C.c_int, [C.POINTER(_vp), _vp, _u32, _u32]),
     "wr_spectrum_destroy": (C.c_int, [_vp]),
     "wr_spectrum_push": (C.c_int, [_vp, _vp, _sz, C.c_int]),
+    "wr_spectrum_lazy_info": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "wr_spectrum_get_db": (C.c_int, [_vp, _vp]),
     "wr_spectrum_get_bins": (C.c_int, [_vp, _vp]),
     "wr_spectrum_frames_done": (C.c_int, [_vp, C.POINTER(C.c_ulong)]),

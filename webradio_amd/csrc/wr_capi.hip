@@ -261,6 +261,15 @@ struct wr_spectrum {
 	size_t pending;            /* frames buffered in stage, not yet consumed */
 	float *bins;               /* [n][2] most recent transform */
 	unsigned long frames_done;
+	/* r06: a frame pushed while a streaming launch is open on the device is NOT transformed then and there (the transform
+	 * would have to close the launch, every block): its frames -- from the frame's first to the block's last -- are copied
+	 * into `stage` on the upload stream (the DMA engine: no wave slot needed beside the launch) and transformed when somebody
+	 * asks for the spectrum (spectrum_resolve), which is what the reference's own FIXME asks for (io/spectrumsink.cxx:93-94:
+	 * only the most recent frame is observable, waterfallhandler.cxx:56-61 reads it at 5 Hz) */
+	bool deferred = false;
+	size_t def_rest = 0;       /* frames behind the deferred frame's hop that belong to the NEXT frame (at stage + 2 * hop) */
+	hipEvent_t def_ev = nullptr;   /* behind that copy */
+	unsigned long long deferred_pushes = 0, resolves = 0;
 };
 
 /* ------------------------------------------------------------------ helpers -- */
@@ -782,7 +791,7 @@ extern "C" int wr_u8_to_f32(wr_dev *d, const uint8_t *in_dev, float *out_dev, si
  * that followed the last one to write `out_dev` (a caller alternating between two buffers: before the previous call), or --
  * the same buffer twice in a row, or one not seen lately -- by now.  upload_ahead_end makes the device's stream wait for
  * what was put on the upload stream in between and marks the upload (wr_dev_wait_uploads).  Under d->upload_lock. */
-static int upload_ahead_begin(wr_dev *d, void *out_dev, unsigned long long *call)
+static int dev_up_stream(wr_dev *d)
 {
 	if (!d->up_stream) {
 		int prio_low = 0, prio_high = 0;                     /* lowest priority: the kernels of the block before go first */
@@ -794,6 +803,13 @@ static int upload_ahead_begin(wr_dev *d, void *out_dev, unsigned long long *call
 		for (int i = 0; i < WR_UPLOAD_RING; ++i)
 			HIP_TRY(hipEventCreateWithFlags(&d->up_tail[i], hipEventDisableTiming | hipEventReleaseToDevice));
 	}
+	return WR_OK;
+}
+
+static int upload_ahead_begin(wr_dev *d, void *out_dev, unsigned long long *call)
+{
+	if (int rc = dev_up_stream(d))
+		return rc;
 	const unsigned long long n = d->up_calls;
 	HIP_TRY(hipEventRecord(d->up_tail[n % WR_UPLOAD_RING], d->stream));
 	unsigned long long after = n;                      /* wait for the tail recorded by call `after` */
@@ -3276,10 +3292,43 @@ extern "C" int wr_spectrum_destroy(wr_spectrum *s)
 		return WR_OK;
 	(void)hipSetDevice(s->dev->device);
 	(void)dev_stream_sync(s->dev);
+	if (s->dev->up_stream)
+		(void)hipStreamSynchronize(s->dev->up_stream);      /* (a deferred frame's copy may be on its way) */
+	if (s->def_ev)
+		(void)hipEventDestroy(s->def_ev);
 	plan_free(s->plan);
 	(void)hipFree(s->stage);
 	(void)hipFree(s->bins);
 	delete s;
+	return WR_OK;
+}
+
+/* the deferred frame, if there is one: transformed now, and what follows its hop moved to the stage's front (where the
+ * frames carried over to the next push live).  Closes an open streaming launch: once per poll, not once per block. */
+static int spectrum_resolve(wr_spectrum *s)
+{
+	if (!s->deferred)
+		return WR_OK;
+	wr_dev *d = s->dev;
+	DEV_SETTLE(d);
+	hipStream_t st = d->stream;
+	HIP_TRY(hipStreamWaitEvent(st, s->def_ev, 0));
+	HIP_TRY(wrk_fft_frames(st, s->plan, s->stage, s->hop, 1, s->bins, nullptr));
+	const size_t rest = s->def_rest;
+	if (rest) {
+		if (rest <= s->hop) {
+			HIP_TRY(hipMemcpyAsync(s->stage, s->stage + 2 * (size_t)s->hop, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+		} else {
+			SCRATCH_GUARD(d);
+			if (int rc = dev_scratch(d, rest * 2))
+				return rc;
+			HIP_TRY(hipMemcpyAsync(d->scratch, s->stage + 2 * (size_t)s->hop, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+			HIP_TRY(hipMemcpyAsync(s->stage, d->scratch, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+		}
+	}
+	s->pending = rest;
+	s->deferred = false;
+	++s->resolves;
 	return WR_OK;
 }
 
@@ -3292,10 +3341,55 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 	wr_dev *d = s->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	const bool inside = where == WR_DEVICE && s->pending + nframes >= s->n &&
+	                    ((s->pending + nframes - s->n) / s->hop) * s->hop >= s->pending;   /* the newest frame starts inside this block */
+	if (inside && d->streaming) {
+		/* (r06) a streaming launch is open: keep the frame, transform it when somebody asks (see wr_spectrum::deferred).  A
+		 * deferred frame of an earlier push that nobody asked for is simply superseded: nobody can observe it any more. */
+		const size_t have = s->pending + nframes;
+		const size_t nfft = (have - s->n) / s->hop + 1;
+		const size_t first = (nfft - 1) * s->hop - s->pending;  /* where that frame starts in THIS block */
+		const size_t keep = nframes - first;                    /* = n + what follows the frame's hop ... */
+		const size_t rest = have - nfft * s->hop;               /* ... of which this much belongs to the next frame */
+		if (keep > s->stage_cap) {
+			float *nb = nullptr;
+			const size_t cap = keep + s->n;
+			HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
+			if (s->stage) {
+				/* (a stage that must GROW: whatever still reads the old one goes first -- this closes the launch, once) */
+				HIP_TRY(dev_stream_sync(s->dev));
+				if (d->up_stream)
+					HIP_TRY(hipStreamSynchronize(d->up_stream));
+				HIP_TRY(hipFree(s->stage));
+			}
+			s->stage = nb;
+			s->stage_cap = cap;
+		}
+		std::lock_guard<std::mutex> up_guard(*d->upload_lock);
+		if (int rc = dev_up_stream(d))
+			return rc;
+		if (!s->def_ev)
+			HIP_TRY(hipEventCreateWithFlags(&s->def_ev, hipEventDisableTiming));
+		HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * first, keep * 2 * sizeof(float), hipMemcpyDeviceToDevice, d->up_stream));
+		HIP_TRY(hipEventRecord(s->def_ev, d->up_stream));
+		s->frames_done += nfft;
+		s->def_rest = rest;
+		s->pending = rest;                                  /* (logically; physically at stage + 2 * hop until resolved) */
+		s->deferred = true;
+		++s->deferred_pushes;
+		return WR_OK;
+	}
+	if (s->deferred) {
+		if (inside) {
+			/* this block's newest frame supersedes the deferred one, and reads nothing carried over: drop it */
+			s->deferred = false;
+		} else if (int rc = spectrum_resolve(s)) {
+			return rc;
+		}
+	}
 	DEV_SETTLE(d);
 	hipStream_t st = d->stream;
-	if (where == WR_DEVICE && s->pending + nframes >= s->n &&
-	    ((s->pending + nframes - s->n) / s->hop) * s->hop >= s->pending) {
+	if (inside) {
 		/* A block that already lies in device memory and whose most recent complete frame starts INSIDE it (any block of
 		 * fftSize + hop frames or more; whatever was carried over belongs to frames nobody can observe,
 		 * spectrumsink.cxx:114-116,136-141): that frame is transformed where it lies and only the tail that belongs to
@@ -3376,6 +3470,17 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 	return WR_OK;
 }
 
+extern "C" int wr_spectrum_lazy_info(wr_spectrum *s, unsigned long long *deferred_pushes, unsigned long long *resolves)
+{
+	if (!s)
+		return fail(WR_ERR_ARG, "spectrum is NULL");
+	if (deferred_pushes)
+		*deferred_pushes = s->deferred_pushes;
+	if (resolves)
+		*resolves = s->resolves;
+	return WR_OK;
+}
+
 extern "C" int wr_spectrum_get_bins(wr_spectrum *s, float *bins_host)
 {
 	if (!s || !bins_host)
@@ -3384,6 +3489,8 @@ extern "C" int wr_spectrum_get_bins(wr_spectrum *s, float *bins_host)
 		return fail(WR_ERR_STATE, "no complete frame yet");
 	if (dev_bind(s->dev))
 		return WR_ERR_HIP;
+	if (int rc = spectrum_resolve(s))
+		return rc;
 	HIP_TRY(hipMemcpyAsync(bins_host, s->bins, (size_t)s->n * 2 * sizeof(float), hipMemcpyDeviceToHost,
 	                       s->dev->stream));
 	HIP_TRY(dev_stream_sync(s->dev));
@@ -3399,6 +3506,8 @@ extern "C" int wr_spectrum_get_db(wr_spectrum *s, float *magnitudes_host)
 	wr_dev *d = s->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	if (int rc = spectrum_resolve(s))
+		return rc;
 	SCRATCH_GUARD(d);
 	int rc = dev_scratch(d, s->n);
 	if (rc)
@@ -3421,6 +3530,8 @@ extern "C" int wr_spectrum_get_waterfall_row(wr_spectrum *s, unsigned int width,
 	wr_dev *d = s->dev;
 	if (dev_bind(d))
 		return WR_ERR_HIP;
+	if (int rc = spectrum_resolve(s))
+		return rc;
 	SCRATCH_GUARD(d);
 	int rc = dev_scratch(d, (size_t)width * 2);
 	if (rc)

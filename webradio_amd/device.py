@@ -304,6 +304,12 @@ class Spectrum:
         check(self.lib.wr_spectrum_frames_done(self.h, C.byref(n)))
         return n.value
 
+    def lazy_info(self):
+        """(pushes kept for later because a streaming launch was open, frames transformed on demand)"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        check(self.lib.wr_spectrum_lazy_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def batch_db(self, iq_dev, nframes_fft, db_dev):
         check(self.lib.wr_spectrum_batch_db(self.h, ptr(iq_dev), nframes_fft, ptr(db_dev)))
 
