@@ -459,9 +459,15 @@ def host_fed_secondary():
     if not os.path.exists(exe):
         return None
     rows = []
-    for src in ("u8", "f32"):
+    # (r06) "dev": a source that produces its blocks in GPU memory (DeviceBlock): the host classes STREAM it -- Radio::run() rings
+    # the doorbell of k_tuner_stream, the kernel the headline times; the same source with WEBRADIO_STREAM=0 beside it
+    for src in ("dev", "dev-nostream", "u8", "f32"):
         for late, sparse in (("1", "1"), ("0", "1"), ("0", "0")):
-            env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_AUDIO_LATE=late, WEBRADIO_SPARSE=sparse)
+            if src.startswith("dev") and sparse == "0":
+                continue
+            env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_AUDIO_LATE=late, WEBRADIO_SPARSE=sparse,
+                       WEBRADIO_STREAM="0" if src == "dev-nostream" else "1")
+            src = src.split("-")[0]
             try:
                 r = subprocess.run([exe, "256", "100", "4000000", src], env=env, capture_output=True, text=True, timeout=120)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -470,11 +476,15 @@ def host_fed_secondary():
                 rows.append({"source": src, "audio_late": int(late), "error": str(e)[:200]})
                 continue
             rows.append({"source": d["source"], "audio": d["audio"],
-                         "staging": "sparse: only the frames under the channel filters' taps (64 of every 400) and the block's "
+                         "stream_info": d.get("stream_info"),
+                         "staging": "none: the block lies in GPU memory" + ("" if env["WEBRADIO_STREAM"] == "1" else " (WEBRADIO_STREAM=0: a launch per block)")
+                                    if src == "dev" else
+                                    "sparse: only the frames under the channel filters' taps (64 of every 400) and the block's "
                                     "tail cross PCIe, read by a kernel (wr_stage_windows_from_host)" if sparse == "1"
                                     else "the whole block crosses PCIe (WEBRADIO_SPARSE=0: r03's path)",
                          "ms_per_block": d["ms_per_block"], "msps_tuner_input": d["msps_tuner_input"], "blocks": d["blocks"]})
-    return {"workload": "C2 through the C++ host classes (Radio::run, 256 Receivers), block in host memory: PCIe inside the timing",
+    return {"workload": "C2 through the C++ host classes (Radio::run, 256 Receivers): the block in GPU memory (streamed: k_tuner_stream) "
+                        "and in host memory (PCIe inside the timing)",
             "unit": "complex Msamples/s of tuner input", "runs": rows}
 
 

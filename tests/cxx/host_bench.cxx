@@ -4,7 +4,7 @@
  * webradio process would see: the tuner block lives in HOST memory (PCIe is inside the
  * timing), every Receiver's AudioStreamManager gets its audio.  TEST/MEASUREMENT DRIVER.
  *
- *   host_bench [receivers=256] [blocks=10] [block_frames=4000000] [f32|u8]
+ *   host_bench [receivers=256] [blocks=10] [block_frames=4000000] [f32|u8|dev]
  *
  * u8: the source holds its block in the RTL-SDR byte format (RawU8Block, like FileTuner: what an RTL-SDR or a
  * recording delivers, io/rtlsdrtuner.cxx:86-117) -- 8 MB per 4 M-frame block over PCIe instead of 32 MB.
@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "filetuner.h"
+#include "gpubatch.h"
 #include "radio.h"
 
 namespace {
@@ -76,6 +77,46 @@ protected:
 };
 Tuner *make_u8(const string &n) { return new SynthU8Tuner(n); }
 
+/* r06: the same block RESIDENT in GPU memory (three copies taken in turn, as a capture card with a DMA ring would leave
+ * them): a DeviceBlock source -- nothing crosses PCIe, and the tuner batch streams it (wr_tuner_set_streaming: the kernel
+ * bench.py's headline times, through Radio::run() and 256 Receivers) */
+class SynthDeviceTuner : public Tuner, public DeviceBlock {
+public:
+	SynthDeviceTuner(const string &n) : Tuner(n, "SynthDeviceTuner"), dev(NULL), cur(0) { memset(copy, 0, sizeof(copy)); }
+	~SynthDeviceTuner() { for (int i = 0; i < 3; i++) if (copy[i]) wr_dev_free(dev, copy[i]); }
+	const float *deviceBlock(wr_dev **d, size_t *frames) const {
+		if (d) *d = dev;
+		if (frames) *frames = g_block.size() / 2;
+		return (const float *)copy[cur];
+	}
+protected:
+	bool init() {
+		dev = wrhost::deviceFor(this);
+		if (!dev)
+			return false;
+		for (int i = 0; i < 3; i++)
+			if (!copy[i] && (wr_dev_malloc(dev, g_block.size() * sizeof(float), &copy[i]) != WR_OK ||
+			                 wr_dev_upload(dev, copy[i], g_block.data(), g_block.size() * sizeof(float)) != WR_OK))
+				return false;
+		return true;
+	}
+	void deinit() {}
+	bool process(const vector<sample_t> &, vector<sample_t> &out) {
+		if (out.size() != g_block.size())
+			return false;
+		cur = (cur + 1u) % 3u;
+		const bool skip = consumersReadOnDevice();
+		if (!skip)
+			out = g_block;
+		setHostBlockValid(!skip);
+		return true;
+	}
+	wr_dev *dev;
+	void *copy[3];
+	unsigned int cur;
+};
+Tuner *make_dev(const string &n) { return new SynthDeviceTuner(n); }
+
 double now()
 {
 	timespec ts;
@@ -91,6 +132,7 @@ int main(int argc, char **argv)
 	const unsigned int blocks = argc > 2 ? atoi(argv[2]) : 10;
 	const unsigned int frames = argc > 3 ? atoi(argv[3]) : 4000000;
 	const bool u8 = argc > 4 && !strcmp(argv[4], "u8");
+	const bool resident = argc > 4 && !strcmp(argv[4], "dev");
 	const unsigned int fs = 100000000;
 
 	g_block.resize((size_t)frames * 2);
@@ -117,7 +159,7 @@ int main(int argc, char **argv)
 			g_bytes[n] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
 		}
 	}
-	FrontEnd *fe = new FrontEnd(u8 ? make_u8 : make);
+	FrontEnd *fe = new FrontEnd(u8 ? make_u8 : resident ? make_dev : make);
 	fe->tuner()->setSampleRate(fs);
 	fe->tuner()->setChannels(2);
 	fe->tuner()->setBlockSize(frames * 2);
@@ -164,13 +206,17 @@ int main(int argc, char **argv)
 		for (size_t i = 0; i < a.size(); i++)
 			sum += fabs(a[i]);
 	}
+	bool live = false;
+	unsigned long long launches = 0, streamed = 0;
+	(void)wrhost::streamInfo(rx.empty() ? NULL : rx[0]->downconverter(), &live, &launches, &streamed);
 	printf("{\"source\": \"%s\", \"audio\": \"%s\", \"receivers\": %u, \"blocks\": %u, \"block_frames\": %u, \"ms_per_block\": %.3f, "
-	       "\"msps_tuner_input\": %.1f, \"audio_samples_per_receiver\": %lu, \"audio_abs_sum\": %.3f}\n",
-	       u8 ? "u8 (RTL-SDR byte format, 2 B per frame over PCIe)" : "f32 (8 B per frame over PCIe)",
+	       "\"msps_tuner_input\": %.1f, \"audio_samples_per_receiver\": %lu, \"audio_abs_sum\": %.3f, "
+	       "\"stream_info\": {\"live\": %s, \"launches\": %llu, \"blocks\": %llu}}\n",
+	       u8 ? "u8 (RTL-SDR byte format, 2 B per frame over PCIe)" : resident ? "device (the block resident in GPU memory: DeviceBlock)" : "f32 (8 B per frame over PCIe)",
 	       (getenv("WEBRADIO_AUDIO_LATE") && atoi(getenv("WEBRADIO_AUDIO_LATE")) >= 2) ? "two blocks late (WEBRADIO_AUDIO_LATE=2: one launch per block)"
 	       : (getenv("WEBRADIO_AUDIO_LATE") && atoi(getenv("WEBRADIO_AUDIO_LATE"))) ? "one block late (WEBRADIO_AUDIO_LATE=1)" : "on time",
 	       nrx, blocks, frames, dt / blocks * 1e3, (double)frames * blocks / dt / 1e6,
-	       total / (unsigned long)rx.size(), sum);
+	       total / (unsigned long)rx.size(), sum, live ? "true" : "false", launches, streamed);
 	if (getenv("WR_HOST_BENCH_PROFILE")) {
 		/* DspBlock's own profiler (process-CPU ns inside process(), dspblock.h:69-75), summed per block type */
 		uint64_t mix = 0, f1 = 0, dem = 0, f2 = 0, snk = 0;

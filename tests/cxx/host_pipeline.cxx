@@ -49,7 +49,56 @@ protected:
 	}
 };
 
-Tuner *makeTuner(const string &name) { return new ReplayTuner(name); }
+/* r06: the same replay with every block produced in DEVICE memory (DeviceBlock: three buffers in turn) -- the tuner batch
+ * then streams the blocks (wr_tuner_set_streaming).  WR_TEST_DEVICE_SOURCE=1 selects it. */
+class ReplayDeviceTuner : public Tuner, public DeviceBlock {
+public:
+	ReplayDeviceTuner(const string &name) : Tuner(name, "ReplayDeviceTuner"), _dev(NULL), _all(NULL), _at(0), _frames(0) {
+		_name = "replay (device memory)";
+		_manufacturer = "webradio_amd tests";
+	}
+	~ReplayDeviceTuner() { if (_all) wr_dev_free(_dev, _all); }
+	const float *deviceBlock(wr_dev **dev, size_t *frames) const {
+		if (dev) *dev = _dev;
+		if (frames) *frames = _frames;
+		return _all ? (const float *)_all + 2 * _at : NULL;
+	}
+protected:
+	bool init() {
+		/* the whole recording goes to the device once (a resident capture): the blocks are consecutive pieces of it */
+		_dev = wrhost::deviceFor(this);
+		if (!_dev)
+			return false;
+		if (!_all && (wr_dev_malloc(_dev, g_frames * 2 * sizeof(float), &_all) != WR_OK ||
+		              wr_dev_upload(_dev, _all, g_iq, g_frames * 2 * sizeof(float)) != WR_OK))
+			return false;
+		return true;
+	}
+	void deinit() {}
+	bool process(const vector<sample_t> &, vector<sample_t> &out) {
+		size_t frames = out.size() / 2;
+		if (g_pos + frames > g_frames)
+			return false;
+		_at = g_pos;
+		_frames = frames;
+		const bool skip = consumersReadOnDevice();
+		if (!skip)
+			memcpy(out.data(), g_iq + 2 * g_pos, out.size() * sizeof(float));
+		setHostBlockValid(!skip);
+		g_pos += frames;
+		return true;
+	}
+	wr_dev *_dev;
+	void *_all;
+	size_t _at, _frames;
+};
+
+Tuner *makeTuner(const string &name)
+{
+	if (getenv("WR_TEST_DEVICE_SOURCE") && atoi(getenv("WR_TEST_DEVICE_SOURCE")))
+		return new ReplayDeviceTuner(name);
+	return new ReplayTuner(name);
+}
 
 /* a sink that keeps what it is handed (any channel count) */
 class TapSink : public DspBlock {
@@ -77,6 +126,11 @@ extern "C" {
  * REST handlers do this from other threads, receiverhandler.cxx:130-137).
  * spectrum_out (optional) receives fft_size dB values from FrontEnd::spectrum().
  * Returns 0, or a negative stage code. */
+/* what the tuner batch of the last wr_host_run streamed (wr_tuner_stream_info): launches opened, blocks taken */
+static unsigned long long g_stream_launches, g_stream_blocks;
+unsigned long long wr_host_stream_launches(void) { return g_stream_launches; }
+unsigned long long wr_host_stream_blocks(void) { return g_stream_blocks; }
+
 int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int block_frames,
                 unsigned int nrx, const int *if_hz, const int *modes,
                 unsigned int chan_passband, unsigned int chan_rate,
@@ -128,6 +182,12 @@ int wr_host_run(const float *iq, size_t nframes, unsigned int rate, unsigned int
 			if ((long)b == (long)retune_at && nrx)
 				rx[0]->downconverter()->setIF(retune_if);
 			Radio::run();
+		}
+		{
+			bool live = false;
+			g_stream_launches = g_stream_blocks = 0;
+			if (nrx)
+				(void)wrhost::streamInfo(rx[0]->downconverter(), &live, &g_stream_launches, &g_stream_blocks);
 		}
 		if (spectrum_out && fft_size)
 			fe->spectrum()->getSpectrum(spectrum_out);

@@ -39,8 +39,12 @@ rc = L.wr_host_run(iq.ctypes.data_as(fp), iq.size // 2, int(p[0]), int(p[1]), nr
                    modes.ctypes.data_as(ip), int(p[2]), int(p[3]), int(p[4]), int(p[5]), int(p[6]), int(p[7]),
                    audio.ctypes.data_as(fp), cap, C.byref(n), fft, spec.ctypes.data_as(fp))
 L.wr_block_kernel_calls.restype = C.c_ulonglong     # (libwebradio_amd, a dependency of the harness)
+sl = sb = 0
+if hasattr(L, "wr_host_stream_blocks"):
+    L.wr_host_stream_blocks.restype = L.wr_host_stream_launches.restype = C.c_ulonglong
+    sl, sb = int(L.wr_host_stream_launches()), int(L.wr_host_stream_blocks())
 np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], spec=spec, left=L.wr_host_registry_sizes(),
-         traced=L.wr_host_trace_count(), block_calls=int(L.wr_block_kernel_calls()))
+         traced=L.wr_host_trace_count(), block_calls=int(L.wr_block_kernel_calls()), stream_launches=sl, stream_blocks=sb)
 '''
 
 
@@ -62,6 +66,7 @@ def _run(libname, tmp_path, iq, rate, block, ifs, modes, cpb, crate, apb, arate,
     r = np.load(out)
     assert int(r["rc"]) == 0
     assert int(r["left"]) == 0                    # registries empty again (radio.cxx:98,143)
+    _run.last_stream = (int(r["stream_launches"]), int(r["stream_blocks"]))
     return r["audio"], r["spec"]
 
 
@@ -372,6 +377,40 @@ rc = L.wr_host_run_two_traced(iq.ctypes.data_as(fp), iq.size // 2, p[0], p[1], n
                               audio.ctypes.data_as(fp), cap, C.byref(n), tr, 4096)
 np.savez(sys.argv[3], rc=rc, audio=audio[:, :n.value], trace=np.array(tr.value.decode()), left=L.wr_host_registry_sizes())
 '''
+
+
+@pytest.mark.parametrize("late", ["0", "1"], ids=["on-time", "late"])
+def test_a_source_in_device_memory_is_streamed(tmp_path, oracle, late):
+    """r06 (VERDICT r05 item 3): a source that produces its blocks in GPU memory (DeviceBlock) goes through
+    k_tuner_stream -- the kernel bench.py's headline times -- from the product's own classes: Radio::run(), 70 Receivers in
+    two lane groups, a SpectrumSink beside them (whose pushes do not close the launch), audio out of the pinned ring when
+    WrStreamCtl::done says so.  The same audio bits as the same blocks out of host memory (a launch per block, WEBRADIO_STREAM=0
+    likewise), the oracle's spectrum, and the library's own count of what was streamed."""
+    nrx, nblk = 70, 9
+    ifs = [(-35 + c) * 6250 + 99 for c in range(nrx)]
+    modes = [(1, 3, 0, 2)[c % 4] for c in range(nrx)]
+    rate, block = CFG["rate"], CFG["block"]
+    iq = synth.fm_stream(nblk * block, rate, ifs[::5], amp=0.1, fm_base=30.0, beta=2.0)
+    args = (iq, rate, block, ifs, modes, CFG["cpb"], CFG["crate"], CFG["apb"], CFG["arate"])
+    env = {"WEBRADIO_AUDIO_LATE": late}
+    host, spec_h = _run("libwr_host_pipeline.so", tmp_path, *args, fft=512, env=env)
+    assert _run.last_stream == (0, 0)
+    dev, spec_d = _run("libwr_host_pipeline.so", tmp_path, *args, fft=512, env=dict(env, WR_TEST_DEVICE_SOURCE="1"))
+    launches, blocks = _run.last_stream
+    # (blocks this small go through in one part; the first block's submit also pushes every receiver's parameters and reads
+    # their slots back, which closes the launch it opened, and the one-off allocations behind it can outlast the 0.1 s after
+    # which the library opens a new launch rather than ring an old one: a few launches -- but not one per block)
+    assert launches >= 1 and blocks >= nblk - 1, (launches, blocks)
+    assert launches <= 4, "the SpectrumSink's pushes (or anything else per block) closed the launch: %d launches" % launches
+    off, _ = _run("libwr_host_pipeline.so", tmp_path, *args, fft=512, env=dict(env, WR_TEST_DEVICE_SOURCE="1", WEBRADIO_STREAM="0"))
+    assert _run.last_stream == (0, 0)
+    assert host.shape == dev.shape == off.shape and host.shape[1] > 0
+    assert np.array_equal(host.view(np.uint32), dev.view(np.uint32))
+    assert np.array_equal(host.view(np.uint32), off.view(np.uint32))
+    assert np.array_equal(spec_h.view(np.uint32), spec_d.view(np.uint32))
+    if late == "0":
+        want = _oracle(oracle, *args)
+        assert float(np.abs(host - want).max()) <= 2e-5
 
 
 def test_late_audio_keeps_both_front_ends_in_flight(tmp_path, oracle):

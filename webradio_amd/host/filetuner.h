@@ -38,6 +38,19 @@ public:
 	virtual unsigned int rawU8Buffers() const { return 1; }
 };
 
+/* implemented by sources whose current block already lies in GPU memory -- a capture card that writes there by DMA, a
+ * resident recording, a synthetic source: nothing crosses PCIe, every GPU consumer reads the block where it lies, and the
+ * tuner batch STREAMS it (wr_tuner_set_streaming: a doorbell per block instead of a kernel launch; r06).  The block's memory
+ * must stay untouched until the source has produced two further blocks (rotate three buffers or more). */
+struct wr_dev;
+class DeviceBlock {
+public:
+	virtual ~DeviceBlock() {}
+	/* device address of the block most recently produced (interleaved float pairs), the device context it was allocated
+	 * through and its frames -- or NULL */
+	virtual const float* deviceBlock(wr_dev **dev, size_t *frames) const = 0;
+};
+
 class FileTuner : public Tuner, public RawU8Block
 {
 public:

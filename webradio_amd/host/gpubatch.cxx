@@ -221,6 +221,18 @@ wr_dev *deviceFor(const DspBlock *block)
 
 static std::mutex g_stageLock;
 
+/* a source whose block already lies on `dev` (DeviceBlock): where */
+static const float *residentBlock(const DspSource *src, wr_dev *dev, size_t floats)
+{
+	const DeviceBlock *db = dynamic_cast<const DeviceBlock *>(src);
+	if (!db)
+		return NULL;
+	wr_dev *bd = NULL;
+	size_t frames = 0;
+	const float *p = db->deviceBlock(&bd, &frames);
+	return (p && bd == dev && frames * 2 == floats) ? p : NULL;
+}
+
 /* The source's current block staged in `pieces` equal parts, part `p` (0, 1, ... in order) now: part p crosses PCIe on the
  * upload stream -- as bytes where the source still holds them (RawU8Block), converted on the device -- while the caller has
  * the parts before it worked on.  Returns the device address of the part inside the staged block, which after the last
@@ -298,6 +310,11 @@ static const float *stagedSparse(const DspBlock *consumer, const vector<sample_t
 	wr_dev *dev = deviceFor(consumer);
 	if (!dev)
 		return NULL;
+	if (const float *there = residentBlock(src, dev, host.size())) {
+		if (dev_out)
+			*dev_out = dev;
+		return there;                                   /* nothing to stage: the source produced it in device memory */
+	}
 	std::lock_guard<std::mutex> g(g_stageLock);
 	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
 	if (!st) {
@@ -375,6 +392,11 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 	wr_dev *dev = deviceFor(consumer);
 	if (!dev)
 		return NULL;
+	if (const float *there = residentBlock(src, dev, host.size())) {
+		if (dev_out)
+			*dev_out = dev;
+		return there;
+	}
 	std::lock_guard<std::mutex> g(g_stageLock);
 	SourceStage *st = static_cast<SourceStage *>(src->gpuStage());
 	if (!st && only_if_present)
@@ -460,6 +482,13 @@ void submitBatchFirst(const DspBlock *consumer, const vector<sample_t> &host)
 		(void)batch->submitOnce(host, (unsigned int)(host.size() / 2));      /* (the receivers see its verdict when they ask) */
 }
 
+bool streamInfo(const DspBlock *block, bool *live, unsigned long long *launches, unsigned long long *blocks)
+{
+	DspSource *src = TunerBatch::rootSource(block);
+	TunerBatch *batch = src ? src->batch() : NULL;
+	return batch && batch->streamInfo(live, launches, blocks);
+}
+
 bool hostBlockValid(const DspBlock *block)
 {
 	DspSource *src = TunerBatch::rootSource(block);
@@ -508,7 +537,8 @@ TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
 	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateDepth(envUnsigned("WEBRADIO_AUDIO_LATE", 0) >= 2 ? 2u : 1u),
-	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false), _submits(0), _partSeq0(0)
+	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false), _submits(0), _partSeq0(0),
+	  _streaming(false)
 {
 	if (_pieces < 1 || _late)
 		_pieces = 1;
@@ -633,6 +663,14 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 			return NULL;
 		}
 		wr_tuner_audio_ring(batch->_tuner, batch->_late ? 2 + batch->_lateDepth : 1 + (batch->_pieces > 1 ? batch->_pieces : 1));
+		/* r06: a source that produces its blocks in device memory (DeviceBlock) is STREAMED: its blocks ring the doorbell of
+		 * one persistent launch (k_tuner_stream, what bench.py's headline times) instead of launching a kernel each; a block's
+		 * audio is in the pinned ring when WrStreamCtl::done says so, no flush.  Blocks that come out of HOST memory are
+		 * staged by work on the device's own stream, which an open launch would hold up: they go the ordinary way.
+		 * WEBRADIO_STREAM=0 turns it off. */
+		batch->_streaming = dynamic_cast<DeviceBlock *>(src) != NULL && envUnsigned("WEBRADIO_STREAM", 1) != 0;
+		if (batch->_streaming && wr_tuner_set_streaming(batch->_tuner, 1) != WR_OK)
+			batch->_streaming = false;
 		batch->_lateQueued = false;
 		batch->_lateSeq = 0;
 		batch->_submits = 0;                    /* a new tuner numbers its submits from 0 again */
@@ -806,7 +844,8 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 			if (parts == 1)
 				return afterSubmit(false);
 			++_lateSeq;
-			wr_tuner_flush(_tuner);
+			if (!_streaming)
+				wr_tuner_flush(_tuner);                     /* (a streaming launch's post stage starts by itself) */
 			traceAdd(_source, 'S');
 			if (g_times)
 				g_tacc[2] += nowUs() - tt0;         /* ... parts submitted and flushed */
@@ -871,6 +910,22 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 	return afterSubmit(pushed);
 }
 
+bool TunerBatch::streamInfo(bool *live, unsigned long long *launches, unsigned long long *blocks)
+{
+	std::lock_guard<std::mutex> g(_lock);
+	int l = 0;
+	unsigned long long a = 0, b = 0;
+	if (!_tuner || wr_tuner_stream_info(_tuner, &l, &a, &b) != WR_OK)
+		return false;
+	if (live)
+		*live = l != 0;
+	if (launches)
+		*launches = a;
+	if (blocks)
+		*blocks = b;
+	return true;
+}
+
 /* do all receivers read the source block through windows of one shape -- the same decimation, the same channel-filter
  * length -- and sparsely enough for sparse staging to pay (a window at most every second filter length)? */
 bool TunerBatch::sparseWindows(unsigned int *period, unsigned int *length)
@@ -913,8 +968,8 @@ bool TunerBatch::afterSubmit(bool pushed)
 	/* the graph hands this block's audio on within this very run(): no waiting for the next launch.
 	 * (WEBRADIO_AUDIO_LATE=2 hands out the audio of the block before the previous one: the demodulator and
 	 * audio filter of a block then ride in the NEXT block's launch, as in bench.py -- one launch per block.) */
-	if (!(_late && _lateDepth >= 2))
-		wr_tuner_flush(_tuner);
+	if (!(_late && _lateDepth >= 2) && !_streaming)
+		wr_tuner_flush(_tuner);                /* (a flush would close a streaming launch, every block: its post stage needs none) */
 	traceAdd(_source, 'S');
 	{
 		int ready = 0;

@@ -52,6 +52,9 @@ const float *stagedBlock(const DspBlock *consumer, const vector<sample_t> &host,
 /* false while the root source of `block` left its host vector unfilled for the current block (a byte-format
  * source all of whose consumers read on the device): a device path that fails must then fail loudly */
 bool hostBlockValid(const DspBlock *block);
+/* r06: did the tuner batch of `block`'s root source stream (a DeviceBlock source: wr_tuner_set_streaming)?  `live`: a launch is
+ * open right now; `launches` / `blocks`: opened / taken so far.  false: no batch */
+bool streamInfo(const DspBlock *block, bool *live, unsigned long long *launches, unsigned long long *blocks);
 /* For a consumer of the source's block that is NOT part of the tuner batch (the SpectrumSink, which FrontEnd connects
  * first): have the batch submit this block now, before the consumer enqueues its own work -- the receivers' launches then
  * come first on the device's stream and the audio does not wait behind the spectrum's copy and transform (the batch
@@ -120,6 +123,8 @@ public:
 	 * block boundary */
 	static void markDirty(Channel *ch);
 
+	bool streamInfo(bool *live, unsigned long long *launches, unsigned long long *blocks);
+	bool streaming() const { return _streaming; }
 	wr_dev *dev() const { return _dev; }
 	DspSource *source() const { return _source; }
 	size_t channels() const { return _channels.size(); }
@@ -158,6 +163,7 @@ private:
 	std::mutex _lock;
 	unsigned long long _submits;      /* wr_tuner_submit calls that went through on _tuner: the tuner numbers its ring entries so */
 	unsigned long long _partSeq0;     /* ... the first part of the block collectParts is about to collect */
+	bool _streaming;                  /* the source produces its blocks in device memory (DeviceBlock): wr_tuner_set_streaming */
 };
 
 } // namespace wrhost
