@@ -461,13 +461,13 @@ def host_fed_secondary():
     rows = []
     # (r06) "dev": a source that produces its blocks in GPU memory (DeviceBlock): the host classes STREAM it -- Radio::run() rings
     # the doorbell of k_tuner_stream, the kernel the headline times; the same source with WEBRADIO_STREAM=0 beside it
-    for src in ("dev", "dev-nostream", "u8", "f32"):
+    for kind in ("dev", "dev-nostream", "u8", "f32"):
+        src = kind.split("-")[0]
         for late, sparse in (("1", "1"), ("0", "1"), ("0", "0")):
-            if src.startswith("dev") and sparse == "0":
+            if src == "dev" and sparse == "0":
                 continue
             env = dict(os.environ, WEBRADIO_QUIET="1", WEBRADIO_AUDIO_LATE=late, WEBRADIO_SPARSE=sparse,
-                       WEBRADIO_STREAM="0" if src == "dev-nostream" else "1")
-            src = src.split("-")[0]
+                       WEBRADIO_STREAM="0" if kind == "dev-nostream" else "1")
             try:
                 r = subprocess.run([exe, "256", "100", "4000000", src], env=env, capture_output=True, text=True, timeout=120)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

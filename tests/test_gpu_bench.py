@@ -62,9 +62,24 @@ def test_single_gpu_line():
     assert abs(c3["roofline"]["frac"] - c3["roofline"]["achieved"] / 8000.0) < 1e-4
     c1 = j["secondary"]["c1"]
     hf = j["secondary"]["host_fed"]                                  # the drop-in path, block in host memory (PCIe inside)
-    assert len(hf["runs"]) == 6 and all("error" not in r and r["msps_tuner_input"] > 1000 for r in hf["runs"])
+    assert len(hf["runs"]) == 10 and all("error" not in r and r["msps_tuner_input"] > 1000 for r in hf["runs"])
     assert max(r["msps_tuner_input"] for r in hf["runs"]) < j["value"]          # never the headline
+    # r06: a source that produces its blocks in GPU memory (DeviceBlock) is streamed by the host classes themselves -- the rows
+    # say so with the library's own count (wr_tuner_stream_info), the same source with WEBRADIO_STREAM=0 beside them
+    dev = [r for r in hf["runs"] if r["source"].startswith("device")]
+    assert len(dev) == 4
+    streamed = [r for r in dev if "WEBRADIO_STREAM=0" not in r["staging"]]
+    assert len(streamed) == 2 and all(r["stream_info"]["blocks"] >= r["blocks"] for r in streamed)
+    assert all(r["stream_info"]["blocks"] == 0 for r in hf["runs"] if r not in streamed)
     assert c1["value"] > 2.048 and abs(c1["times_real_time"] - c1["value"] / 2.048) < 0.1
+    assert c1["streaming"]["blocks"] == c1["steps"] and c1["streaming"]["launches"] >= 1 and c1["streaming"]["value"] > 0
+    fe = j["secondary"]["frontend"]                                  # r06: C2 and C3 on the same blocks of one tuner
+    for mode in ("per_block_launches", "per_block_launches_newest_frame", "streaming_closed_per_block", "streaming_newest_frame"):
+        assert fe[mode]["us_per_block"] > 0 and 0 < fe[mode]["c2_frac_of_hbm_roof"] < 1
+    assert fe["per_block_launches"]["streaming_launches"] == 0
+    assert fe["streaming_closed_per_block"]["streaming_launches"] == fe["blocks"]       # every waterfall batch closes the launch
+    assert fe["streaming_newest_frame"]["streaming_launches"] <= fe["blocks"] // 5 + 1  # a poll does, a block does not
+    assert fe["lazy"]["pushes_kept"] > 0 and fe["lazy"]["transformed_on_demand"] > 0
 
 
 def test_two_rank_launch_path():
