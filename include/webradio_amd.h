@@ -301,7 +301,13 @@ int wr_chan_set_state(wr_tuner *tuner, int chan, unsigned int phase, const float
  * tail cross PCIe, read by a kernel on the device's stream (see wr_stage_windows_from_host); like any copy out of
  * page-locked memory it is asynchronous: the block must stay untouched until wr_dev_wait_uploads / wr_dev_sync.
  * $WR_HOST_SPARSE=0: the whole block, as before.  wr_tuner_last_staging says how the last WR_HOST block travelled:
- * 0 none yet, 1 copied whole, 2 staged sparsely. */
+ * 0 none yet, 1 copied whole, 2 staged sparsely, 3 (r06) streamed: a wr_tuner_submit_u8 block out of page-locked memory
+ * under wr_tuner_set_streaming(tuner, 2) -- its bytes cross PCIe as a DMA copy on the library's upload stream and the
+ * streaming launch's doorbell is rung by a stream memory operation behind them; nothing waits, and the block must stay
+ * untouched until wr_dev_wait_uploads (as for any asynchronous upload).  wr_tuner_stream_host_blocks counts them.  The
+ * WHOLE block crosses the link that way (sparse staging brings over a sixth at BASELINE config 2), and whatever else the
+ * caller queues on the upload stream in front of a block (wr_dev_upload_ahead, wr_u8_to_f32_from_host) holds its doorbell
+ * up: copies of 16 KB or less are copy kernels on this runtime and do not start beside an open launch. */
 int wr_tuner_last_staging(wr_tuner *tuner, int *how);
 int wr_tuner_submit(wr_tuner *tuner, const float *iq, size_t nframes, int where);
 /* the same for a block in the RTL-SDR byte format (unsigned 8-bit interleaved IQ, what
@@ -454,9 +460,13 @@ int wr_tuner_set_blocks_per_launch(wr_tuner *tuner, unsigned int nblocks);
  * waits until the launch has ended; one streaming launch per GPU and process, a second context's tuner goes the
  * ordinary way meanwhile. */
 #define WR_STREAM_MAX_BLOCKS 512u   /* blocks ONE streaming launch takes; the submit after them opens the next launch */
+/* enable = 2 (r06): byte-format blocks out of page-locked HOST memory stream as well (wr_tuner_submit_u8(..., WR_HOST), see
+ * wr_tuner_last_staging) */
 int wr_tuner_set_streaming(wr_tuner *tuner, int enable);
 /* `live`: a streaming launch is open right now; `launches`, `blocks`: opened / taken so far (any may be NULL) */
 int wr_tuner_stream_info(wr_tuner *tuner, int *live, unsigned long long *launches, unsigned long long *blocks);
+/* r06: of those blocks, how many came out of page-locked HOST memory (wr_tuner_submit_u8(..., WR_HOST), see wr_tuner_last_staging) */
+int wr_tuner_stream_host_blocks(wr_tuner *tuner, unsigned long long *blocks);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
  * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75), with HIP events on the tuner's stream.

@@ -338,6 +338,11 @@ int wr_host_run_file(const char *path, unsigned int rate, unsigned int block_fra
 		for (unsigned int b = 0; b < nblocks; b++)
 			if (!tuner->run())
 				rc = -4;
+		{
+			bool live = false;
+			g_stream_launches = g_stream_blocks = 0;
+			(void)wrhost::streamInfo(rx->downconverter(), &live, &g_stream_launches, &g_stream_blocks);
+		}
 		/* one more block than the file holds: process() must fail, not crash */
 		if (rc == 0 && tuner->run())
 			rc = -5;

@@ -477,7 +477,8 @@ L.wr_host_run_file.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_int
                                C.c_uint, C.c_int, fp, C.c_size_t, C.POINTER(C.c_size_t)]
 audio = np.zeros(1 << 16, np.float32); n = C.c_size_t()
 rc = L.wr_host_run_file(path.encode(), *p, audio.ctypes.data_as(fp), audio.size, C.byref(n))
-np.savez(out, rc=rc, audio=audio[:n.value], left=L.wr_host_registry_sizes())
+L.wr_host_stream_blocks.restype = C.c_ulonglong
+np.savez(out, rc=rc, audio=audio[:n.value], left=L.wr_host_registry_sizes(), stream_blocks=int(L.wr_host_stream_blocks()))
 '''
 
 

@@ -296,6 +296,72 @@ def test_u8_blocks_stream_too(dev):
         assert s1 == s2 and np.array_equal(_bits(a), _bits(b))
 
 
+@pytest.mark.parametrize("on_time", [False, True], ids=["ahead", "on-time"])
+def test_byte_blocks_out_of_page_locked_host_memory_stream(dev, page_locked, on_time):
+    """r06: what an RTL-SDR delivers (io/rtlsdrtuner.cxx:86-117: bytes in host memory, a ring of buffers) goes through the
+    streaming launch too when asked (wr_tuner_set_streaming(tuner, 2)): wr_tuner_submit_u8(..., WR_HOST) out of page-locked
+    memory -- the bytes cross PCIe as a DMA copy on the upload stream, the doorbell is rung by a stream memory operation behind them, the launch reads the windows at agent scope (its L2
+    may hold what the buffer held four blocks ago).  Nine blocks through four rotating host buffers: the same bits as the
+    same bytes resident on the device with a launch per block -- submitted all ahead of the GPU, or each block's audio taken
+    before the next is handed over (what an on-time run() does); pageable memory goes the ordinary way."""
+    import torch
+    nch, nblk = 70, 9
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, size=2 * N * nblk, dtype=np.uint8)
+    x = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+    t, _ = _tuner(dev, nch)
+    t.audio_ring(nblk)
+    for b in range(nblk):
+        t.submit_u8_device(x[2 * N * b: 2 * N * (b + 1)], N)
+    t.flush()
+    want = _drain(t, nblk)
+    t.destroy()
+
+    bufs = [page_locked(2 * N) for _ in range(4)]
+    t, chans = _tuner(dev, nch)
+    t.audio_ring(nblk)
+    t.streaming(True)
+    t.submit_u8_host(bufs[0])                               # (level 1: host blocks do not stream)
+    assert t.last_staging() != 3 and t.stream_host_blocks() == 0
+    t.destroy()
+    t, chans = _tuner(dev, nch)
+    t.audio_ring(nblk)
+    t.streaming(2)                                          # wr_tuner_set_streaming(tuner, 2): byte blocks out of host memory too
+    got = []
+    for b in range(nblk):
+        h = bufs[b % 4]
+        if b >= 4:
+            dev.lib.wr_dev_wait_uploads(dev.h)              # (the buffer's last copy has run: as a source's run() does)
+        h[:] = raw[2 * N * b: 2 * N * (b + 1)]
+        t.submit_u8_host(h)
+        assert t.last_staging() == 3 and t.stream_info()[0], (b, t.last_staging(), t.stream_info())
+        if on_time:
+            got += _drain(t, 1)
+            assert t.stream_info()[0]                       # (taking a block's audio needs no flush: WrStreamCtl::done)
+    live, launches, blocks = t.stream_info()
+    assert launches == 1 and blocks == nblk and t.stream_host_blocks() == nblk
+    t.flush()
+    if not on_time:
+        got = _drain(t, nblk)
+    st = t.state(chans[3])
+    t.destroy()
+    assert [s for s, _ in got] == [s for s, _ in want] == list(range(nblk))
+    for (_, a), (_, b) in zip(want, got):
+        assert np.array_equal(_bits(a[:nch]), _bits(b[:nch]))
+    assert float(np.abs(want[-1][1]).max()) > 0.0 and st is not None
+    # pageable memory: not streamed (the runtime would stage the copy synchronously), the same bits all the same
+    t, _ = _tuner(dev, nch)
+    t.audio_ring(2)
+    t.streaming(2)
+    t.submit_u8_host(raw[: 2 * N].copy())
+    assert t.last_staging() != 3 and t.stream_host_blocks() == 0
+    t.flush()
+    a0 = _drain(t, 1)[0][1]
+    t.destroy()
+    assert np.array_equal(_bits(a0[:nch]), _bits(want[0][1][:nch]))
+
+
 def test_streaming_at_c2_size(dev):
     """bench.py's configuration: 256 receivers, 4 M-frame blocks off 100 Msps.  Ten resident blocks through a tuner
     that launches each on its own and through ONE streaming launch: every audio sample of every receiver is the

@@ -66,8 +66,10 @@ def main(rnd):
                                      "hbm_bytes_per_launch": int(round((2 * f[one][0] + w[one][0]) * kb)),
                                      "x_algorithmic": round((2 * f[one][0] + w[one][0]) * kb / ALGO_PER_BLOCK, 3)},
         })
-    p1 = [k for k in f if k[0].startswith("k_fft64k_pass1") and k in w]
-    p2 = [k for k in f if k[0].startswith("k_fft64k_pass2") and k in w]
+    # (the waterfall batch's launches: the LARGEST grids -- the frontend secondary's pushes and polls transform single frames
+    # with the same kernels, r06)
+    p1 = sorted([k for k in f if k[0].startswith("k_fft64k_pass1") and k in w], key=lambda k: -k[1])
+    p2 = sorted([k for k in f if k[0].startswith("k_fft64k_pass2") and k in w], key=lambda k: -k[1])
     if p1 and p2:
         p1, p2 = p1[0], p2[0]
         out["c3"] = {
@@ -83,4 +85,4 @@ def main(rnd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r05")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r06")

@@ -82,6 +82,10 @@ struct wr_dev {
 	 * is being worked on: up_tail[i] marks what the device's stream held when call i was made (the last readers of the
 	 * buffer the call AFTER it may overwrite), up_out[i] is the buffer call i wrote */
 	hipStream_t up_stream;
+	hipStream_t lazy_stream = nullptr;   /* r06: the copies a SpectrumSink keeps its newest frame with beside an open streaming launch -- device to
+	                                        device, i.e. copy KERNELS on this runtime, which do not start before the launch has closed: on a
+	                                        stream of their own, where nothing that must not wait (the upload stream's blocks and
+	                                        doorbells) can queue behind them */
 	hipEvent_t up_tail[WR_UPLOAD_RING], up_done;
 	void *up_out[WR_UPLOAD_RING];
 	unsigned long long up_calls;
@@ -232,6 +236,7 @@ struct wr_tuner {
 	 * doorbell instead of a launch each; see wr_internal.h and stream_open / stream_bell / stream_close below */
 	struct Stream {
 		bool enabled = false;
+		bool host_bytes = false;           /* wr_tuner_set_streaming(t, 2): byte blocks out of page-locked HOST memory stream too */
 		bool live = false;                 /* a launch is running and takes blocks */
 		bool unchecked = false;            /* a closed launch whose outcome (WrStreamCtl::err, final_blocks) has not been read yet */
 		WrStreamCtl *ctl = nullptr;        /* page-locked, mapped */
@@ -249,6 +254,18 @@ struct wr_tuner {
 		unsigned long long blocks = 0;     /* blocks streamed so far, all launches */
 		std::chrono::steady_clock::time_point last_bell;
 		const float *last_iq = nullptr;    /* channel IQ of the last block of the last launch (wr_chan_fetch) */
+		/* r06: blocks in the RTL-SDR byte format out of PAGE-LOCKED host memory stream too (wr_tuner_submit_u8(..., WR_HOST)):
+		 * the bytes cross PCIe as a DMA copy on the upload stream into one of four device buffers taken in turn, and the
+		 * doorbell is rung by a 4-byte copy queued behind it (WrStreamDev::ready_up) -- the host waits for neither */
+		uint8_t *raw[4] = {nullptr, nullptr, nullptr, nullptr};
+		size_t raw_cap = 0;                /* bytes each */
+		unsigned long long raw_next = 0;   /* submits that took a raw buffer so far */
+		unsigned long long raw_gen[4] = {0, 0, 0, 0};      /* launch (gen) and block index of the buffer's last tenant */
+		unsigned int raw_idx[4] = {0, 0, 0, 0};
+		hipEvent_t raw_ev = nullptr;       /* behind the copy of a block that OPENS a launch: the launch waits for it */
+		bool ext = false;                  /* the live launch takes such blocks (WrStreamArgs::ext) */
+		bool up_pending = false;           /* doorbells of the live launch are queued on the upload stream */
+		unsigned long long host_blocks = 0;    /* blocks streamed out of host memory so far */
 	} stream;
 };
 
@@ -1871,8 +1888,9 @@ extern "C" int wr_tuner_submit_u8(wr_tuner *t, const uint8_t *iq_u8, size_t nfra
 
 static int tuner_submit_now(wr_tuner *t, const void *iq, size_t nframes, int where, bool u8);
 static bool stream_follows(const wr_tuner *t, size_t nframes, int where, bool u8);
-static int stream_bell(wr_tuner *t, const void *iq);
+static int stream_bell(wr_tuner *t, const void *iq, bool behind_upload);
 static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, bool *took);
+static int stream_host_u8(wr_tuner *t, const uint8_t *bytes, size_t nframes, bool *took);
 static Group *single_group(wr_tuner *t);
 
 static int tuner_launch_held(wr_tuner *t)
@@ -1928,13 +1946,21 @@ static int tuner_submit(wr_tuner *t, const void *iq, size_t nframes, int where, 
 		return rc;
 	if (t->stream.live) {
 		if (stream_follows(t, nframes, where, u8))
-			return stream_bell(t, iq);
-		if (int rc = stream_close(t))
-			return rc;
+			return stream_bell(t, iq, false);
+		if (!(t->stream.ext && where == WR_HOST && u8 && stream_follows(t, nframes, WR_DEVICE, true)))
+			if (int rc = stream_close(t))
+				return rc;
 	}
 	if (t->stream.enabled && where == WR_DEVICE && nframes) {
 		bool took = false;
+		t->stream.ext = false;
 		const int rc = stream_open(t, iq, nframes, u8, &took);
+		if (rc || took)
+			return rc;
+	}
+	if (t->stream.enabled && t->stream.host_bytes && where == WR_HOST && u8 && nframes) {
+		bool took = false;
+		const int rc = stream_host_u8(t, (const uint8_t *)iq, nframes, &took);
 		if (rc || took)
 			return rc;
 	}
@@ -2300,6 +2326,14 @@ static void stream_free(wr_tuner *t)
 	(void)hipHostFree(s.desc);
 	(void)hipFree(s.sdev);
 	(void)hipFree(s.ring);
+	for (uint8_t *&r : s.raw) {
+		(void)hipFree(r);
+		r = nullptr;
+	}
+	s.raw_cap = 0;
+	if (s.raw_ev)
+		(void)hipEventDestroy(s.raw_ev);
+	s.raw_ev = nullptr;
 	s.ctl = nullptr;
 	s.desc = nullptr;
 	s.sdev = nullptr;
@@ -2357,7 +2391,7 @@ static bool stream_follows(const wr_tuner *t, size_t nframes, int where, bool u8
 	return idle < std::chrono::milliseconds(WR_STREAM_STALE_MS);
 }
 
-static int stream_bell(wr_tuner *t, const void *iq)
+static int stream_bell(wr_tuner *t, const void *iq, bool behind_upload = false)
 {
 	wr_tuner::Stream &s = t->stream;
 	const unsigned int j = s.count;
@@ -2365,8 +2399,25 @@ static int stream_bell(wr_tuner *t, const void *iq)
 	float *slot = stream_ring_entry(t, s.g, seq, s.k2, group_slots_used(s.g), j);
 	s.desc[j].cur = (unsigned long long)(uintptr_t)iq;
 	s.desc[j].audio_host = (unsigned long long)(uintptr_t)slot;
+	s.desc[j].count = j + 1u;
 	std::atomic_thread_fence(std::memory_order_release);      /* the descriptor before the count */
-	s.ctl->ready = j + 1u;
+	if (behind_upload) {
+		/* (r06) the block is still crossing PCIe on the upload stream: the count follows it there, into the doorbell's
+		 * device-side twin -- in order with the data, nobody waits.  A stream memory operation (the command processor writes the
+		 * word): a 4-byte hipMemcpyAsync is a copy KERNEL on this runtime (GPU_FORCE_BLIT_COPY_SIZE), and a kernel does not find
+		 * a free wave slot with enough registers beside the launch it is supposed to ring -- measured: it ran 0.5 s later, when
+		 * the launch had closed itself */
+		HIP_TRY(hipStreamWriteValue32(t->dev->up_stream, &s.sdev->ready_up, j + 1u, 0));
+		s.up_pending = true;
+	} else {
+		if (s.up_pending) {
+			/* (doorbells of earlier blocks are still queued behind their copies on the upload stream: this count would overtake
+			 * them -- the bell takes the larger of the two -- and ring blocks whose bytes have not landed) */
+			HIP_TRY(hipStreamSynchronize(t->dev->up_stream));
+			s.up_pending = false;
+		}
+		s.ctl->ready = j + 1u;
+	}
 	std::atomic_thread_fence(std::memory_order_seq_cst);
 	s.count = j + 1u;
 	++s.blocks;
@@ -2498,6 +2549,7 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	A.k1 = (unsigned int)k1;
 	A.d1 = g->d1;
 	A.is_u8 = u8 ? 1u : 0u;
+	A.ext = (s.ext || (getenv("WR_STREAM_EXT") && atoi(getenv("WR_STREAM_EXT")))) ? 1u : 0u;
 	A.slots = g->slots;
 	A.groups = groups;
 	for (unsigned int gi = 0; gi < groups; ++gi)
@@ -2597,6 +2649,91 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	return WR_OK;
 }
 
+/* r06: a block in the RTL-SDR byte format out of PAGE-LOCKED host memory, streamed (see wr_tuner::Stream::raw).  `*took` false:
+ * not this way (pageable memory, a shape the launch cannot take, no memory) -- the caller goes the ordinary way. */
+static int stream_host_u8(wr_tuner *t, const uint8_t *bytes, size_t nframes, bool *took)
+{
+	*took = false;
+	wr_tuner::Stream &s = t->stream;
+	wr_dev *d = t->dev;
+	if (dev_bind(d))
+		return WR_ERR_HIP;
+	void *mapped = nullptr;
+	if (hipHostGetDevicePointer(&mapped, const_cast<uint8_t *>(bytes), 0) != hipSuccess || !mapped) {
+		(void)hipGetLastError();
+		return WR_OK;                                       /* pageable: the copy would be staged by the runtime, synchronously */
+	}
+	const size_t need = nframes * 2;
+	const bool follows = s.live && s.ext && stream_follows(t, nframes, WR_DEVICE, true);
+	if (need > s.raw_cap) {
+		if (s.live)
+			if (int rc = stream_close(t))
+				return rc;
+		HIP_TRY(dev_stream_sync(d));
+		if (d->up_stream)
+			HIP_TRY(hipStreamSynchronize(d->up_stream));
+		for (uint8_t *&r : s.raw) {
+			(void)hipFree(r);
+			r = nullptr;
+		}
+		s.raw_cap = 0;
+		for (uint8_t *&r : s.raw)
+			HIP_TRY(hipMalloc((void **)&r, need));
+		s.raw_cap = need;
+	}
+	const unsigned int slot = (unsigned int)(s.raw_next & 3u);
+	if (s.live && s.raw_gen[slot] == s.gen && s.ctl->done <= s.raw_idx[slot] + 1u) {
+		/* the buffer's last tenant -- four blocks back in this very launch -- and the block behind it, whose first windows reach
+		 * into its tail, are not through yet (a caller far ahead of the GPU): wait for their audio, which comes behind the
+		 * last read of their frames */
+		const auto t0 = std::chrono::steady_clock::now();
+		while (s.ctl->done <= s.raw_idx[slot] + 1u && !s.ctl->err)
+			if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4 * WR_STREAM_WAIT_MS))
+				return fail(WR_ERR_HIP, "streaming launch: block %u did not finish", s.raw_idx[slot] + 1u);
+	}
+	{
+		std::lock_guard<std::mutex> up_guard(*d->upload_lock);
+		if (int rc = dev_up_stream(d))
+			return rc;
+		HIP_TRY(hipMemcpyAsync(s.raw[slot], bytes, need, hipMemcpyHostToDevice, d->up_stream));
+		if (int rc = upload_mark_locked(d, d->up_stream))   /* (wr_dev_wait_uploads: the host block is free again when the copy has run) */
+			return rc;
+	}
+	if (follows) {
+		s.raw_gen[slot] = s.gen;
+		s.raw_idx[slot] = s.count;
+		++s.raw_next;
+		++s.host_blocks;
+		t->last_staging = 3;
+		*took = true;
+		return stream_bell(t, s.raw[slot], true);
+	}
+	if (s.live)
+		if (int rc = stream_close(t))
+			return rc;
+	/* this block opens a launch (or, if it cannot, goes the ordinary way out of the device copy): either waits for the copy */
+	if (!s.raw_ev)
+		HIP_TRY(hipEventCreateWithFlags(&s.raw_ev, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(s.raw_ev, d->up_stream));
+	HIP_TRY(hipStreamWaitEvent(d->stream, s.raw_ev, 0));
+	s.ext = true;
+	bool opened = false;
+	if (int rc = stream_open(t, s.raw[slot], nframes, true, &opened))
+		return rc;
+	s.raw_gen[slot] = opened ? s.gen : 0;
+	s.raw_idx[slot] = 0;
+	++s.raw_next;
+	*took = true;
+	if (opened) {
+		++s.host_blocks;
+		t->last_staging = 3;
+		return WR_OK;
+	}
+	s.ext = false;
+	t->last_staging = 1;
+	return tuner_submit_now(t, s.raw[slot], nframes, WR_DEVICE, true);
+}
+
 /* close the live launch: tell it that no block follows, and advance the host's picture of the tuner by the blocks
  * it was given.  Does not wait: the launch finishes them and ends, stream-ordered work queues behind it. */
 static int stream_close(wr_tuner *t)
@@ -2604,6 +2741,12 @@ static int stream_close(wr_tuner *t)
 	wr_tuner::Stream &s = t->stream;
 	if (!s.live)
 		return WR_OK;
+	if (s.up_pending) {
+		/* doorbells still queued behind their blocks on the upload stream: the count must be final before the stop */
+		HIP_TRY(hipStreamSynchronize(t->dev->up_stream));
+		s.ctl->ready = s.count;
+		s.up_pending = false;
+	}
 	std::atomic_thread_fence(std::memory_order_seq_cst);
 	s.ctl->stop = 1;
 	std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -2651,6 +2794,7 @@ extern "C" int wr_tuner_set_streaming(wr_tuner *t, int enable)
 	if (int rc = tuner_launch_held(t))
 		return rc;
 	t->stream.enabled = enable != 0;
+	t->stream.host_bytes = enable >= 2;
 	return WR_OK;
 }
 
@@ -2664,6 +2808,14 @@ extern "C" int wr_tuner_stream_info(wr_tuner *t, int *live, unsigned long long *
 		*launches = t->stream.gen;
 	if (blocks)
 		*blocks = t->stream.blocks;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_stream_host_blocks(wr_tuner *t, unsigned long long *blocks)
+{
+	if (!t || !blocks)
+		return fail(WR_ERR_ARG, "wr_tuner_stream_host_blocks: bad argument");
+	*blocks = t->stream.host_blocks;
 	return WR_OK;
 }
 
@@ -3292,8 +3444,8 @@ extern "C" int wr_spectrum_destroy(wr_spectrum *s)
 		return WR_OK;
 	(void)hipSetDevice(s->dev->device);
 	(void)dev_stream_sync(s->dev);
-	if (s->dev->up_stream)
-		(void)hipStreamSynchronize(s->dev->up_stream);      /* (a deferred frame's copy may be on its way) */
+	if (s->dev->lazy_stream)
+		(void)hipStreamSynchronize(s->dev->lazy_stream);    /* (a deferred frame's copy may be on its way) */
 	if (s->def_ev)
 		(void)hipEventDestroy(s->def_ev);
 	plan_free(s->plan);
@@ -3358,20 +3510,25 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 			if (s->stage) {
 				/* (a stage that must GROW: whatever still reads the old one goes first -- this closes the launch, once) */
 				HIP_TRY(dev_stream_sync(s->dev));
-				if (d->up_stream)
-					HIP_TRY(hipStreamSynchronize(d->up_stream));
+				if (d->lazy_stream)
+					HIP_TRY(hipStreamSynchronize(d->lazy_stream));
 				HIP_TRY(hipFree(s->stage));
 			}
 			s->stage = nb;
 			s->stage_cap = cap;
 		}
 		std::lock_guard<std::mutex> up_guard(*d->upload_lock);
-		if (int rc = dev_up_stream(d))
-			return rc;
+		if (!d->lazy_stream)
+			HIP_TRY(hipStreamCreateWithFlags(&d->lazy_stream, hipStreamNonBlocking));
 		if (!s->def_ev)
 			HIP_TRY(hipEventCreateWithFlags(&s->def_ev, hipEventDisableTiming));
-		HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * first, keep * 2 * sizeof(float), hipMemcpyDeviceToDevice, d->up_stream));
-		HIP_TRY(hipEventRecord(s->def_ev, d->up_stream));
+		if (d->up_stream) {
+			/* (the block may itself be on its way on the upload stream: behind it) */
+			HIP_TRY(hipEventRecord(s->def_ev, d->up_stream));
+			HIP_TRY(hipStreamWaitEvent(d->lazy_stream, s->def_ev, 0));
+		}
+		HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * first, keep * 2 * sizeof(float), hipMemcpyDeviceToDevice, d->lazy_stream));
+		HIP_TRY(hipEventRecord(s->def_ev, d->lazy_stream));
 		s->frames_done += nfft;
 		s->def_rest = rest;
 		s->pending = rest;                                  /* (logically; physically at stage + 2 * hop until resolved) */

@@ -206,6 +206,9 @@ hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t
 struct WrStreamDesc {                      /* one submitted block */
 	unsigned long long cur;                /* device address of its frames (float pairs, or byte pairs) */
 	unsigned long long audio_host;         /* mapped page-locked ring slot that takes its audio too, or 0 */
+	unsigned int count;                    /* r06: blocks rung with this one = its index + 1: the 4 bytes a device-side doorbell copies
+	                                          into WrStreamDev::ready_up (they must lie in page-locked memory until the copy has run) */
+	unsigned int pad;
 };
 struct WrStreamCtl {                       /* page-locked host memory, mapped: the doorbell and the way back */
 	volatile unsigned int ready;           /* host -> device: blocks submitted so far (monotonic) */
@@ -221,7 +224,9 @@ struct WrStreamCtl {                       /* page-locked host memory, mapped: t
 struct WrStreamDev {                       /* device memory: what the bell wave republishes, and the hand-over counters */
 	unsigned int ready, stop;
 	unsigned long long beat;                   /* the bell's heartbeat: the 100 MHz clock, every time round its loop */
-	unsigned int pad0[28];
+	unsigned int ready_up;                     /* r06: the doorbell's device-side twin, written by a copy on the upload stream behind a
+	                                              block's own copy (blocks out of page-locked host memory); the bell takes the larger */
+	unsigned int pad0[27];
 	/* what the waiting waves poll: one word each, written once per block (never the counters the arrivals land on:
 	 * 4 000 waves arriving on ONE word queue up at 11-13 ns each -- MI355X_MICROARCH.md "fanin" -- and every wave
 	 * that has an arrival in flight waits for it the next time it waits for vector memory) */
@@ -257,6 +262,7 @@ struct WrStreamArgs {
 	/* the block shape (every block of a stream has it) */
 	unsigned long long  nframes;           /* input frames per block, = k1 * d1 */
 	unsigned int        k1, d1, is_u8;
+	unsigned int        ext;               /* r06: blocks may be written by the DMA engine while the launch runs: window loads at agent scope */
 	unsigned int        slots, groups;     /* row stride of the per-slot arrays; lane groups in use */
 	unsigned long long  gmap0, gmap1;      /* which lane groups (as k_tuner_ddc) */
 	unsigned int        kslow;             /* output frames of a block whose window reaches into the block before */

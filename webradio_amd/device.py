@@ -143,13 +143,19 @@ class Tuner:
     def streaming(self, enable=True):
         """Device blocks go to ONE persistent launch through a doorbell (wr_tuner_set_streaming): the same bits,
         no kernel launch per block.  flush() -- or anything else that touches the tuner -- closes the launch."""
-        check(self.lib.wr_tuner_set_streaming(self.h, 1 if enable else 0))
+        check(self.lib.wr_tuner_set_streaming(self.h, int(enable) if enable is not True else 1))
 
     def stream_info(self):
         """(live, launches opened, blocks taken) of the streaming mode"""
         live, launches, blocks = C.c_int(), C.c_ulonglong(), C.c_ulonglong()
         check(self.lib.wr_tuner_stream_info(self.h, C.byref(live), C.byref(launches), C.byref(blocks)))
         return bool(live.value), launches.value, blocks.value
+
+    def stream_host_blocks(self):
+        """blocks streamed out of page-locked host memory so far (wr_tuner_submit_u8(..., WR_HOST) while streaming)"""
+        n = C.c_ulonglong()
+        check(self.lib.wr_tuner_stream_host_blocks(self.h, C.byref(n)))
+        return n.value
 
     def mark_launches(self, enable=True):
         """every launch that reads a submitted block stamps an event on completion (Ring.exchange_after waits for it)"""
@@ -220,6 +226,15 @@ class Tuner:
 
     def submit_device(self, dev_ptr, nframes):
         check(self.lib.wr_tuner_submit(self.h, ptr(dev_ptr), nframes, capi.WR_DEVICE))
+
+    def submit_u8_host(self, raw):
+        """A block in the RTL-SDR byte format in HOST memory (a numpy uint8 array, 2 bytes per frame)."""
+        check(self.lib.wr_tuner_submit_u8(self.h, raw.ctypes.data_as(C.c_void_p), raw.size // 2, capi.WR_HOST))
+
+    def last_staging(self):
+        how = C.c_int()
+        check(self.lib.wr_tuner_last_staging(self.h, C.byref(how)))
+        return how.value
 
     def submit_u8_device(self, dev_ptr, nframes):
         """A block in the RTL-SDR byte format (io/rtlsdrtuner.cxx:106), already in device memory."""

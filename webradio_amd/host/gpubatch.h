@@ -22,6 +22,7 @@
 #define WRHOST_GPUBATCH_H_
 
 #include <stddef.h>
+#include <stdint.h>
 
 #include <mutex>
 #include <string>
