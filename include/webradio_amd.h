@@ -39,13 +39,17 @@
 extern "C" {
 #endif
 
-#define WR_ABI_VERSION   5       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
+#define WR_ABI_VERSION   6       /* 2: wr_tuner_seek, *_n filters, af_gain/squelch, async uploads, ring_ready,
                                     blocks per launch added.  3: wr_ring_* (the halo ring of a time-sharded stream, incl.
                                     wr_ring_exchange_after / wr_tuner_mark_launches), wr_u8_to_f32_from_host, wr_dev_upload_ahead,
                                     wr_dev_wait_uploads_but added; channel filters of 128 / 256 taps accepted (WR_FIR_FUSED_MAX).
                                     4: wr_tune, wr_stage_windows_from_host, wr_tuner_last_staging added.
                                     5: wr_tuner_set_streaming, wr_tuner_stream_info, wr_block_kernel_calls added; audio filters and second
-                                    channel stages of 128 / 256 taps accepted.  Nothing of an earlier version changed or removed */
+                                    channel stages of 128 / 256 taps accepted.
+                                    6: wr_spectrum_lazy_info, wr_tuner_stream_host_blocks, WR_STREAM_MAX_BLOCKS added; wr_tuner_set_streaming
+                                    takes 2 (byte blocks out of page-locked host memory stream too), wr_tuner_last_staging may say 3;
+                                    wr_spectrum_push beside an open streaming launch keeps the frame and transforms it on demand.
+                                    Nothing of an earlier version changed or removed */
 #define WR_FIR_LENGTH    64      /* dsp/lowpass.cxx:39  FIR_LENGTH */
 #define WR_TABLE_SIZE    65536   /* dsp/downconverter.cxx:35 LOOKUP_BITS 16 */
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     missing = [n for n in _declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.wr_abi_version() == capi.WR_ABI_VERSION == 5
+    assert lib.wr_abi_version() == capi.WR_ABI_VERSION == 6
 
 
 def test_python_binding_covers_header():

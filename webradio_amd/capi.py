@@ -16,7 +16,7 @@ WR_AM, WR_FM, WR_USB, WR_LSB = range(4)
 WR_STAGE_CHAN_IQ, WR_STAGE_DEMOD, WR_STAGE_AUDIO = 1, 2, 3
 WR_NCO_SPLIT, WR_NCO_EXACT, WR_NCO_ROTATE = 0, 1, 2
 WR_HOST, WR_DEVICE = 0, 1
-WR_ABI_VERSION = 5            # include/webradio_amd.h
+WR_ABI_VERSION = 6            # include/webradio_amd.h
 WR_STREAM_MAX_BLOCKS = 512    # blocks one streaming launch takes (include/webradio_amd.h)
 WR_FIR_LENGTH = 64
 WR_TABLE_SIZE = 65536
