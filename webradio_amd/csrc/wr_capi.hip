@@ -284,6 +284,9 @@ struct wr_spectrum {
 	 * asks for the spectrum (spectrum_resolve), which is what the reference's own FIXME asks for (io/spectrumsink.cxx:93-94:
 	 * only the most recent frame is observable, waterfallhandler.cxx:56-61 reads it at 5 Hz) */
 	bool deferred = false;
+	float *keep_host = nullptr;    /* page-locked: the kept frames (from the frame's first to the block's last, padded at the front) */
+	size_t keep_cap = 0;           /* frames */
+	size_t def_off = 0, def_keep = 0;   /* the frame begins `def_off` frames into keep_host; `def_keep` frames from there are kept */
 	size_t def_rest = 0;       /* frames behind the deferred frame's hop that belong to the NEXT frame (at stage + 2 * hop) */
 	hipEvent_t def_ev = nullptr;   /* behind that copy */
 	unsigned long long deferred_pushes = 0, resolves = 0;
@@ -3448,6 +3451,7 @@ extern "C" int wr_spectrum_destroy(wr_spectrum *s)
 		(void)hipStreamSynchronize(s->dev->lazy_stream);    /* (a deferred frame's copy may be on its way) */
 	if (s->def_ev)
 		(void)hipEventDestroy(s->def_ev);
+	(void)hipHostFree(s->keep_host);
 	plan_free(s->plan);
 	(void)hipFree(s->stage);
 	(void)hipFree(s->bins);
@@ -3464,7 +3468,18 @@ static int spectrum_resolve(wr_spectrum *s)
 	wr_dev *d = s->dev;
 	DEV_SETTLE(d);
 	hipStream_t st = d->stream;
+	if (s->def_keep > s->stage_cap) {
+		float *nb = nullptr;
+		const size_t cap = s->def_keep + s->n;
+		HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
+		HIP_TRY(hipStreamSynchronize(st));                  /* (whatever still reads the old stage) */
+		if (s->stage)
+			HIP_TRY(hipFree(s->stage));
+		s->stage = nb;
+		s->stage_cap = cap;
+	}
 	HIP_TRY(hipStreamWaitEvent(st, s->def_ev, 0));
+	HIP_TRY(hipMemcpyAsync(s->stage, s->keep_host + 2 * s->def_off, s->def_keep * 2 * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(wrk_fft_frames(st, s->plan, s->stage, s->hop, 1, s->bins, nullptr));
 	const size_t rest = s->def_rest;
 	if (rest) {
@@ -3503,32 +3518,51 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 		const size_t first = (nfft - 1) * s->hop - s->pending;  /* where that frame starts in THIS block */
 		const size_t keep = nframes - first;                    /* = n + what follows the frame's hop ... */
 		const size_t rest = have - nfft * s->hop;               /* ... of which this much belongs to the next frame */
-		if (keep > s->stage_cap) {
-			float *nb = nullptr;
-			const size_t cap = keep + s->n;
-			HIP_TRY(hipMalloc((void **)&nb, cap * 2 * sizeof(float)));
-			if (s->stage) {
-				/* (a stage that must GROW: whatever still reads the old one goes first -- this closes the launch, once) */
-				HIP_TRY(dev_stream_sync(s->dev));
+		/* WHERE it is kept: in page-locked HOST memory, brought there by the DMA engine.  A device-to-device copy is a copy
+		 * KERNEL on this runtime, and a kernel queued beside an open launch is trouble: dispatched while the launch still
+		 * fills the chip it holds workgroup slots the launch's own workgroups wait for, and its waves, behind spinning waves
+		 * of a higher priority, may never finish -- the launch then runs into its deadline (measured: tools/scratch/fe_loop.py,
+		 * 12 of 12 at the device stream's priority, 2 of 8 at the lowest).  Copies of 16 KB or less are kernels too
+		 * (GPU_FORCE_BLIT_COPY_SIZE), so at least 4096 frames (32 KB) of the block's end travel. */
+		const size_t MINF = 4096;
+		const size_t copyf = keep >= MINF ? keep : (nframes >= MINF ? MINF : nframes);
+		const size_t off = copyf - keep;
+		if (copyf * 2 * sizeof(float) <= 16384u) {
+			/* (a block of under 2 K frames: nothing the DMA engine would copy -- the ordinary way, which closes the launch) */
+			if (int rc = spectrum_resolve(s))
+				return rc;
+			goto eager;
+		}
+		if (copyf > s->keep_cap) {
+			if (s->keep_host) {
 				if (d->lazy_stream)
 					HIP_TRY(hipStreamSynchronize(d->lazy_stream));
-				HIP_TRY(hipFree(s->stage));
+				(void)hipHostFree(s->keep_host);
+				s->keep_host = nullptr;
+				s->keep_cap = 0;
 			}
-			s->stage = nb;
-			s->stage_cap = cap;
+			HIP_TRY(hipHostMalloc((void **)&s->keep_host, (copyf + s->n) * 2 * sizeof(float), hipHostMallocDefault));
+			s->keep_cap = copyf + s->n;
 		}
-		std::lock_guard<std::mutex> up_guard(*d->upload_lock);
-		if (!d->lazy_stream)
-			HIP_TRY(hipStreamCreateWithFlags(&d->lazy_stream, hipStreamNonBlocking));
-		if (!s->def_ev)
-			HIP_TRY(hipEventCreateWithFlags(&s->def_ev, hipEventDisableTiming));
-		if (d->up_stream) {
-			/* (the block may itself be on its way on the upload stream: behind it) */
-			HIP_TRY(hipEventRecord(s->def_ev, d->up_stream));
-			HIP_TRY(hipStreamWaitEvent(d->lazy_stream, s->def_ev, 0));
+		{
+			std::lock_guard<std::mutex> up_guard(*d->upload_lock);
+			if (!d->lazy_stream) {
+				int prio_low = 0, prio_high = 0;
+				HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+				HIP_TRY(hipStreamCreateWithPriority(&d->lazy_stream, hipStreamNonBlocking, prio_low));
+			}
+			if (!s->def_ev)
+				HIP_TRY(hipEventCreateWithFlags(&s->def_ev, hipEventDisableTiming));
+			if (d->up_stream) {
+				/* (the block may itself be on its way on the upload stream: behind it) */
+				HIP_TRY(hipEventRecord(s->def_ev, d->up_stream));
+				HIP_TRY(hipStreamWaitEvent(d->lazy_stream, s->def_ev, 0));
+			}
+			HIP_TRY(hipMemcpyAsync(s->keep_host, iq + 2 * (first - off), copyf * 2 * sizeof(float), hipMemcpyDeviceToHost, d->lazy_stream));
+			HIP_TRY(hipEventRecord(s->def_ev, d->lazy_stream));
 		}
-		HIP_TRY(hipMemcpyAsync(s->stage, iq + 2 * first, keep * 2 * sizeof(float), hipMemcpyDeviceToDevice, d->lazy_stream));
-		HIP_TRY(hipEventRecord(s->def_ev, d->lazy_stream));
+		s->def_off = off;
+		s->def_keep = keep;
 		s->frames_done += nfft;
 		s->def_rest = rest;
 		s->pending = rest;                                  /* (logically; physically at stage + 2 * hop until resolved) */
@@ -3536,6 +3570,7 @@ extern "C" int wr_spectrum_push(wr_spectrum *s, const float *iq, size_t nframes,
 		++s->deferred_pushes;
 		return WR_OK;
 	}
+eager:
 	if (s->deferred) {
 		if (inside) {
 			/* this block's newest frame supersedes the deferred one, and reads nothing carried over: drop it */
