@@ -53,7 +53,7 @@ PY
 # the headline's kernel by itself: bench.py --no-secondary, every k_tuner_stream launch in order -- the warm-up's, the 100-block
 # streams of the clock settling, and LAST the timed region's one launch of 60 blocks (what bench.py's own events time)
 rm -rf /tmp/prof_${round}_s
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${round}_s -o s -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/${round}_stream_bench.json 2>/tmp/prof_${round}_s.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${round}_s -o s -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/${round}_stream_bench.json 2>/tmp/prof_${round}_s.log
 python3 - "$round" <<'PY'
 import csv, sys, glob, os, json
 r = sys.argv[1]; R = os.environ['GRAFT_REPO_ROOT']

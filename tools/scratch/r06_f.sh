@@ -25,5 +25,3 @@ with open(R + '/gpurun_out/%s_stream_launches.txt' % r, 'w') as f:
         f.write('the %d launches of the clock settling (100 blocks each): mean %.1f us per block\n' % (len(settle), sum(settle) / len(settle) / 100e3))
 PY
 cat gpurun_out/r06_stream_launches.txt
-bash tools/scratch/ab.sh 200 3 head sc1
-bash tools/scratch/ab.sh 20 3 head sc1
