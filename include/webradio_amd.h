@@ -370,6 +370,10 @@ int wr_tuner_audio_ring_release(wr_tuner *tuner);
 /* *ready = 1 when the oldest queued block's copy has landed: acquire would return without waiting */
 int wr_tuner_audio_ring_ready(wr_tuner *tuner, int *ready);
 int wr_tuner_audio_ring_stats(wr_tuner *tuner, unsigned int *queued, unsigned long long *overruns);
+/* the number the NEXT wr_tuner_submit* of this tuner will carry (the `seq` of its ring entry): submits numbered so far,
+ * whether or not they went through -- a caller that matches ring entries to its own blocks asks here instead of
+ * keeping a count of its own beside the library's.  From the thread that submits. */
+int wr_tuner_submit_count(wr_tuner *tuner, unsigned long long *submits);
 /* LowPass::deinit + init (dsp/lowpass.cxx:118-129, 81-116): both filter histories of the
  * channel become empty again; NCO phase and Demodulator prev_i/q are kept (quirk Q5). */
 int wr_chan_reset_history(wr_tuner *tuner, int chan);

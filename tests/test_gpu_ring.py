@@ -41,8 +41,11 @@ def test_ring_delivers_every_block_in_order(dev):
     want = _expected(dev, blocks)
     t = _tuner(dev)
     t.audio_ring(3)
-    for iq in blocks:
+    assert t.submit_count() == 0
+    for b, iq in enumerate(blocks):
+        assert t.submit_count() == b            # the number this submit's ring entry will carry (what TunerBatch asks for)
         t.submit_host(iq)
+    assert t.submit_count() == 3
     assert t.ring_stats()[0] in (2, 3)          # the last block's post stage may wait for the next launch
     t.flush()
     assert t.ring_stats() == (3, 0)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "wr_tuner_audio_ring_release": (C.c_int, [_vp]),
     "wr_tuner_audio_ring_ready": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "wr_tuner_audio_ring_stats": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_ulonglong)]),
+    "wr_tuner_submit_count": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "wr_chan_get_state": (C.c_int, [_vp, C.c_int, C.POINTER(_u32), _vp]),
     "wr_chan_set_state": (C.c_int, [_vp, C.c_int, _u32, _vp]),
     "wr_tuner_submit": (C.c_int, [_vp, _vp, _sz, C.c_int]),

@@ -3223,6 +3223,14 @@ extern "C" int wr_tuner_audio_ring_stats(wr_tuner *t, unsigned int *queued, unsi
 	return WR_OK;
 }
 
+extern "C" int wr_tuner_submit_count(wr_tuner *t, unsigned long long *submits)
+{
+	if (!t || !submits)
+		return fail(WR_ERR_ARG, "tuner or submits is NULL");
+	*submits = t->submit_seq;                /* (written by submits only: call from the thread that submits) */
+	return WR_OK;
+}
+
 extern "C" int wr_tuner_set_audio_scale(wr_tuner *t, float scale)
 {
 	if (!t)

@@ -201,6 +201,12 @@ class Tuner:
         check(self.lib.wr_tuner_audio_ring_stats(self.h, C.byref(q), C.byref(o)))
         return q.value, o.value
 
+    def submit_count(self):
+        """The number the next submit's ring entry will carry (submits numbered so far, failed ones too)."""
+        n = C.c_ulonglong()
+        check(self.lib.wr_tuner_submit_count(self.h, C.byref(n)))
+        return n.value
+
     def remove_receiver(self, ch):
         check(self.lib.wr_chan_remove(self.h, ch))
 

@@ -537,7 +537,7 @@ TunerBatch::TunerBatch(DspSource *source, wr_dev *dev)
 	: _source(source), _dev(dev), _tuner(NULL), _rate(0), _maxFrames(0), _submittedEpoch(0),
 	  _submitOk(false), _audioPtr(NULL), _ringHeld(false), _audioStride(0), _audioFrames(0), _audioSlots(0),
 	  _late(envUnsigned("WEBRADIO_AUDIO_LATE", 0) != 0), _lateDepth(envUnsigned("WEBRADIO_AUDIO_LATE", 0) >= 2 ? 2u : 1u),
-	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false), _submits(0), _partSeq0(0),
+	  _lateQueued(false), _silence(false), _lateSeq(0), _pieces(envUnsigned("WEBRADIO_PIECES", 2)), _delivered(false), _partSeq0(0),
 	  _streaming(false)
 {
 	if (_pieces < 1 || _late)
@@ -673,7 +673,6 @@ Channel *TunerBatch::enrol(DownConverter *mixer)
 			batch->_streaming = false;
 		batch->_lateQueued = false;
 		batch->_lateSeq = 0;
-		batch->_submits = 0;                    /* a new tuner numbers its submits from 0 again */
 	}
 	int id = -1;
 	if (wr_chan_add(batch->_tuner, &id) != WR_OK) {
@@ -830,16 +829,13 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 			/* on time, the staged block goes through in P parts all the same: a part's audio is put where the audio
 			 * filters' consumers will read it while the parts behind it compute (collectParts) */
 			const unsigned int parts = piecesFor(nframes);
+			wr_tuner_submit_count(_tuner, &_partSeq0);      /* part p's ring entry will be numbered _partSeq0 + p: the library's count */
 			for (unsigned int p = 0; p < parts; p++)
 				if (wr_tuner_submit(_tuner, staged + (size_t)2 * (nframes / parts) * p, nframes / parts, WR_DEVICE) != WR_OK) {
 					LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 					if (p)
 						drainRing();                /* the parts that did go out must not be taken for the next block's */
 					return false;
-				} else {
-					if (!p)
-						_partSeq0 = _submits;
-					++_submits;
 				}
 			if (parts == 1)
 				return afterSubmit(false);
@@ -854,6 +850,7 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 	}
 	unsigned int P = pushed ? 1u : piecesFor(nframes);
 	if (P > 1) {
+		wr_tuner_submit_count(_tuner, &_partSeq0);
 		for (unsigned int p = 0; p < P; p++) {
 			const float *part = stagePiece(_source, _dev, tunerBuffer, P, p);
 			if (!part) {
@@ -869,9 +866,6 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 					drainRing();
 				return false;
 			}
-			if (!p)
-				_partSeq0 = _submits;
-			++_submits;
 		}
 	}
 	if (P > 1) {
@@ -906,7 +900,6 @@ bool TunerBatch::submitOnce(const vector<sample_t> &tunerBuffer, unsigned int nf
 		LOG_ERROR("wr_tuner_submit: %s\n", wr_last_error());
 		return false;
 	}
-	++_submits;
 	return afterSubmit(pushed);
 }
 

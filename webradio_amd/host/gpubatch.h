@@ -162,8 +162,8 @@ private:
 	unsigned int _pieces;             /* WEBRADIO_PIECES: parts an on-time block is put through in (see submitOnce) */
 	bool _delivered;                  /* this block's audio already lies in the audio filters' output vectors */
 	std::mutex _lock;
-	unsigned long long _submits;      /* wr_tuner_submit calls that went through on _tuner: the tuner numbers its ring entries so */
-	unsigned long long _partSeq0;     /* ... the first part of the block collectParts is about to collect */
+	unsigned long long _partSeq0;     /* the number the tuner gave the first part of the block collectParts is about to collect
+	                                     (wr_tuner_submit_count before the parts went out: the library's own count) */
 	bool _streaming;                  /* the source produces its blocks in device memory (DeviceBlock): wr_tuner_set_streaming */
 };
 
