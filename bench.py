@@ -449,6 +449,65 @@ def frontend_secondary(torch, dev, tuner, blocks, n, steps, streaming_ok):
     return out
 
 
+def power_secondary(torch, tuner, blocks, n, seconds=2.5):
+    """What the package draws while the headline's kernel runs back to back (rocm-smi, sampled from a thread beside
+    ~2.5 s of 400-block streaming launches; outside every timed region).  r06: the launch sits at the package's power
+    limit -- the resource that binds it (profiles/r06_power.txt).  None where rocm-smi says nothing."""
+    import re
+    import subprocess
+    import threading
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], [False]
+
+    def read():
+        o = subprocess.run([smi, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+        w = re.findall(r'Package Power \(W\)": "([0-9.]+)"', o)
+        c = re.findall(r'"sclk clock speed:": "\(([0-9]+)Mhz\)"', o)
+        return (time.perf_counter(), float(w[0]) if w else None, int(c[0]) if c else None)
+
+    def sampler():
+        while not stop[0]:
+            try:
+                samples.append(read())
+            except Exception:
+                pass
+            time.sleep(0.1)
+
+    try:
+        tuner.flush()
+        torch.cuda.synchronize()
+        time.sleep(0.5)
+        idle = read()
+        th = threading.Thread(target=sampler)
+        th.start()
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < seconds:
+            for i in range(400):
+                tuner.submit_device(blocks[i % len(blocks)], n)
+            tuner.flush()
+            torch.cuda.synchronize()
+            done += 400
+        t1 = time.perf_counter()
+        stop[0] = True
+        th.join()
+        w = [x[1] for x in samples if x[1] is not None and t0 + 0.6 < x[0] <= t1]
+        c = [x[2] for x in samples if x[2] is not None and t0 + 0.6 < x[0] <= t1]
+        if not w:
+            return None
+        return {"package_w": round(sum(w) / len(w), 1), "package_w_max": max(w), "samples": len(w),
+                "sclk_mhz": round(sum(c) / len(c)) if c else None, "idle_w": idle[1], "idle_sclk_mhz": idle[2],
+                "limit_w": 1400, "us_per_block": round((t1 - t0) / done * 1e6, 2),
+                "how": "rocm-smi --showpower --showclocks beside %.1f s of 400-block streaming launches, samples of the first 0.6 s dropped" % seconds,
+                "reading": "the launch draws what the package may (MI355X: 1400 W) and the shader clock gives way (2.4 GHz idle): "
+                           "the kernel's time is its energy -- DESIGN.md 3.1, profiles/r06_power.txt"}
+    except Exception:
+        stop[0] = True
+        return None
+
+
 def host_fed_secondary():
     """The drop-in path with the block in HOST memory (PCIe inside the timing; never `value`): tests/cxx/host_bench --
     one FrontEnd, 256 Receivers wired as radio.cxx wires them, Radio::run() pumping 4 000 000-frame blocks through the C++
@@ -942,12 +1001,13 @@ def main():
             streamed = other_mode(True, 1, k1)
 
     # BASELINE config 3 off the same resident stream, outside the timed region of the headline
-    c3 = c1 = fe = None
+    c3 = c1 = fe = pw = None
     if world == 1 and not args.no_secondary:
         tuner.flush()
         torch.cuda.synchronize()
         c3 = c3_secondary(torch, dev, blocks, n, max(nb, min(args.steps, 60)), args.settle_ms)
         fe = frontend_secondary(torch, dev, tuner, blocks, n, args.steps, streaming)
+        pw = power_secondary(torch, tuner, blocks, n) if streaming else None
         c1 = c1_secondary(torch, dev, 400, args.settle_ms)
 
     if rank == 0:
@@ -1041,7 +1101,10 @@ def main():
                         "(150 G wave-taps/s = 1.05 T wave-instructions/s with two recurrences per wave, "
                         "profiles/r03_ubench_tap.txt) the 2.56 M wave-taps of a block alone take 17.1 us: the "
                         "algorithmic 34.05 MB per block then are 1.99 TB/s = 24.9 % of the 8 TB/s roof -- the ceiling of "
-                        "this formulation (29 % at the nominal 1.22 T/s); `frac` is to be read against that",
+                        "this formulation (29 % at the nominal 1.22 T/s); `frac` is to be read against that.  r06: the launch "
+                        "runs at the package's 1400 W limit with the shader clock giving way (`power`, profiles/r06_power.txt): "
+                        "what it takes per block is what it spends per block, and the channel IQ's way to memory and back is "
+                        "4 us of its 30",
                 "valu_ceiling_frac_of_hbm_roof": 0.249,
                 # the binding resource, for context: VALU wave-instructions the DDC taps need (7 per
                 # channel-tap in the ROTATE mode, 64 lanes per wave) against the rate the same
@@ -1074,6 +1137,8 @@ def main():
                 out["secondary"]["frontend"] = fe
             if c1 is not None:
                 out["secondary"]["c1"] = c1
+            if pw is not None:
+                out["roofline"]["power"] = pw
             hf = host_fed_secondary()
             if hf is not None:
                 out["secondary"]["host_fed"] = hf

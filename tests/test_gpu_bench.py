@@ -41,6 +41,8 @@ def test_single_gpu_line():
     assert j["config"]["streaming"] is True and j["config"]["blocks_per_launch"] == 1
     assert r["launches_timed"] == 1 and r["frames_per_launch"] == 4.0e6 * 40
     assert r["kernel_ms"] <= j["ms_per_step"] * 40 * 1.05           # the one launch IS the timed region's GPU work
+    if r.get("power"):                                               # r06: what the package draws under the headline's kernel (rocm-smi)
+        assert 300.0 < r["power"]["package_w"] <= r["power"]["package_w_max"] < 1600.0 and r["power"]["samples"] >= 3
     one = j["secondary"]["c2_one_block_per_launch"]                  # a kernel launch per block: r01-r04's like-for-like figure
     assert one["streaming"] is False and one["blocks_per_launch"] == 1 and one["value"] > 0
     assert one["kernel_ms"] <= one["ms_per_step"] * 1.05 and j["value_one_block_per_launch"] == one["value"]

@@ -202,7 +202,14 @@ hipError_t wrk_gather_rows(hipStream_t st, const float *src, size_t rows, size_t
  * its last channel-IQ row is out, whether or not another block follows (dsp/dspblock.cxx:169-212: a block's output
  * leaves within its own run()).  See k_tuner_stream in wr_kernels.hip. ---- */
 #define WR_STREAM_MAXJ   WR_STREAM_MAX_BLOCKS             /* blocks one streaming launch takes at most (the host then opens the next) */
-#define WR_STREAM_RING   8u                /* blocks of channel IQ the ring between the DDC waves and the post stage holds */
+#ifndef WR_STREAM_RING
+#define WR_STREAM_RING   6u                /* blocks of channel IQ the ring between the DDC waves and the post stage holds.  r06: 6,
+                                              not 8 -- the launch runs at the package's power limit (profiles/r06_power.txt) and the
+                                              channel IQ's way to memory and back is a seventh of what it spends; 123 MB of ring
+                                              (C2) beside the input windows stay in the 256 MB Infinity Cache where 164 MB did not
+                                              quite: 29.8-30.0 against 30.5-30.7 us per block, 33.0-33.9 against 34.2-34.4 at the
+                                              driver's 20 steps, two boxes; 5 and 4 leave the DDC too little room to run ahead */
+#endif
 struct WrStreamDesc {                      /* one submitted block */
 	unsigned long long cur;                /* device address of its frames (float pairs, or byte pairs) */
 	unsigned long long audio_host;         /* mapped page-locked ring slot that takes its audio too, or 0 */
@@ -239,6 +246,9 @@ struct WrStreamDev {                       /* device memory: what the bell wave 
 	                                              there on the DDC workgroups, which have nothing left to do, take post tasks too */
 	unsigned int pad1[29];
 	unsigned int post_done[WR_STREAM_MAXJ];    /* post-stage TASKS of block j that are finished (their stores released) */
+	unsigned int post_fine[WR_STREAM_MAXJ];    /* r06: 1 = block j's post stage goes in the SHORT runs of tiles (WrStreamArgs::drain_run): the watcher
+	                                              decides when the block's channel IQ is complete -- short unless two further blocks are rung
+	                                              already (the host is ahead: what counts is what a block costs, not how soon its audio is out) */
 	unsigned int post_ticket[WR_STREAM_MAXJ];  /* the next task of block j to hand out (blocks from drain_from on) */
 	unsigned int ddc_done[WR_STREAM_MAXJ][WR_STREAM_SHARDS][32];   /* lane-group units of block j whose channel IQ is in memory:
 	                                              the sum over the shards' first words (wave w arrives on shard w mod SHARDS) */
@@ -281,6 +291,8 @@ struct WrStreamArgs {
 	float              *audio_bufs[4];     /* WrGroupDev::audio_set, from the current one on: block j's device audio goes to audio_bufs[j & 3] */
 	/* the post stage: what wrk_post_args gives for ONE block, and the two ping-pong state sets */
 	WrPostArgs          post;
+	unsigned int        drain_run, drain_ntiles;   /* r06: `post.run` / `post.ntiles` for the blocks that go in short runs (WrStreamDev::post_fine:
+	                                          a host-paced stream, and a closed stream's last blocks) -- there a block's end is latency, not energy */
 	const float        *prev_iq[2];
 	float              *dem[2];
 	int                 parity0;           /* set block 0 reads */

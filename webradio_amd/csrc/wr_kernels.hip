@@ -646,7 +646,13 @@ __device__ __forceinline__ void post_role(const WrPostArgs &A, unsigned int bx, 
 				 * block's first and last): the loads of POST_LB rows go out together, nothing to
 				 * decide per row -- the stage phase is a chain of memory round trips, and one per
 				 * row made the post workgroups the last to finish */
+#ifdef POST_SMALL_READS
+				/* (development, results wrong: every tile reads the same few hundred rows -- what the channel IQ's way back
+				 * from memory costs, profiles/r06_power.txt) */
+				const float2 *__restrict__ src = chan_iq + ((r0 - HIST) & 127u) * slots + s;
+#else
 				const float2 *__restrict__ src = chan_iq + (r0 - HIST) * slots + s;
+#endif
 				for (unsigned int r = beg; r < end; r += POST_LB) {
 					float2 z[POST_LB + 1u];
 					z[0] = src[((size_t)r - 1u) * slots];
