@@ -954,6 +954,7 @@ def main():
     # (an event record between two launches costs the stream ~10 us: as few pairs as the stride allows -- at the driver's 20 steps
     # ONE pair around the five launches, recorded before the first and behind the last)
     stride = max(1, min(args.profile_stride, n_launches))
+    long0 = tuner.stream_long_blocks()
     elapsed, launches, ddc_ms = timed_steps(args.steps, stride)
     frames_per_launch = float(n) * args.steps / n_launches
 
@@ -969,6 +970,7 @@ def main():
     # sanity: the audio of a carrier channel is finite and non-trivial (nothing was skipped)
     a = tuner.fetch(0, capi.WR_STAGE_AUDIO, n * B)
     assert a.size and a.size % (n // 400 // 5) == 0 and bool((a == a).all()) and float(abs(a).max()) > 0.0
+    long_blocks = tuner.stream_long_blocks() - long0     # (the fetch above looked at the closed launch: the count is in)
 
     # the same job the other ways the library can run it, outside the headline's timed region: a kernel launch per block
     # (r01-r04's like-for-like figure) and four held blocks per launch (r02-r04's headline: up to 120 ms of added audio latency)
@@ -1063,6 +1065,8 @@ def main():
                                   "(its ramp and tail are in `value`); every block's demod + audio filter run as soon as its "
                                   "last channel-rate frame is out -- no added latency, same bits as a launch per block "
                                   "(tests/test_gpu_stream.py)" if streaming else None,
+                "post_stage_long_run_blocks": long_blocks if streaming else None,   # of the K timed blocks: demod + audio filter in runs of 5 tiles
+                                                                                    # (the host was two blocks ahead); the rest -- the stream's end -- in runs of 2
                 "blocks_per_launch": B,
                 "blocks_per_launch_note": None if B == 1 else
                                           "wr_tuner_set_blocks_per_launch(%d): the tuner holds consecutive blocks and "

@@ -46,7 +46,7 @@ extern "C" {
                                     4: wr_tune, wr_stage_windows_from_host, wr_tuner_last_staging added.
                                     5: wr_tuner_set_streaming, wr_tuner_stream_info, wr_block_kernel_calls added; audio filters and second
                                     channel stages of 128 / 256 taps accepted.
-                                    6: wr_spectrum_lazy_info, wr_tuner_stream_host_blocks, WR_STREAM_MAX_BLOCKS added; wr_tuner_set_streaming
+                                    6: wr_spectrum_lazy_info, wr_tuner_stream_host_blocks, wr_tuner_stream_long_blocks, wr_tuner_submit_count, WR_STREAM_MAX_BLOCKS added; wr_tuner_set_streaming
                                     takes 2 (byte blocks out of page-locked host memory stream too), wr_tuner_last_staging may say 3;
                                     wr_spectrum_push beside an open streaming launch keeps the frame and transforms it on demand.
                                     Nothing of an earlier version changed or removed */
@@ -475,6 +475,11 @@ int wr_tuner_set_streaming(wr_tuner *tuner, int enable);
 int wr_tuner_stream_info(wr_tuner *tuner, int *live, unsigned long long *launches, unsigned long long *blocks);
 /* r06: of those blocks, how many came out of page-locked HOST memory (wr_tuner_submit_u8(..., WR_HOST), see wr_tuner_last_staging) */
 int wr_tuner_stream_host_blocks(wr_tuner *tuner, unsigned long long *blocks);
+/* r06: of the blocks of launches that are over and looked at (any fetch or sync after the close), how many had their demodulator + audio
+ * filter run in LONG runs of tiles: the launch cuts a block's post stage into fewer, longer tasks when two further blocks are rung
+ * already -- the host is ahead, the launch runs at the package's power limit and longer runs demodulate and read fewer rows twice --
+ * and into short ones when the stream is host-paced or ends (a block's audio is out sooner).  Same bits either way. */
+int wr_tuner_stream_long_blocks(wr_tuner *tuner, unsigned long long *blocks);
 
 /* Profiling hook, the analogue of the reference's per-block profiler
  * (DspBlock::nsPerFrameOne, dsp/dspblock.h:69-75), with HIP events on the tuner's stream.

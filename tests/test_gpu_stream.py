@@ -362,10 +362,15 @@ def test_byte_blocks_out_of_page_locked_host_memory_stream(dev, page_locked, on_
     assert np.array_equal(_bits(a0[:nch]), _bits(want[0][1][:nch]))
 
 
-def test_streaming_at_c2_size(dev):
+@pytest.mark.parametrize("paced", [False, True], ids=["host-ahead", "host-paced"])
+def test_streaming_at_c2_size(dev, paced):
     """bench.py's configuration: 256 receivers, 4 M-frame blocks off 100 Msps.  Ten resident blocks through a tuner
     that launches each on its own and through ONE streaming launch: every audio sample of every receiver is the
-    same bits, and so is what a further block gives after the stream."""
+    same bits, and so is what a further block gives after the stream.
+    r06: with the host AHEAD (all blocks rung at once) the launch cuts a block's post stage into long runs of tiles, with a
+    host-PACED stream (a block rung when the one before is long done) into short ones (wr_tuner_stream_long_blocks) --
+    the same bits either way."""
+    import time
     import torch
     c2 = synth.C2
     fs, n = c2["input_rate"], c2["block_frames"]
@@ -380,23 +385,29 @@ def test_streaming_at_c2_size(dev):
             t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
         t.audio_ring(nblk)
         t.streaming(stream)
-        for b in range(nblk - 1):
-            t.submit_device(x[2 * n * b: 2 * n * (b + 1)], n)
-        t.flush()
-        out = [a for _, a in _drain(t, nblk - 1)]
+        out = []
+        for rep in range(2):        # (twice: the first pass page-locks the ring's slots as it goes, which paces it whatever the host does)
+            for b in range(nblk - 1):
+                t.submit_device(x[2 * n * b: 2 * n * (b + 1)], n)
+                if paced and stream:
+                    time.sleep(0.002)                           # (a block takes the launch 30 us: it idles till the next ring)
+            t.flush()
+            out += [a for _, a in _drain(t, nblk - 1)]
         #  the device audio array after the close holds the LAST streamed block's audio, all 256 rows
         assert np.array_equal(_bits(t.fetch_audio_all()), _bits(out[-1]))
         t.streaming(False)
         t.submit_device(x[2 * n * (nblk - 1): 2 * n * nblk], n)
         out.append(t.fetch_audio_all().copy())
-        info = t.stream_info()
+        info = t.stream_info() + (t.stream_long_blocks(),)
         t.destroy()
         return np.concatenate(out, axis=1), info
 
     one, _ = run(False)
     many, info = run(True)
-    assert info[1] == 1 and info[2] == nblk - 1
-    assert one.shape == many.shape == (256, nblk * n // 400 // 5)
+    assert info[1] == 2 and info[2] == 2 * (nblk - 1)
+    # nine blocks rung at once: all but the last two (the drain) find two further blocks rung; paced, none does
+    assert (info[3] == 0) if paced else (nblk - 3 <= info[3] <= 2 * (nblk - 3)), info
+    assert one.shape == many.shape == (256, (2 * nblk - 1) * n // 400 // 5)
     assert np.array_equal(_bits(one), _bits(many))
     assert float(np.abs(one[::4]).max()) > 0.0                  # the carrier channels carry audio
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "wr_tuner_set_streaming": (C.c_int, [_vp, C.c_int]),
     "wr_tuner_stream_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "wr_tuner_stream_host_blocks": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
+    "wr_tuner_stream_long_blocks": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "wr_tuner_seek": (C.c_int, [_vp, C.c_ulonglong]),
     "wr_tuner_audio_ring": (C.c_int, [_vp, _u32]),
     "wr_tuner_audio_ring_acquire": (C.c_int, [_vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),

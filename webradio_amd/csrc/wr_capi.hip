@@ -266,6 +266,7 @@ struct wr_tuner {
 		bool ext = false;                  /* the live launch takes such blocks (WrStreamArgs::ext) */
 		bool up_pending = false;           /* doorbells of the live launch are queued on the upload stream */
 		unsigned long long host_blocks = 0;    /* blocks streamed out of host memory so far */
+		unsigned long long long_blocks = 0;    /* blocks of checked launches whose post stage went in long runs (WrStreamCtl::long_blocks) */
 	} stream;
 };
 
@@ -2351,6 +2352,8 @@ static int stream_check(wr_tuner *t)
 	if (!s.unchecked)
 		return WR_OK;
 	s.unchecked = false;
+	s.long_blocks += s.ctl->long_blocks;
+	s.ctl->long_blocks = 0;
 	if (s.ctl->err)
 		return fail(WR_ERR_HIP, "streaming launch: a wait inside the launch ran into its deadline (code %u)", s.ctl->err);
 	if (s.ctl->final_blocks != s.count)
@@ -2604,6 +2607,7 @@ static int stream_open(wr_tuner *t, const void *iq, size_t nframes, bool u8, boo
 	s.ctl->stop = 0;
 	s.ctl->done = 0;
 	s.ctl->final_blocks = 0;
+	s.ctl->long_blocks = 0;
 	s.ctl->err = 0;
 	s.ctl->self_closed = 0;
 	s.desc[0].cur = (unsigned long long)(uintptr_t)iq;
@@ -2811,6 +2815,14 @@ extern "C" int wr_tuner_stream_info(wr_tuner *t, int *live, unsigned long long *
 		*launches = t->stream.gen;
 	if (blocks)
 		*blocks = t->stream.blocks;
+	return WR_OK;
+}
+
+extern "C" int wr_tuner_stream_long_blocks(wr_tuner *t, unsigned long long *blocks)
+{
+	if (!t || !blocks)
+		return fail(WR_ERR_ARG, "wr_tuner_stream_long_blocks: bad argument");
+	*blocks = t->stream.long_blocks;
 	return WR_OK;
 }
 

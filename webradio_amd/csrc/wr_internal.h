@@ -225,7 +225,8 @@ struct WrStreamCtl {                       /* page-locked host memory, mapped: t
 	volatile unsigned int final_blocks;    /* device -> host, at exit: blocks the launch processed */
 	volatile unsigned int err;             /* device -> host: non-zero = a wait ran into its deadline (WR_STREAM_ERR_*) */
 	volatile unsigned int self_closed;     /* device -> host: the doorbell was silent for `idle_ticks`: closed on its own */
-	volatile unsigned int pad1[12];
+	volatile unsigned int long_blocks;     /* device -> host (r06): blocks whose post stage went in the LONG runs of tiles (the host was ahead) */
+	volatile unsigned int pad1[11];
 };
 #define WR_STREAM_SHARDS 16u               /* counters a block's DDC completions are spread over, a cache line each */
 struct WrStreamDev {                       /* device memory: what the bell wave republishes, and the hand-over counters */

@@ -157,6 +157,12 @@ class Tuner:
         check(self.lib.wr_tuner_stream_host_blocks(self.h, C.byref(n)))
         return n.value
 
+    def stream_long_blocks(self):
+        """blocks (of launches that are over and checked) whose post stage ran in long runs of tiles: the host was ahead"""
+        n = C.c_ulonglong()
+        check(self.lib.wr_tuner_stream_long_blocks(self.h, C.byref(n)))
+        return n.value
+
     def mark_launches(self, enable=True):
         """every launch that reads a submitted block stamps an event on completion (Ring.exchange_after waits for it)"""
         check(self.lib.wr_tuner_mark_launches(self.h, 1 if enable else 0))
