@@ -954,6 +954,8 @@ def main():
     # (an event record between two launches costs the stream ~10 us: as few pairs as the stride allows -- at the driver's 20 steps
     # ONE pair around the five launches, recorded before the first and behind the last)
     stride = max(1, min(args.profile_stride, n_launches))
+    tuner.flush()
+    dev.sync()                                           # (looks at the launch the settling steps left closed: its count is in)
     long0 = tuner.stream_long_blocks()
     elapsed, launches, ddc_ms = timed_steps(args.steps, stride)
     frames_per_launch = float(n) * args.steps / n_launches
