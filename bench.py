@@ -955,7 +955,8 @@ def main():
     # ONE pair around the five launches, recorded before the first and behind the last)
     stride = max(1, min(args.profile_stride, n_launches))
     tuner.flush()
-    tuner.fetch(0, capi.WR_STAGE_AUDIO, n * B)           # (a fetch looks at the launch the settling steps left closed: its count is in)
+    if tuner.stream_info()[2]:                           # (not with --warmup 0 --settle-ms 0: nothing to fetch yet)
+        tuner.fetch(0, capi.WR_STAGE_AUDIO, n * B)       # a fetch looks at the launch the settling steps left closed: its count is in
     long0 = tuner.stream_long_blocks()
     elapsed, launches, ddc_ms = timed_steps(args.steps, stride)
     frames_per_launch = float(n) * args.steps / n_launches
