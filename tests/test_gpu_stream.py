@@ -362,14 +362,15 @@ def test_byte_blocks_out_of_page_locked_host_memory_stream(dev, page_locked, on_
     assert np.array_equal(_bits(a0[:nch]), _bits(want[0][1][:nch]))
 
 
-@pytest.mark.parametrize("paced", [False, True], ids=["host-ahead", "host-paced"])
-def test_streaming_at_c2_size(dev, paced):
+@pytest.mark.parametrize("paced,mixed", [(False, False), (True, False), (False, True)], ids=["host-ahead", "host-paced", "host-ahead-all-modes"])
+def test_streaming_at_c2_size(dev, paced, mixed):
     """bench.py's configuration: 256 receivers, 4 M-frame blocks off 100 Msps.  Ten resident blocks through a tuner
     that launches each on its own and through ONE streaming launch: every audio sample of every receiver is the
     same bits, and so is what a further block gives after the stream.
     r06: with the host AHEAD (all blocks rung at once) the launch cuts a block's post stage into long runs of tiles, with a
     host-PACED stream (a block rung when the one before is long done) into short ones (wr_tuner_stream_long_blocks) --
-    the same bits either way."""
+    the same bits either way.  `all-modes`: receiver c demodulates AM / FM / USB / LSB by c mod 4 -- the long runs with every
+    demodulator (the seeded fuzz streams are too small to be cut into long runs)."""
     import time
     import torch
     c2 = synth.C2
@@ -381,8 +382,9 @@ def test_streaming_at_c2_size(dev, paced):
 
     def run(stream):
         t = Tuner(dev, fs, 256, n, capi.WR_NCO_ROTATE)
-        for f in ifs:
-            t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], capi.WR_FM, c2["audio_passband"], c2["audio_rate"])
+        for c, f in enumerate(ifs):
+            t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], (capi.WR_AM, capi.WR_FM, capi.WR_USB, capi.WR_LSB)[c % 4] if mixed else capi.WR_FM,
+                           c2["audio_passband"], c2["audio_rate"])
         t.audio_ring(nblk)
         t.streaming(stream)
         out = []
@@ -409,7 +411,8 @@ def test_streaming_at_c2_size(dev, paced):
     assert (info[3] == 0) if paced else (nblk - 3 <= info[3] <= 2 * (nblk - 3)), info
     assert one.shape == many.shape == (256, (2 * nblk - 1) * n // 400 // 5)
     assert np.array_equal(_bits(one), _bits(many))
-    assert float(np.abs(one[::4]).max()) > 0.0                  # the carrier channels carry audio
+    assert float(np.abs(one[::4]).max()) > 0.0                  # the carrier channels carry audio (every 4th: AM in `all-modes`)
+    assert not mixed or float(np.abs(one[1::4]).max()) > 0.0
 
 
 RATES = [(2_000_000, 250_000, 50_000), (2_400_000, 240_000, 48_000), (1_920_000, 240_000, 24_000), (2_048_000, 256_000, 32_000)]
