@@ -1111,7 +1111,7 @@ def main():
                         "this formulation (29 % at the nominal 1.22 T/s); `frac` is to be read against that.  r06: the launch "
                         "runs at the package's 1400 W limit with the shader clock giving way (`power`, profiles/r06_power.txt): "
                         "what it takes per block is what it spends per block, and the channel IQ's way to memory and back is "
-                        "4 us of its 30",
+                        "4 us of its 28 (it was 30 before the ring of channel IQ shrank to what the Infinity Cache holds and the post stage took to longer runs)",
                 "valu_ceiling_frac_of_hbm_roof": 0.249,
                 # the binding resource, for context: VALU wave-instructions the DDC taps need (7 per
                 # channel-tap in the ROTATE mode, 64 lanes per wave) against the rate the same
