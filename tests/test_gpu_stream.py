@@ -385,6 +385,11 @@ def test_streaming_at_c2_size(dev, paced, mixed):
         for c, f in enumerate(ifs):
             t.add_receiver(f, c2["chan_passband"], c2["chan_rate"], (capi.WR_AM, capi.WR_FM, capi.WR_USB, capi.WR_LSB)[c % 4] if mixed else capi.WR_FM,
                            c2["audio_passband"], c2["audio_rate"])
+        if mixed:                                               # af_gain and squelch ride in the post stage's audio write (f-4)
+            for c in range(0, 256, 8):
+                t.set_af_gain(c, -6.0 + 0.25 * c)
+            for c in range(4, 256, 16):
+                t.set_squelch(c, -60.0 + 0.1 * c)
         t.audio_ring(nblk)
         t.streaming(stream)
         out = []
